@@ -1,0 +1,200 @@
+/*
+ * spectrum_hip.h - C ABI of libspectrum_hip.so, the gfx950 (MI355X) kernel library
+ * behind the spectrum-vae model hot path.
+ *
+ * The reference (tomsasani/spectrum-vae) has no FFI: its model classes call
+ * tf.keras layers, which dispatch to TensorFlow kernels.  Each entry point below
+ * replaces one of those tf.keras layer / loss / optimizer call sites; the comment on
+ * every declaration cites the reference call sites it stands in for.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (no allocation, no ownership
+ *    transfer); workspaces are sized by the matching *_workspace_bytes query;
+ *  - every call only enqueues work on `stream` (a hipStream_t) and returns at once;
+ *  - return value 0 = ok, negative = SV_E_* code; sv_last_error() gives the text of the
+ *    calling thread's last failure;
+ *  - activations are NHWC, Conv2D kernels HWIO (kh,kw,Cin,Cout), Conv2DTranspose kernels
+ *    (kh,kw,Cout,Cin), Dense kernels (in,out): the tf.keras layouts;
+ *  - `dtype` selects the storage type of activations/weights (SV_F32; SV_BF16 where the
+ *    declaration says so); accumulation is always f32.
+ */
+#ifndef SPECTRUM_HIP_H
+#define SPECTRUM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sv_stream_t; /* hipStream_t */
+
+enum { SV_OK = 0, SV_E_INVALID = -1, SV_E_UNSUPPORTED = -2, SV_E_LAUNCH = -3, SV_E_WORKSPACE = -4 };
+enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1, SV_ACT_ELU = 2, SV_ACT_LRELU = 3, SV_ACT_TANH = 4, SV_ACT_SIGMOID = 5 };
+enum { SV_F32 = 0, SV_BF16 = 1 };
+
+/* Geometry of one cross-correlation y[n,oh,ow,co] = sum x[n, oh*sh+kh-pad_t, ow*sw+kw-pad_l, ci] w[kh,kw,ci,co].
+ * H, W are the LOGICAL input extent; when up_h/up_w > 1 the stored tensor is (H/up_h, W/up_w) and is read
+ * through nearest-neighbour repetition (UpSampling2D folded into the gather, autoencoder.py:364,503).
+ * For the transposed entry points the same struct describes the forward conv that the layer is the
+ * input-gradient of: (H,W,Cin) is the transposed layer's OUTPUT, (Ho,Wo,Cout) its INPUT. */
+typedef struct sv_conv_geom {
+    int32_t N, H, W, Cin;
+    int32_t KH, KW, SH, SW;
+    int32_t pad_t, pad_l;
+    int32_t Ho, Wo, Cout;
+    int32_t up_h, up_w;
+} sv_conv_geom;
+
+const char* sv_last_error(void);
+int sv_version(void);
+
+/* ---- Conv2D (autoencoder.py:443,510,521; unet.py:40; context_encoder.py:57,72,172,185,230,242,334,346) */
+/* y = act(conv(x, w) + bias); bias may be NULL. */
+int sv_conv2d_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,
+                  int act, float alpha, int dtype, sv_stream_t stream);
+/* dx = conv input-gradient of dz (dz = dL/d pre-activation). */
+int sv_conv2d_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* dx, int dtype, sv_stream_t stream);
+/* dw (+)= conv kernel-gradient; accumulate != 0 adds into dw instead of overwriting it. */
+size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g);
+int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate,
+                    void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
+
+/* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
+/* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */
+int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,
+                            int act, float alpha, int dtype, sv_stream_t stream);
+int sv_conv2d_transpose_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* dx, int dtype,
+                              sv_stream_t stream);
+int sv_conv2d_transpose_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate,
+                              void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
+
+/* ---- activation layers and the backward of fused activations
+ *      (LeakyReLU unet.py:53,79; activation= arguments of every Conv2D/Dense above) */
+int sv_act_fwd(const void* x, void* y, int64_t n, int act, float alpha, int dtype, sv_stream_t stream);
+/* dz = dy * act'(y) expressed through the activation OUTPUT y; if db != NULL also db[c] (+)= sum_rows dz[r,c]. */
+/* Workspace (bytes) of the per-channel reductions below: act_bwd (when db != NULL), bias_grad, batchnorm. */
+size_t sv_colreduce_workspace_bytes(int64_t rows, int C);
+int sv_act_bwd(const void* dy, const void* y, void* dz, void* db, int db_accumulate, int64_t rows, int C,
+               int act, float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
+/* db[c] (+)= sum_rows dz[r,c] */
+int sv_bias_grad(const void* dz, void* db, int accumulate, int64_t rows, int C, void* workspace,
+                 size_t workspace_bytes, int dtype, sv_stream_t stream);
+
+/* ---- MaxPooling2D, stride == pool (autoencoder.py:33,98,167,319,451); idx is uint8 [N,Ho,Wo,C] = kh*pw+kw of
+ *      the first maximum in window scan order */
+int sv_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int ph, int pw, int pad_t,
+                     int pad_l, int Ho, int Wo, int dtype, sv_stream_t stream);
+int sv_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int ph, int pw,
+                     int pad_t, int pad_l, int Ho, int Wo, int dtype, sv_stream_t stream);
+
+/* ---- UpSampling2D nearest (autoencoder.py:364,503); (H,W) is the INPUT extent */
+int sv_upsample2d_fwd(const void* x, void* y, int N, int H, int W, int C, int uh, int uw, int dtype, sv_stream_t stream);
+int sv_upsample2d_bwd(const void* dy, void* dx, int N, int H, int W, int C, int uh, int uw, int dtype,
+                      sv_stream_t stream);
+
+/* ---- BatchNormalization, axis -1 (autoencoder.py:318,450,468; unet.py:51;
+ *      context_encoder.py:64,88,179,237,267,283,341).  rows = product of all other axes.
+ *      Training: y = gamma*(x-mean)/sqrt(var_biased+eps)+beta; saves mean and 1/sqrt(var+eps);
+ *      moving <- momentum*moving + (1-momentum)*batch, the variance fed to it being unbiased when
+ *      unbiased_moving_var != 0 (the fused 4-D kernel of Keras 2).  moving_* may both be NULL.
+ *      workspace: sv_colreduce_workspace_bytes(rows, C). */
+int sv_batchnorm_fwd_train(const void* x, const float* gamma, const float* beta, void* y, float* save_mean,
+                           float* save_invstd, float* moving_mean, float* moving_var, int64_t rows, int C, float eps,
+                           float momentum, int unbiased_moving_var, void* workspace, size_t workspace_bytes,
+                           int dtype, sv_stream_t stream);
+int sv_batchnorm_fwd_infer(const void* x, const float* gamma, const float* beta, const float* moving_mean,
+                           const float* moving_var, void* y, int64_t rows, int C, float eps, int dtype,
+                           sv_stream_t stream);
+/* dgamma/dbeta are overwritten (accumulate == 0) or added to. */
+int sv_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const float* save_mean,
+                     const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t rows,
+                     int C, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
+
+/* ---- Concatenate on the channel axis (unet.py:144): y[r] = [a[r], b[r]] and its split backward */
+int sv_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int Ca, int Cb, int dtype,
+                           sv_stream_t stream);
+int sv_concat_channels_bwd(const void* dy, void* da, void* db, int64_t rows, int Ca, int Cb, int dtype,
+                           sv_stream_t stream);
+
+/* ---- Dense (autoencoder.py:38-40,107,110,176,179,222-241,330-352,466-492): y = act(x[M,K] w[K,N] + b) */
+int sv_dense_fwd(const void* x, const void* w, const void* bias, void* y, int M, int K, int N, int act, float alpha,
+                 int dtype, sv_stream_t stream);
+int sv_dense_dgrad(const void* dz, const void* w, void* dx, int M, int K, int N, int dtype, sv_stream_t stream);
+int sv_dense_wgrad(const void* x, const void* dz, void* dw, int accumulate, int M, int K, int N, int dtype,
+                   sv_stream_t stream);
+
+/* ---- Dropout (autoencoder.py:108,177,223,331): inverted dropout with a counter-based generator;
+ *      element i is kept iff hash(seed, offset + i) >= rate. */
+int sv_dropout_fwd(const void* x, void* y, int64_t n, float rate, uint64_t seed, uint64_t offset, int dtype,
+                   sv_stream_t stream);
+int sv_dropout_bwd(const void* dy, void* dx, int64_t n, float rate, uint64_t seed, uint64_t offset, int dtype,
+                   sv_stream_t stream);
+
+/* ---- reduce_sum over the H axis of NHWC (autoencoder.py:36) */
+int sv_reduce_sum_h_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, sv_stream_t stream);
+int sv_reduce_sum_h_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, sv_stream_t stream);
+
+/* ---- Sampling (autoencoder.py:264-272): z = mean + exp(0.5*logvar)*eps, eps ~ N(0,1) from a counter-based
+ *      generator (seed, offset) or, when eps_in != NULL, supplied by the caller.  kl_out (1 float) receives
+ *      mean_b( -1/2 sum_d(1 + logvar - mean^2 - exp(logvar)) ); the KL term has no counterpart in the reference.
+ *      eps_out (optional) stores the epsilon used, for the backward pass. */
+int sv_reparam_kl_fwd(const float* mean, const float* logvar, const float* eps_in, float* z, float* eps_out,
+                      float* kl_out, float* partials /* sv_loss_workspace_bytes() */, int B, int D, uint64_t seed,
+                      uint64_t offset, sv_stream_t stream);
+/* dmean = dz + kl_weight*mean/B ; dlogvar = dz*0.5*exp(0.5*logvar)*eps + kl_weight*0.5*(exp(logvar)-1)/B */
+int sv_reparam_kl_bwd(const float* mean, const float* logvar, const float* eps, const float* dz, float* dmean,
+                      float* dlogvar, float kl_weight, int B, int D, sv_stream_t stream);
+
+/* ---- losses.  Each writes the scalar loss to loss_out[0] (device; += when accumulate != 0) and, if dpred != NULL,
+ *      loss_scale * dL/dpred.  partials is scratch of sv_loss_workspace_bytes().
+ *  MSE (run_model.py:140,281; run_unet.py:102): mean over all elements.  With weight != NULL
+ *  (run_context_encoder.py:190-198) weight is [n_pix] and the loss is sum_p w[p]*mean_c(d^2) / n_pix.
+ *  weight_stride lets the caller pass channel 0 of an NHWC mask directly (stride = C). */
+size_t sv_loss_workspace_bytes(void);
+int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int weight_stride, float weight_scale,
+                float* loss_out, int accumulate, void* dpred, float loss_scale, int64_t n_pix, int C, float* partials,
+                int dtype, sv_stream_t stream);
+/* per-pixel map, reduction="none" (run_context_encoder.py:493-501; run_model.py:361-362): out[p] = w[p]*mean_c(d^2) */
+int sv_loss_mse_map(const void* y_true, const void* y_pred, const float* weight, int weight_stride,
+                    float weight_scale, float* out, int64_t n_pix, int C, int dtype, sv_stream_t stream);
+/* MeanAbsoluteError (run_unet.py:147) */
+int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int accumulate, void* dpred,
+                float loss_scale, int64_t n, float* partials, int dtype, sv_stream_t stream);
+/* BinaryCrossentropy against a constant label (run_context_encoder.py:165-187: from_logits=False, clip 1e-7;
+ * run_unet.py:84-90,148-154: from_logits=True) */
+int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out, int accumulate, void* dpred,
+                float loss_scale, int64_t n, float* partials, int dtype, sv_stream_t stream);
+
+/* ---- optimizer: tf.keras.optimizers.legacy.Adam + ExponentialDecay(staircase)
+ *      (run_model.py:77-89; run_unet.py:48-66; run_context_encoder.py:144-162) over one flat buffer.
+ *      step_state is a 16-byte device buffer: int64 count of updates applied so far, then two floats of
+ *      scratch.  sv_adam_keras_prepare reads the count `it`, stores
+ *        lr = lr0 * decay_rate^floor(it/decay_steps) (decay_steps <= 0: constant), t = it+1,
+ *        alpha = lr*sqrt(1-b2^t)/(1-b1^t)
+ *      (in double) into the scratch and increments the count, so a captured graph replays the schedule with
+ *      no host input.  sv_adam_keras_apply then does, per element,
+ *        g *= grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= alpha m/(sqrt(v)+eps)
+ *      (grad_scale = 1/world_size after a sum all-reduce).  Buffers must be 16-byte aligned. */
+int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float beta2, int decay_steps,
+                          float decay_rate, int staircase, sv_stream_t stream);
+int sv_adam_keras_apply(float* theta, const float* grad, float* m, float* v, int64_t n, const int64_t* step_state,
+                        float beta1, float beta2, float eps, float grad_scale, sv_stream_t stream);
+
+/* ---- batching helpers for Model.fit / predict (run_model.py:141-146,283-289,300):
+ *      dst[i, :] = src[idx[i], :] with rows of row_elems elements; src may be f64 or f32 (src_is_f64), dst is f32:
+ *      Keras casts the float64 arrays np.zeros/np.concatenate produce (run_model.py:23,110,245) to float32. */
+int sv_gather_rows(const void* src, int src_is_f64, const int64_t* idx, float* dst, int64_t n_rows,
+                   int64_t row_elems, sv_stream_t stream);
+/* y = x * (1 - mask) (run_context_encoder.py:242) */
+int sv_mask_input(const float* x, const float* mask, float* y, int64_t n, sv_stream_t stream);
+int sv_fill_f32(float* p, float value, int64_t n, sv_stream_t stream);
+int sv_axpy_f32(float* y, const float* x, float a, int64_t n, sv_stream_t stream); /* y += a*x */
+int sv_cast_f32_bf16(const float* x, void* y, int64_t n, sv_stream_t stream);
+int sv_cast_bf16_f32(const void* x, float* y, int64_t n, sv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECTRUM_HIP_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of ``libspectrum_hip.so`` (declared in ``include/spectrum_hip.h``).
+
+The library is the only compute backend of this package: there is no CPU or
+eager fallback.  If the shared object is missing or does not export a declared
+symbol, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspectrum_hip.so")
+
+ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "elu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5}
+F32, BF16 = 0, 1
+
+
+class ConvGeom(C.Structure):
+    """Mirror of ``sv_conv_geom``."""
+
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "H", "W", "Cin", "KH", "KW", "SH", "SW", "pad_t", "pad_l", "Ho", "Wo", "Cout", "up_h", "up_w")]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+_p, _i, _f, _i64, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64, C.c_size_t
+_g = C.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); one entry per declaration in include/spectrum_hip.h
+SIGNATURES = {
+    "sv_last_error": (C.c_char_p, []),
+    "sv_version": (_i, []),
+    "sv_conv2d_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
+    "sv_conv2d_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
+    "sv_conv2d_wgrad_workspace_bytes": (_sz, [_g]),
+    "sv_conv2d_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),
+    "sv_conv2d_transpose_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
+    "sv_conv2d_transpose_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
+    "sv_conv2d_transpose_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),
+    "sv_act_fwd": (_i, [_p, _p, _i64, _i, _f, _i, _p]),
+    "sv_colreduce_workspace_bytes": (_sz, [_i64, _i]),
+    "sv_act_bwd": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _f, _p, _sz, _i, _p]),
+    "sv_bias_grad": (_i, [_p, _p, _i, _i64, _i, _p, _sz, _i, _p]),
+    "sv_maxpool2d_fwd": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
+    "sv_maxpool2d_bwd": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
+    "sv_upsample2d_fwd": (_i, [_p, _p] + [_i] * 7 + [_p]),
+    "sv_upsample2d_bwd": (_i, [_p, _p] + [_i] * 7 + [_p]),
+    "sv_batchnorm_fwd_train": (_i, [_p] * 8 + [_i64, _i, _f, _f, _i, _p, _sz, _i, _p]),
+    "sv_batchnorm_fwd_infer": (_i, [_p] * 6 + [_i64, _i, _f, _i, _p]),
+    "sv_batchnorm_bwd": (_i, [_p] * 8 + [_i, _i64, _i, _p, _sz, _i, _p]),
+    "sv_concat_channels_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
+    "sv_concat_channels_bwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
+    "sv_dense_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "sv_dense_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "sv_dense_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "sv_dropout_fwd": (_i, [_p, _p, _i64, _f, _u64, _u64, _i, _p]),
+    "sv_dropout_bwd": (_i, [_p, _p, _i64, _f, _u64, _u64, _i, _p]),
+    "sv_reduce_sum_h_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "sv_reduce_sum_h_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "sv_reparam_kl_fwd": (_i, [_p] * 7 + [_i, _i, _u64, _u64, _p]),
+    "sv_reparam_kl_bwd": (_i, [_p] * 6 + [_f, _i, _i, _p]),
+    "sv_loss_workspace_bytes": (_sz, []),
+    "sv_loss_mse": (_i, [_p, _p, _p, _i, _f, _p, _i, _p, _f, _i64, _i, _p, _i, _p]),
+    "sv_loss_mse_map": (_i, [_p, _p, _p, _i, _f, _p, _i64, _i, _i, _p]),
+    "sv_loss_mae": (_i, [_p, _p, _p, _i, _p, _f, _i64, _p, _i, _p]),
+    "sv_loss_bce": (_i, [_p, _f, _i, _p, _i, _p, _f, _i64, _p, _i, _p]),
+    "sv_adam_keras_prepare": (_i, [_p, _f, _f, _f, _i, _f, _i, _p]),
+    "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p]),
+    "sv_gather_rows": (_i, [_p, _i, _p, _p, _i64, _i64, _p]),
+    "sv_mask_input": (_i, [_p, _p, _p, _i64, _p]),
+    "sv_fill_f32": (_i, [_p, _f, _i64, _p]),
+    "sv_axpy_f32": (_i, [_p, _p, _f, _i64, _p]),
+    "sv_cast_f32_bf16": (_i, [_p, _p, _i64, _p]),
+    "sv_cast_bf16_f32": (_i, [_p, _p, _i64, _p]),
+}
+
+
+class SpectrumHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback backend.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover - build/packaging error
+            raise ImportError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.sv_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise SpectrumHipError(f"{what or 'libspectrum_hip'} failed (code {rc}): {last_error()}")

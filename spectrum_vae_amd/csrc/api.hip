@@ -1,0 +1,101 @@
+// C-ABI entry points for the convolution family and library-wide helpers.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace sv {
+
+thread_local char g_last_error[512] = "";
+
+// conv_direct.hip
+int validate_geom(const sv_conv_geom* g, const char* who);
+int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                      float alpha, hipStream_t st);
+int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx,
+                        int act, float alpha, hipStream_t st);
+size_t wgrad_direct_workspace(const sv_conv_geom& g);
+int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, float* dw, int accumulate, void* ws,
+                        size_t ws_bytes, hipStream_t st);
+
+}  // namespace sv
+
+using namespace sv;
+
+extern "C" {
+
+const char* sv_last_error(void) { return g_last_error; }
+
+int sv_version(void) { return 1; }
+
+int sv_conv2d_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
+                  float alpha, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_fwd");
+    int rc = validate_geom(g, "sv_conv2d_fwd");
+    if (rc) return rc;
+    SV_REQUIRE(x && w && y, "sv_conv2d_fwd: null tensor");
+    return launch_fwd_direct(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, act, alpha,
+                             to_stream(stream));
+}
+
+int sv_conv2d_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* dx, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_dgrad");
+    int rc = validate_geom(g, "sv_conv2d_dgrad");
+    if (rc) return rc;
+    SV_REQUIRE(dz && w && dx, "sv_conv2d_dgrad: null tensor");
+    return launch_dgrad_direct(*g, (const float*)dz, (const float*)w, nullptr, (float*)dx, SV_ACT_NONE, 0.f,
+                               to_stream(stream));
+}
+
+size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g) {
+    if (validate_geom(g, "sv_conv2d_wgrad_workspace_bytes")) return 0;
+    return wgrad_direct_workspace(*g);
+}
+
+int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate, void* workspace,
+                    size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_wgrad");
+    int rc = validate_geom(g, "sv_conv2d_wgrad");
+    if (rc) return rc;
+    SV_REQUIRE(x && dz && dw, "sv_conv2d_wgrad: null tensor");
+    return launch_wgrad_direct(*g, (const float*)x, (const float*)dz, (float*)dw, accumulate, workspace,
+                               workspace_bytes, to_stream(stream));
+}
+
+// Conv2DTranspose forward is the input-gradient kernel of the described conv, plus bias and activation.
+int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
+                            float alpha, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_transpose_fwd");
+    int rc = validate_geom(g, "sv_conv2d_transpose_fwd");
+    if (rc) return rc;
+    SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_transpose_fwd: folded upsampling is not defined here");
+    SV_REQUIRE(x && w && y, "sv_conv2d_transpose_fwd: null tensor");
+    return launch_dgrad_direct(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, act, alpha,
+                               to_stream(stream));
+}
+
+// ... and its input-gradient is the described conv run forward without epilogue.
+int sv_conv2d_transpose_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* dx, int dtype,
+                              sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_transpose_dgrad");
+    int rc = validate_geom(g, "sv_conv2d_transpose_dgrad");
+    if (rc) return rc;
+    SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_transpose_dgrad: folded upsampling is not defined here");
+    SV_REQUIRE(dz && w && dx, "sv_conv2d_transpose_dgrad: null tensor");
+    return launch_fwd_direct(*g, (const float*)dz, (const float*)w, nullptr, (float*)dx, SV_ACT_NONE, 0.f,
+                             to_stream(stream));
+}
+
+// dw[kh,kw,co_T,ci_T] = sum dz_T[(H,W,Cin) side] * x_T[(Ho,Wo,Cout) side]: the conv kernel-gradient with the
+// layer's output gradient in the role of the conv input and the layer's input in the role of the conv's dz.
+int sv_conv2d_transpose_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate,
+                              void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_transpose_wgrad");
+    int rc = validate_geom(g, "sv_conv2d_transpose_wgrad");
+    if (rc) return rc;
+    SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_transpose_wgrad: folded upsampling is not defined here");
+    SV_REQUIRE(x && dz && dw, "sv_conv2d_transpose_wgrad: null tensor");
+    return launch_wgrad_direct(*g, (const float*)dz, (const float*)x, (float*)dw, accumulate, workspace,
+                               workspace_bytes, to_stream(stream));
+}
+
+}  // extern "C"

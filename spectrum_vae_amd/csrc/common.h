@@ -1,0 +1,105 @@
+// Shared host/device helpers for libspectrum_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/spectrum_hip.h"
+
+namespace sv {
+
+// Text of the calling thread's last failure (returned by sv_last_error()).
+extern thread_local char g_last_error[512];
+
+inline int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SV_E_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return SV_OK;
+}
+
+#define SV_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return sv::fail(SV_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define SV_F32_ONLY(dtype, name)                                                             \
+    do {                                                                                     \
+        if ((dtype) != SV_F32) return sv::fail(SV_E_UNSUPPORTED, name ": dtype %d unsupported", (int)(dtype)); \
+    } while (0)
+
+inline hipStream_t to_stream(sv_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, never more than the work.
+inline int ew_grid(int64_t n_items, int block = 256, int max_blocks = 2048) {
+    int64_t b = ceil_div(n_items, block);
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float act_apply(float z, int act, float alpha) {
+    switch (act) {
+        case SV_ACT_RELU: return z > 0.f ? z : 0.f;
+        case SV_ACT_ELU: return z > 0.f ? z : expm1f(z);
+        case SV_ACT_LRELU: return z >= 0.f ? z : alpha * z;
+        case SV_ACT_TANH: return tanhf(z);
+        case SV_ACT_SIGMOID: return 1.f / (1.f + expf(-z));
+        default: return z;
+    }
+}
+
+// d act / d z written in terms of the activation output y.
+__device__ __forceinline__ float act_grad_from_y(float y, int act, float alpha) {
+    switch (act) {
+        case SV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case SV_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+        case SV_ACT_LRELU: return y >= 0.f ? 1.f : alpha;
+        case SV_ACT_TANH: return 1.f - y * y;
+        case SV_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over a 256-thread block; result valid in every thread. `red` is 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// splitmix64-style counter hash -> uniform in [0,1)
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t ctr) {
+    return (float)(mix64(seed ^ mix64(ctr)) >> 40) * (1.0f / 16777216.0f);
+}
+
+}  // namespace sv

@@ -1,0 +1,257 @@
+// Generic direct convolution kernels (any kernel size, stride, padding, channel count; f32).
+//
+// These are the shape-agnostic fallbacks: one lane per output (or input) pixel, a register tile of
+// channels per lane, filter taps read through wave-uniform addresses so the compiler keeps them on the
+// scalar path.  Shapes on the benchmarked path are routed to the tiled kernels in conv_tiled.hip first.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace sv {
+
+// ------------------------------------------------------------------------------------------------ forward
+// y[n,oh,ow,co] = act(bias[co] + sum_{kh,kw,ci} x[n, (oh*SH+kh-pt)/up_h, (ow*SW+kw-pl)/up_w, ci] * w[kh,kw,ci,co])
+template <int CO_T>
+__global__ __launch_bounds__(256) void conv2d_fwd_direct(sv_conv_geom g, const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int act, float alpha) {
+    const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
+    const int co0 = blockIdx.y * CO_T;
+    const int Hp = g.H / g.up_h, Wp = g.W / g.up_w;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(p % g.Wo);
+        const int oh = (int)((p / g.Wo) % g.Ho);
+        const int n = (int)(p / ((int64_t)g.Wo * g.Ho));
+        float acc[CO_T];
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c) acc[c] = (bias != nullptr && co0 + c < g.Cout) ? bias[co0 + c] : 0.f;
+        for (int kh = 0; kh < g.KH; ++kh) {
+            const int ihl = oh * g.SH + kh - g.pad_t;
+            const bool okh = ihl >= 0 && ihl < g.H;
+            const int ih = okh ? ihl / g.up_h : 0;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                const int iwl = ow * g.SW + kw - g.pad_l;
+                const bool ok = okh && iwl >= 0 && iwl < g.W;
+                const int iw = ok ? iwl / g.up_w : 0;
+                const float* xp = x + (((int64_t)n * Hp + ih) * Wp + iw) * g.Cin;
+                const float* wp = w + (int64_t)(kh * g.KW + kw) * g.Cin * g.Cout + co0;
+                if (ok) {
+                    for (int ci = 0; ci < g.Cin; ++ci) {
+                        const float xv = xp[ci];
+#pragma unroll
+                        for (int c = 0; c < CO_T; ++c)
+                            if (co0 + c < g.Cout) acc[c] = fmaf(xv, wp[(int64_t)ci * g.Cout + c], acc[c]);
+                    }
+                }
+            }
+        }
+        float* yp = y + p * g.Cout + co0;
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c)
+            if (co0 + c < g.Cout) yp[c] = act_apply(acc[c], act, alpha);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ input gradient
+// out[n,ihp,iwp,ci] = epi( sum over logical (ih,iw) mapped to this stored pixel, kh, kw, co with
+//                         (ih+pt-kh) % SH == 0:  dz[n,(ih+pt-kh)/SH,(iw+pl-kw)/SW,co] * w[kh,kw,ci,co] )
+// epi = optional bias[ci] + activation: that is the forward of Conv2DTranspose.
+template <int CI_T>
+__global__ __launch_bounds__(256) void conv2d_dgrad_direct(sv_conv_geom g, const float* __restrict__ dz,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ dx,
+                                                           int act, float alpha) {
+    const int Hp = g.H / g.up_h, Wp = g.W / g.up_w;
+    const int64_t npix = (int64_t)g.N * Hp * Wp;
+    const int ci0 = blockIdx.y * CI_T;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int iwp = (int)(p % Wp);
+        const int ihp = (int)((p / Wp) % Hp);
+        const int n = (int)(p / ((int64_t)Wp * Hp));
+        float acc[CI_T];
+#pragma unroll
+        for (int c = 0; c < CI_T; ++c) acc[c] = 0.f;
+        for (int a = 0; a < g.up_h; ++a) {
+            const int ih = ihp * g.up_h + a;
+            for (int kh = 0; kh < g.KH; ++kh) {
+                const int t = ih + g.pad_t - kh;
+                const bool okh = t >= 0 && (t % g.SH) == 0 && (t / g.SH) < g.Ho;
+                const int oh = okh ? t / g.SH : 0;
+                for (int b = 0; b < g.up_w; ++b) {
+                    const int iw = iwp * g.up_w + b;
+                    for (int kw = 0; kw < g.KW; ++kw) {
+                        const int u = iw + g.pad_l - kw;
+                        const bool ok = okh && u >= 0 && (u % g.SW) == 0 && (u / g.SW) < g.Wo;
+                        const int ow = ok ? u / g.SW : 0;
+                        const float* zp = dz + (((int64_t)n * g.Ho + oh) * g.Wo + ow) * g.Cout;
+                        const float* wp = w + ((int64_t)(kh * g.KW + kw) * g.Cin + ci0) * g.Cout;
+                        if (ok) {
+                            for (int co = 0; co < g.Cout; ++co) {
+                                const float zv = zp[co];
+#pragma unroll
+                                for (int c = 0; c < CI_T; ++c)
+                                    if (ci0 + c < g.Cin) acc[c] = fmaf(zv, wp[(int64_t)c * g.Cout + co], acc[c]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        float* op = dx + p * g.Cin + ci0;
+#pragma unroll
+        for (int c = 0; c < CI_T; ++c)
+            if (ci0 + c < g.Cin) {
+                float v = acc[c] + (bias != nullptr ? bias[ci0 + c] : 0.f);
+                op[c] = act_apply(v, act, alpha);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernel gradient
+// part[split][k][co] = sum over the split's output pixels of x[n, ih, iw, ci] * dz[n, oh, ow, co], k = (kh,kw,ci).
+// grid = (K_total, cout tiles, n_split); the slab of partial sums is folded in split order by wgrad_reduce so
+// the result does not depend on scheduling.  SWAP exchanges the roles of the two tensors' channels in the
+// OUTPUT layout (dw[kh,kw,ci,co] vs the Conv2DTranspose layout, which is the same memory order) - unused here,
+// the transposed wrapper swaps its operands instead.
+template <int CO_T>
+__global__ __launch_bounds__(256) void conv2d_wgrad_direct(sv_conv_geom g, const float* __restrict__ x,
+                                                           const float* __restrict__ dz, float* __restrict__ part,
+                                                           int64_t pix_per_split) {
+    __shared__ float red[4 * CO_T];
+    const int k = blockIdx.x;
+    const int ci = k % g.Cin;
+    const int kw = (k / g.Cin) % g.KW;
+    const int kh = k / (g.Cin * g.KW);
+    const int co0 = blockIdx.y * CO_T;
+    const int Hp = g.H / g.up_h, Wp = g.W / g.up_w;
+    const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
+    const int64_t p_begin = (int64_t)blockIdx.z * pix_per_split;
+    int64_t p_end = p_begin + pix_per_split;
+    if (p_end > npix) p_end = npix;
+    float acc[CO_T];
+#pragma unroll
+    for (int c = 0; c < CO_T; ++c) acc[c] = 0.f;
+    for (int64_t p = p_begin + threadIdx.x; p < p_end; p += blockDim.x) {
+        const int ow = (int)(p % g.Wo);
+        const int oh = (int)((p / g.Wo) % g.Ho);
+        const int n = (int)(p / ((int64_t)g.Wo * g.Ho));
+        const int ihl = oh * g.SH + kh - g.pad_t;
+        const int iwl = ow * g.SW + kw - g.pad_l;
+        if (ihl < 0 || ihl >= g.H || iwl < 0 || iwl >= g.W) continue;
+        const float xv = x[(((int64_t)n * Hp + ihl / g.up_h) * Wp + iwl / g.up_w) * g.Cin + ci];
+        const float* zp = dz + p * g.Cout + co0;
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c)
+            if (co0 + c < g.Cout) acc[c] = fmaf(xv, zp[c], acc[c]);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CO_T; ++c) {
+        const float s = wave_sum(acc[c]);
+        if (lane == 0) red[wid * CO_T + c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < CO_T && co0 + threadIdx.x < g.Cout) {
+        const int c = threadIdx.x;
+        const float s = red[c] + red[CO_T + c] + red[2 * CO_T + c] + red[3 * CO_T + c];
+        const int64_t kc = (int64_t)g.KH * g.KW * g.Cin * g.Cout;
+        part[(int64_t)blockIdx.z * kc + (int64_t)k * g.Cout + co0 + c] = s;
+    }
+}
+
+__global__ void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int64_t kc, int n_split,
+                             int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < kc; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int sp = 0; sp < n_split; ++sp) s += part[(int64_t)sp * kc + i];
+        dw[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int validate_geom(const sv_conv_geom* g, const char* who) {
+    if (g == nullptr) return fail(SV_E_INVALID, "%s: null geometry", who);
+    if (g->N <= 0 || g->H <= 0 || g->W <= 0 || g->Cin <= 0 || g->Cout <= 0 || g->KH <= 0 || g->KW <= 0 ||
+        g->SH <= 0 || g->SW <= 0 || g->Ho <= 0 || g->Wo <= 0 || g->up_h <= 0 || g->up_w <= 0 || g->pad_t < 0 ||
+        g->pad_l < 0)
+        return fail(SV_E_INVALID, "%s: non-positive extent in geometry", who);
+    if (g->H % g->up_h != 0 || g->W % g->up_w != 0)
+        return fail(SV_E_INVALID, "%s: logical extent %dx%d is not a multiple of the upsample factor %dx%d", who,
+                    g->H, g->W, g->up_h, g->up_w);
+    // every output pixel's window must start inside the padded input: (Ho-1)*SH - pad_t <= H-1
+    if ((int64_t)(g->Ho - 1) * g->SH - g->pad_t > g->H - 1 || (int64_t)(g->Wo - 1) * g->SW - g->pad_l > g->W - 1)
+        return fail(SV_E_INVALID, "%s: output extent %dx%d does not fit input %dx%d", who, g->Ho, g->Wo, g->H, g->W);
+    return SV_OK;
+}
+
+int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                      float alpha, hipStream_t st) {
+    const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
+    const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
+    dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cout, cot));
+    if (cot == 16)
+        hipLaunchKernelGGL(conv2d_fwd_direct<16>, grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
+    else if (cot == 8)
+        hipLaunchKernelGGL(conv2d_fwd_direct<8>, grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
+    else
+        hipLaunchKernelGGL(conv2d_fwd_direct<4>, grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
+    return check_launch("conv2d_fwd_direct");
+}
+
+int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx,
+                        int act, float alpha, hipStream_t st) {
+    const int64_t npix = (int64_t)g.N * (g.H / g.up_h) * (g.W / g.up_w);
+    const int cit = g.Cin >= 16 ? 16 : (g.Cin > 4 ? 8 : 4);
+    dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cin, cit));
+    if (cit == 16)
+        hipLaunchKernelGGL(conv2d_dgrad_direct<16>, grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
+    else if (cit == 8)
+        hipLaunchKernelGGL(conv2d_dgrad_direct<8>, grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
+    else
+        hipLaunchKernelGGL(conv2d_dgrad_direct<4>, grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
+    return check_launch("conv2d_dgrad_direct");
+}
+
+// Split of the pixel reduction: aim at >= 1024 blocks in total, at least 256 pixels per block.
+int wgrad_direct_splits(const sv_conv_geom& g) {
+    const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
+    const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
+    const int64_t base = (int64_t)g.KH * g.KW * g.Cin * ceil_div(g.Cout, cot);
+    int64_t want = ceil_div(2048, base);
+    int64_t maxs = ceil_div(npix, 512);
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    return (int)want;
+}
+
+size_t wgrad_direct_workspace(const sv_conv_geom& g) {
+    return (size_t)wgrad_direct_splits(g) * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
+}
+
+int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, float* dw, int accumulate,
+                        void* ws, size_t ws_bytes, hipStream_t st) {
+    const int ns = wgrad_direct_splits(g);
+    const int64_t kc = (int64_t)g.KH * g.KW * g.Cin * g.Cout;
+    if (ws == nullptr || ws_bytes < wgrad_direct_workspace(g))
+        return fail(SV_E_WORKSPACE, "conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes,
+                    wgrad_direct_workspace(g));
+    const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
+    const int64_t pps = ceil_div(npix, ns);
+    const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
+    dim3 grid((unsigned)(g.KH * g.KW * g.Cin), (unsigned)ceil_div(g.Cout, cot), (unsigned)ns);
+    float* part = (float*)ws;
+    if (cot == 16)
+        hipLaunchKernelGGL(conv2d_wgrad_direct<16>, grid, dim3(256), 0, st, g, x, dz, part, pps);
+    else if (cot == 8)
+        hipLaunchKernelGGL(conv2d_wgrad_direct<8>, grid, dim3(256), 0, st, g, x, dz, part, pps);
+    else
+        hipLaunchKernelGGL(conv2d_wgrad_direct<4>, grid, dim3(256), 0, st, g, x, dz, part, pps);
+    int rc = check_launch("conv2d_wgrad_direct");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(ew_grid(kc)), dim3(256), 0, st, part, dw, kc, ns, accumulate);
+    return check_launch("wgrad_reduce");
+}
+
+}  // namespace sv

@@ -1,0 +1,749 @@
+// Bandwidth-bound kernels: activations, pooling, resampling, batch normalisation, concat, dropout,
+// batching helpers.  All f32, NHWC, grid-stride with 16-byte accesses where the channel count allows.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace sv {
+
+// ------------------------------------------------------------------------------------------------ activations
+__global__ void act_fwd_k(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act, float alpha) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = act_apply(v.x, act, alpha);
+        v.y = act_apply(v.y, act, alpha);
+        v.z = act_apply(v.z, act, alpha);
+        v.w = act_apply(v.w, act, alpha);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = act_apply(x[i], act, alpha);
+}
+
+// dz = dy * act'(y); optional per-channel column sums of dz into part[block][C] (C <= 1024).
+// Rows are dealt to blocks in contiguous chunks; thread t of a block owns channel (t % C) of rows t/C, ...
+__global__ __launch_bounds__(256) void act_bwd_k(const float* __restrict__ dy, const float* __restrict__ y,
+                                                  float* __restrict__ dz, float* __restrict__ part, int64_t rows,
+                                                  int C, int act, float alpha, int64_t rows_per_block) {
+    extern __shared__ float sm[];  // [rows_in_flight][C] partial sums when part != nullptr
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    const int rif = blockDim.x / C > 0 ? blockDim.x / C : 1;  // rows handled per sweep (C <= 256) else 1
+    if (C <= (int)blockDim.x) {
+        const int c = threadIdx.x % C;
+        const int rr = threadIdx.x / C;
+        float acc = 0.f;
+        if (rr < rif) {
+            for (int64_t r = r0 + rr; r < r1; r += rif) {
+                const int64_t i = r * C + c;
+                const float g = dy[i] * act_grad_from_y(y[i], act, alpha);
+                dz[i] = g;
+                acc += g;
+            }
+        }
+        if (part != nullptr) {
+            sm[threadIdx.x] = (rr < rif) ? acc : 0.f;
+            __syncthreads();
+            if (threadIdx.x < C) {
+                float s = 0.f;
+                for (int k = 0; k < rif; ++k) s += sm[k * C + threadIdx.x];
+                part[(int64_t)blockIdx.x * C + threadIdx.x] = s;
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float acc = 0.f;
+            for (int64_t r = r0; r < r1; ++r) {
+                const int64_t i = r * C + c;
+                const float g = dy[i] * act_grad_from_y(y[i], act, alpha);
+                dz[i] = g;
+                acc += g;
+            }
+            if (part != nullptr) part[(int64_t)blockIdx.x * C + c] = acc;
+        }
+    }
+}
+
+// column sums only
+__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ z, float* __restrict__ part, int64_t rows,
+                                                 int C, int64_t rows_per_block) {
+    extern __shared__ float sm[];
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (C <= (int)blockDim.x) {
+        const int rif = blockDim.x / C;
+        const int c = threadIdx.x % C, rr = threadIdx.x / C;
+        float acc = 0.f;
+        if (rr < rif)
+            for (int64_t r = r0 + rr; r < r1; r += rif) acc += z[r * C + c];
+        sm[threadIdx.x] = (rr < rif) ? acc : 0.f;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float s = 0.f;
+            for (int k = 0; k < rif; ++k) s += sm[k * C + threadIdx.x];
+            part[(int64_t)blockIdx.x * C + threadIdx.x] = s;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float acc = 0.f;
+            for (int64_t r = r0; r < r1; ++r) acc += z[r * C + c];
+            part[(int64_t)blockIdx.x * C + c] = acc;
+        }
+    }
+}
+
+// out[c] (+)= sum_b part[b][c], in block order (deterministic)
+__global__ void fold_partials_k(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C,
+                                int accumulate) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        float s = accumulate ? out[c] : 0.f;
+        for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * C + c];
+        out[c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ max pooling
+__global__ void maxpool_fwd_k(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int N,
+                              int H, int W, int C, int ph, int pw, int pt, int pl, int Ho, int Wo) {
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int ow = (int)(p % Wo);
+        p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float best = -INFINITY;
+        int bi = 0;
+        for (int a = 0; a < ph; ++a) {
+            const int ih = oh * ph + a - pt;
+            if (ih < 0 || ih >= H) continue;
+            for (int b = 0; b < pw; ++b) {
+                const int iw = ow * pw + b - pl;
+                if (iw < 0 || iw >= W) continue;
+                const float v = x[(((int64_t)n * H + ih) * W + iw) * C + c];
+                if (v > best) {
+                    best = v;
+                    bi = a * pw + b;
+                }
+            }
+        }
+        y[i] = best;
+        if (idx != nullptr) idx[i] = (uint8_t)bi;
+    }
+}
+
+// one thread per INPUT element: non-overlapping windows, so every input belongs to exactly one window
+__global__ void maxpool_bwd_k(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                              int N, int H, int W, int C, int ph, int pw, int pt, int pl, int Ho, int Wo) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int iw = (int)(p % W);
+        p /= W;
+        const int ih = (int)(p % H);
+        const int n = (int)(p / H);
+        const int oh = (ih + pt) / ph, ow = (iw + pl) / pw;
+        float g = 0.f;
+        if (oh < Ho && ow < Wo) {
+            const int64_t o = (((int64_t)n * Ho + oh) * Wo + ow) * C + c;
+            const int a = ih + pt - oh * ph, b = iw + pl - ow * pw;
+            if ((int)idx[o] == a * pw + b) g = dy[o];
+        }
+        dx[i] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ nearest upsampling
+__global__ void upsample_fwd_k(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                               int uh, int uw) {
+    const int Ho = H * uh, Wo = W * uw;
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int ow = (int)(p % Wo);
+        p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        y[i] = x[(((int64_t)n * H + oh / uh) * W + ow / uw) * C + c];
+    }
+}
+
+__global__ void upsample_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C,
+                               int uh, int uw) {
+    const int Ho = H * uh, Wo = W * uw;
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int iw = (int)(p % W);
+        p /= W;
+        const int ih = (int)(p % H);
+        const int n = (int)(p / H);
+        float s = 0.f;
+        for (int a = 0; a < uh; ++a)
+            for (int b = 0; b < uw; ++b) s += dy[(((int64_t)n * Ho + ih * uh + a) * Wo + iw * uw + b) * C + c];
+        dx[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ batch norm
+// pass 1: per-block partial (sum, sum of squares about a per-channel pivot) -> part[block][2][C].
+// The pivot (first row of the tensor) keeps the one-pass variance well conditioned.
+__global__ __launch_bounds__(256) void bn_stats_k(const float* __restrict__ x, float* __restrict__ part,
+                                                   int64_t rows, int C, int64_t rows_per_block) {
+    extern __shared__ float sm[];  // 2 * blockDim.x
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (C <= (int)blockDim.x) {
+        const int rif = blockDim.x / C;
+        const int c = threadIdx.x % C, rr = threadIdx.x / C;
+        float s = 0.f, q = 0.f;
+        if (rr < rif) {
+            const float piv = x[c];
+            for (int64_t r = r0 + rr; r < r1; r += rif) {
+                const float d = x[r * C + c] - piv;
+                s += d;
+                q = fmaf(d, d, q);
+            }
+        }
+        sm[threadIdx.x] = (rr < rif) ? s : 0.f;
+        sm[blockDim.x + threadIdx.x] = (rr < rif) ? q : 0.f;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float ss = 0.f, qq = 0.f;
+            for (int k = 0; k < rif; ++k) {
+                ss += sm[k * C + threadIdx.x];
+                qq += sm[blockDim.x + k * C + threadIdx.x];
+            }
+            part[((int64_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = ss;
+            part[((int64_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = qq;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float piv = x[c];
+            float s = 0.f, q = 0.f;
+            for (int64_t r = r0; r < r1; ++r) {
+                const float d = x[r * C + c] - piv;
+                s += d;
+                q = fmaf(d, d, q);
+            }
+            part[((int64_t)blockIdx.x * 2 + 0) * C + c] = s;
+            part[((int64_t)blockIdx.x * 2 + 1) * C + c] = q;
+        }
+    }
+}
+
+// pass 2: fold partials -> mean, invstd; update the moving statistics.
+__global__ void bn_finalize_k(const float* __restrict__ x, const float* __restrict__ part, int nblocks,
+                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                              float* __restrict__ moving_mean, float* __restrict__ moving_var, int64_t rows, int C,
+                              float eps, float momentum, int unbiased) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nblocks; ++b) {
+            s += (double)part[((int64_t)b * 2 + 0) * C + c];
+            q += (double)part[((int64_t)b * 2 + 1) * C + c];
+        }
+        const double m = (double)rows;
+        const double dmean = s / m;
+        double var = q / m - dmean * dmean;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)((double)x[c] + dmean);
+        save_mean[c] = mean;
+        save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (moving_mean != nullptr) {
+            const double mv = unbiased && rows > 1 ? var * m / (m - 1.0) : var;
+            moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * mean;
+            moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)mv;
+        }
+    }
+}
+
+// y = (x - mean) * invstd * gamma + beta   (mean/invstd either saved batch stats or derived from moving stats)
+__global__ void bn_apply_k(const float* __restrict__ x, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, const float* __restrict__ mean,
+                           const float* __restrict__ var_or_invstd, int is_var, float eps, float* __restrict__ y,
+                           int64_t total, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float inv = is_var ? rsqrtf(var_or_invstd[c] + eps) : var_or_invstd[c];
+        y[i] = (x[i] - mean[c]) * inv * gamma[c] + beta[c];
+    }
+}
+
+// backward pass 1: per-block partial (sum dy, sum dy*xhat) -> part[block][2][C]
+__global__ __launch_bounds__(256) void bn_bwd_stats_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, float* __restrict__ part,
+                                                       int64_t rows, int C, int64_t rows_per_block) {
+    extern __shared__ float sm[];
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (C <= (int)blockDim.x) {
+        const int rif = blockDim.x / C;
+        const int c = threadIdx.x % C, rr = threadIdx.x / C;
+        float s = 0.f, q = 0.f;
+        if (rr < rif) {
+            const float mu = mean[c], inv = invstd[c];
+            for (int64_t r = r0 + rr; r < r1; r += rif) {
+                const float g = dy[r * C + c];
+                s += g;
+                q = fmaf(g, (x[r * C + c] - mu) * inv, q);
+            }
+        }
+        sm[threadIdx.x] = (rr < rif) ? s : 0.f;
+        sm[blockDim.x + threadIdx.x] = (rr < rif) ? q : 0.f;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float ss = 0.f, qq = 0.f;
+            for (int k = 0; k < rif; ++k) {
+                ss += sm[k * C + threadIdx.x];
+                qq += sm[blockDim.x + k * C + threadIdx.x];
+            }
+            part[((int64_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = ss;
+            part[((int64_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = qq;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float mu = mean[c], inv = invstd[c];
+            float s = 0.f, q = 0.f;
+            for (int64_t r = r0; r < r1; ++r) {
+                const float g = dy[r * C + c];
+                s += g;
+                q = fmaf(g, (x[r * C + c] - mu) * inv, q);
+            }
+            part[((int64_t)blockIdx.x * 2 + 0) * C + c] = s;
+            part[((int64_t)blockIdx.x * 2 + 1) * C + c] = q;
+        }
+    }
+}
+
+// fold -> stats2[0][C] = sum dy (dbeta), stats2[1][C] = sum dy*xhat (dgamma); also emit dgamma/dbeta
+__global__ void bn_bwd_fold_k(const float* __restrict__ part, int nblocks, float* __restrict__ stats2,
+                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int C) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        float s = 0.f, q = 0.f;
+        for (int b = 0; b < nblocks; ++b) {
+            s += part[((int64_t)b * 2 + 0) * C + c];
+            q += part[((int64_t)b * 2 + 1) * C + c];
+        }
+        stats2[c] = s;
+        stats2[C + c] = q;
+        dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s;
+        dgamma[c] = (accumulate ? dgamma[c] : 0.f) + q;
+    }
+}
+
+// dx = gamma*invstd/m * (m*dy - sum_dy - xhat*sum_dy_xhat)
+__global__ void bn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ dy,
+                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                               const float* __restrict__ invstd, const float* __restrict__ stats2,
+                               float* __restrict__ dx, int64_t rows, int C) {
+    const int64_t total = rows * C;
+    const float invm = 1.f / (float)rows;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float inv = invstd[c];
+        const float xh = (x[i] - mean[c]) * inv;
+        dx[i] = gamma[c] * inv * (dy[i] - invm * (stats2[c] + xh * stats2[C + c]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ concat / misc
+__global__ void concat_fwd_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                             int64_t rows, int Ca, int Cb) {
+    const int Cy = Ca + Cb;
+    const int64_t total = rows * Cy;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cy);
+        const int64_t r = i / Cy;
+        y[i] = c < Ca ? a[r * Ca + c] : b[r * Cb + (c - Ca)];
+    }
+}
+
+__global__ void concat_bwd_k(const float* __restrict__ dy, float* __restrict__ da, float* __restrict__ db,
+                             int64_t rows, int Ca, int Cb) {
+    const int Cy = Ca + Cb;
+    const int64_t total = rows * Cy;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cy);
+        const int64_t r = i / Cy;
+        if (c < Ca)
+            da[r * Ca + c] = dy[i];
+        else
+            db[r * Cb + (c - Ca)] = dy[i];
+    }
+}
+
+__global__ void dropout_k(const float* __restrict__ x, float* __restrict__ y, int64_t n, float rate, uint64_t seed,
+                          uint64_t offset) {
+    const float scale = 1.f / (1.f - rate);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = u01(seed, offset + (uint64_t)i) >= rate ? x[i] * scale : 0.f;
+}
+
+__global__ void reduce_sum_h_fwd_k(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const int64_t total = (int64_t)N * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t wc = i % ((int64_t)W * C);
+        const int64_t n = i / ((int64_t)W * C);
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += x[(n * H + h) * (int64_t)W * C + wc];
+        y[i] = s;
+    }
+}
+
+__global__ void reduce_sum_h_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+    const int64_t total = (int64_t)N * H * W * C;
+    const int64_t wcn = (int64_t)W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t wc = i % wcn;
+        const int64_t n = i / (wcn * H);
+        dx[i] = dy[n * wcn + wc];
+    }
+}
+
+template <typename SRC>
+__global__ void gather_rows_k(const SRC* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst,
+                              int64_t n_rows, int64_t row_elems) {
+    const int64_t total = n_rows * row_elems;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / row_elems, e = i % row_elems;
+        const int64_t sr = idx != nullptr ? idx[r] : r;
+        dst[i] = (float)src[sr * row_elems + e];
+    }
+}
+
+__global__ void mask_input_k(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y,
+                             int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * (1.f - m[i]);
+}
+
+__global__ void fill_k(float* __restrict__ p, float v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void axpy_k(float* __restrict__ y, const float* __restrict__ x, float a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = fmaf(a, x[i], y[i]);
+}
+
+__global__ void cast_f32_bf16_k(const float* __restrict__ x, __hip_bfloat16* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = __float2bfloat16(x[i]);
+}
+
+__global__ void cast_bf16_f32_k(const __hip_bfloat16* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = __bfloat162float(x[i]);
+}
+
+}  // namespace sv
+
+// =================================================================================================== C ABI
+using namespace sv;
+
+// Row-chunked column reductions share this plan: nblocks blocks of rows_per_block rows, partial slabs in
+// a caller-visible scratch.  The scratch for act_bwd/bias_grad/batchnorm lives in a per-device buffer that
+// is allocated once (first use) and only grows when a larger reduction shows up.
+namespace {
+struct ColPlan {
+    int nblocks;
+    int64_t rows_per_block;
+};
+ColPlan col_plan(int64_t rows, int C) {
+    // at least ~64 rows of work per block, at most 1024 blocks
+    int64_t nb = ceil_div(rows, 64);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    ColPlan p;
+    p.rows_per_block = ceil_div(rows, nb);
+    p.nblocks = (int)ceil_div(rows, p.rows_per_block);
+    (void)C;
+    return p;
+}
+
+constexpr int kMaxC = 4096;
+// Workspace layout of a column reduction: [nblocks][2][C] partial slabs followed by [2][C] folded sums.
+size_t col_ws_bytes(int64_t rows, int C) {
+    ColPlan p = col_plan(rows, C);
+    return ((size_t)p.nblocks * 2 * C + 2 * (size_t)C) * sizeof(float);
+}
+int col_ws(void* ws, size_t ws_bytes, int64_t rows, int C, float** part, float** folded, const char* who) {
+    const size_t need = col_ws_bytes(rows, C);
+    if (ws == nullptr || ws_bytes < need)
+        return fail(SV_E_WORKSPACE, "%s: workspace %zu bytes < required %zu", who, ws_bytes, need);
+    ColPlan p = col_plan(rows, C);
+    *part = (float*)ws;
+    *folded = (float*)ws + (size_t)p.nblocks * 2 * C;
+    return SV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sv_act_fwd(const void* x, void* y, int64_t n, int act, float alpha, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_act_fwd");
+    SV_REQUIRE(x && y && n >= 0, "sv_act_fwd: bad arguments");
+    if (n == 0) return SV_OK;
+    hipLaunchKernelGGL(act_fwd_k, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, to_stream(stream), (const float*)x,
+                       (float*)y, n, act, alpha);
+    return check_launch("sv_act_fwd");
+}
+
+size_t sv_colreduce_workspace_bytes(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return col_ws_bytes(rows, C);
+}
+
+int sv_act_bwd(const void* dy, const void* y, void* dz, void* db, int db_accumulate, int64_t rows, int C, int act,
+               float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_act_bwd");
+    SV_REQUIRE(dy && y && dz && rows > 0 && C > 0 && C <= kMaxC, "sv_act_bwd: bad arguments (C=%d)", C);
+    ColPlan p = col_plan(rows, C);
+    float *part = nullptr, *folded = nullptr;
+    if (db != nullptr) {
+        int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_act_bwd");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(act_bwd_k, dim3(p.nblocks), dim3(256), 256 * sizeof(float), to_stream(stream),
+                       (const float*)dy, (const float*)y, (float*)dz, part, rows, C, act, alpha, p.rows_per_block);
+    int rc = check_launch("sv_act_bwd");
+    if (rc || db == nullptr) return rc;
+    hipLaunchKernelGGL(fold_partials_k, dim3(ew_grid(C)), dim3(256), 0, to_stream(stream), part, (float*)db,
+                       p.nblocks, C, db_accumulate);
+    return check_launch("sv_act_bwd/fold");
+}
+
+int sv_bias_grad(const void* dz, void* db, int accumulate, int64_t rows, int C, void* workspace,
+                 size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_bias_grad");
+    SV_REQUIRE(dz && db && rows > 0 && C > 0 && C <= kMaxC, "sv_bias_grad: bad arguments (C=%d)", C);
+    ColPlan p = col_plan(rows, C);
+    float *part = nullptr, *folded = nullptr;
+    int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_bias_grad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_k, dim3(p.nblocks), dim3(256), 256 * sizeof(float), to_stream(stream),
+                       (const float*)dz, part, rows, C, p.rows_per_block);
+    rc = check_launch("sv_bias_grad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(fold_partials_k, dim3(ew_grid(C)), dim3(256), 0, to_stream(stream), part, (float*)db,
+                       p.nblocks, C, accumulate);
+    return check_launch("sv_bias_grad/fold");
+}
+
+int sv_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int ph, int pw, int pad_t,
+                     int pad_l, int Ho, int Wo, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_maxpool2d_fwd");
+    SV_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && ph > 0 && pw > 0 && ph * pw <= 255 && Ho > 0 && Wo > 0,
+               "sv_maxpool2d_fwd: bad arguments");
+    SV_REQUIRE(pad_t >= 0 && pad_t < ph && pad_l >= 0 && pad_l < pw, "sv_maxpool2d_fwd: pad must be < pool");
+    SV_REQUIRE((int64_t)(Ho - 1) * ph - pad_t < H && (int64_t)(Wo - 1) * pw - pad_l < W,
+               "sv_maxpool2d_fwd: output extent does not fit the input");
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    hipLaunchKernelGGL(maxpool_fwd_k, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const float*)x, (float*)y, idx, N, H, W, C, ph, pw, pad_t, pad_l, Ho, Wo);
+    return check_launch("sv_maxpool2d_fwd");
+}
+
+int sv_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int ph, int pw,
+                     int pad_t, int pad_l, int Ho, int Wo, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_maxpool2d_bwd");
+    SV_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && ph > 0 && pw > 0 && Ho > 0 && Wo > 0,
+               "sv_maxpool2d_bwd: bad arguments");
+    SV_REQUIRE(pad_t >= 0 && pad_t < ph && pad_l >= 0 && pad_l < pw, "sv_maxpool2d_bwd: pad must be < pool");
+    const int64_t total = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_k, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const float*)dy, idx, (float*)dx, N, H, W, C, ph, pw, pad_t, pad_l, Ho, Wo);
+    return check_launch("sv_maxpool2d_bwd");
+}
+
+int sv_upsample2d_fwd(const void* x, void* y, int N, int H, int W, int C, int uh, int uw, int dtype,
+                      sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_upsample2d_fwd");
+    SV_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && uh > 0 && uw > 0, "sv_upsample2d_fwd: bad arguments");
+    const int64_t total = (int64_t)N * H * uh * W * uw * C;
+    hipLaunchKernelGGL(upsample_fwd_k, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const float*)x, (float*)y, N, H, W, C, uh, uw);
+    return check_launch("sv_upsample2d_fwd");
+}
+
+int sv_upsample2d_bwd(const void* dy, void* dx, int N, int H, int W, int C, int uh, int uw, int dtype,
+                      sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_upsample2d_bwd");
+    SV_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && uh > 0 && uw > 0, "sv_upsample2d_bwd: bad arguments");
+    const int64_t total = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(upsample_bwd_k, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const float*)dy, (float*)dx, N, H, W, C, uh, uw);
+    return check_launch("sv_upsample2d_bwd");
+}
+
+int sv_batchnorm_fwd_train(const void* x, const float* gamma, const float* beta, void* y, float* save_mean,
+                           float* save_invstd, float* moving_mean, float* moving_var, int64_t rows, int C, float eps,
+                           float momentum, int unbiased_moving_var, void* workspace, size_t workspace_bytes,
+                           int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_batchnorm_fwd_train");
+    SV_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && rows > 0 && C > 0 && C <= kMaxC,
+               "sv_batchnorm_fwd_train: bad arguments (C=%d)", C);
+    SV_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr),
+               "sv_batchnorm_fwd_train: moving_mean and moving_var must both be given or both be NULL");
+    ColPlan p = col_plan(rows, C);
+    float *part = nullptr, *folded = nullptr;
+    int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_batchnorm_fwd_train");
+    if (rc) return rc;
+    hipStream_t st = to_stream(stream);
+    hipLaunchKernelGGL(bn_stats_k, dim3(p.nblocks), dim3(256), 512 * sizeof(float), st, (const float*)x, part, rows,
+                       C, p.rows_per_block);
+    rc = check_launch("bn_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_k, dim3(ew_grid(C)), dim3(256), 0, st, (const float*)x, part, p.nblocks,
+                       save_mean, save_invstd, moving_mean, moving_var, rows, C, eps, momentum, unbiased_moving_var);
+    rc = check_launch("bn_finalize");
+    if (rc) return rc;
+    const int64_t total = rows * C;
+    hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, st, (const float*)x, gamma, beta,
+                       save_mean, save_invstd, 0, eps, (float*)y, total, C);
+    return check_launch("bn_apply");
+}
+
+int sv_batchnorm_fwd_infer(const void* x, const float* gamma, const float* beta, const float* moving_mean,
+                           const float* moving_var, void* y, int64_t rows, int C, float eps, int dtype,
+                           sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_batchnorm_fwd_infer");
+    SV_REQUIRE(x && gamma && beta && moving_mean && moving_var && y && rows > 0 && C > 0,
+               "sv_batchnorm_fwd_infer: bad arguments");
+    const int64_t total = rows * C;
+    hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const float*)x, gamma, beta, moving_mean, moving_var, 1, eps, (float*)y, total, C);
+    return check_launch("sv_batchnorm_fwd_infer");
+}
+
+int sv_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const float* save_mean,
+                     const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t rows,
+                     int C, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_batchnorm_bwd");
+    SV_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && rows > 0 && C > 0 &&
+                   C <= kMaxC,
+               "sv_batchnorm_bwd: bad arguments (C=%d)", C);
+    ColPlan p = col_plan(rows, C);
+    float *part = nullptr, *stats2 = nullptr;
+    int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &stats2, "sv_batchnorm_bwd");
+    if (rc) return rc;
+    hipStream_t st = to_stream(stream);
+    hipLaunchKernelGGL(bn_bwd_stats_k, dim3(p.nblocks), dim3(256), 512 * sizeof(float), st, (const float*)x,
+                       (const float*)dy, save_mean, save_invstd, part, rows, C, p.rows_per_block);
+    rc = check_launch("bn_bwd_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_fold_k, dim3(ew_grid(C)), dim3(256), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
+                       accumulate, C);
+    rc = check_launch("bn_bwd_fold");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(rows * C, 256, 8192)), dim3(256), 0, st, (const float*)x,
+                       (const float*)dy, gamma, save_mean, save_invstd, stats2, (float*)dx, rows, C);
+    return check_launch("bn_bwd_apply");
+}
+
+int sv_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int Ca, int Cb, int dtype,
+                           sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_concat_channels_fwd");
+    SV_REQUIRE(a && b && y && rows > 0 && Ca > 0 && Cb > 0, "sv_concat_channels_fwd: bad arguments");
+    hipLaunchKernelGGL(concat_fwd_k, dim3(ew_grid(rows * (Ca + Cb), 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const float*)a, (const float*)b, (float*)y, rows, Ca, Cb);
+    return check_launch("sv_concat_channels_fwd");
+}
+
+int sv_concat_channels_bwd(const void* dy, void* da, void* db, int64_t rows, int Ca, int Cb, int dtype,
+                           sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_concat_channels_bwd");
+    SV_REQUIRE(dy && da && db && rows > 0 && Ca > 0 && Cb > 0, "sv_concat_channels_bwd: bad arguments");
+    hipLaunchKernelGGL(concat_bwd_k, dim3(ew_grid(rows * (Ca + Cb), 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const float*)dy, (float*)da, (float*)db, rows, Ca, Cb);
+    return check_launch("sv_concat_channels_bwd");
+}
+
+int sv_dropout_fwd(const void* x, void* y, int64_t n, float rate, uint64_t seed, uint64_t offset, int dtype,
+                   sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_dropout_fwd");
+    SV_REQUIRE(x && y && n > 0 && rate >= 0.f && rate < 1.f, "sv_dropout_fwd: bad arguments");
+    hipLaunchKernelGGL(dropout_k, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream), (const float*)x,
+                       (float*)y, n, rate, seed, offset);
+    return check_launch("sv_dropout_fwd");
+}
+
+int sv_dropout_bwd(const void* dy, void* dx, int64_t n, float rate, uint64_t seed, uint64_t offset, int dtype,
+                   sv_stream_t stream) {
+    return sv_dropout_fwd(dy, dx, n, rate, seed, offset, dtype, stream);  // same mask, same scale
+}
+
+int sv_reduce_sum_h_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_reduce_sum_h_fwd");
+    SV_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "sv_reduce_sum_h_fwd: bad arguments");
+    hipLaunchKernelGGL(reduce_sum_h_fwd_k, dim3(ew_grid((int64_t)N * W * C)), dim3(256), 0, to_stream(stream),
+                       (const float*)x, (float*)y, N, H, W, C);
+    return check_launch("sv_reduce_sum_h_fwd");
+}
+
+int sv_reduce_sum_h_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_reduce_sum_h_bwd");
+    SV_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "sv_reduce_sum_h_bwd: bad arguments");
+    hipLaunchKernelGGL(reduce_sum_h_bwd_k, dim3(ew_grid((int64_t)N * H * W * C, 256, 8192)), dim3(256), 0,
+                       to_stream(stream), (const float*)dy, (float*)dx, N, H, W, C);
+    return check_launch("sv_reduce_sum_h_bwd");
+}
+
+int sv_gather_rows(const void* src, int src_is_f64, const int64_t* idx, float* dst, int64_t n_rows,
+                   int64_t row_elems, sv_stream_t stream) {
+    SV_REQUIRE(src && dst && n_rows > 0 && row_elems > 0, "sv_gather_rows: bad arguments");
+    const int grid = ew_grid(n_rows * row_elems, 256, 8192);
+    if (src_is_f64)
+        hipLaunchKernelGGL(gather_rows_k<double>, dim3(grid), dim3(256), 0, to_stream(stream), (const double*)src,
+                           idx, dst, n_rows, row_elems);
+    else
+        hipLaunchKernelGGL(gather_rows_k<float>, dim3(grid), dim3(256), 0, to_stream(stream), (const float*)src, idx,
+                           dst, n_rows, row_elems);
+    return check_launch("sv_gather_rows");
+}
+
+int sv_mask_input(const float* x, const float* mask, float* y, int64_t n, sv_stream_t stream) {
+    SV_REQUIRE(x && mask && y && n > 0, "sv_mask_input: bad arguments");
+    hipLaunchKernelGGL(mask_input_k, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream), x, mask, y, n);
+    return check_launch("sv_mask_input");
+}
+
+int sv_fill_f32(float* p, float value, int64_t n, sv_stream_t stream) {
+    SV_REQUIRE(p && n > 0, "sv_fill_f32: bad arguments");
+    hipLaunchKernelGGL(fill_k, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream), p, value, n);
+    return check_launch("sv_fill_f32");
+}
+
+int sv_axpy_f32(float* y, const float* x, float a, int64_t n, sv_stream_t stream) {
+    SV_REQUIRE(x && y && n > 0, "sv_axpy_f32: bad arguments");
+    hipLaunchKernelGGL(axpy_k, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream), y, x, a, n);
+    return check_launch("sv_axpy_f32");
+}
+
+int sv_cast_f32_bf16(const float* x, void* y, int64_t n, sv_stream_t stream) {
+    SV_REQUIRE(x && y && n > 0, "sv_cast_f32_bf16: bad arguments");
+    hipLaunchKernelGGL(cast_f32_bf16_k, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream), x,
+                       (__hip_bfloat16*)y, n);
+    return check_launch("sv_cast_f32_bf16");
+}
+
+int sv_cast_bf16_f32(const void* x, float* y, int64_t n, sv_stream_t stream) {
+    SV_REQUIRE(x && y && n > 0, "sv_cast_bf16_f32: bad arguments");
+    hipLaunchKernelGGL(cast_bf16_f32_k, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const __hip_bfloat16*)x, y, n);
+    return check_launch("sv_cast_bf16_f32");
+}
+
+}  // extern "C"

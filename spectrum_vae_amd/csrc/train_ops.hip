@@ -1,0 +1,380 @@
+// Losses with fused dL/dprediction, the Keras-form Adam step, Dense (GEMM) and the Sampling/KL pair.  f32.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace sv {
+
+constexpr int kLossBlocks = 1024;
+
+// ------------------------------------------------------------------------------------------------ losses
+// mode 0: squared error, weight per pixel optional;  mode 1: absolute error;
+// mode 2: BCE on probabilities against constant label; mode 3: BCE on logits against constant label.
+// value_i is summed and scaled by inv_count; dpred_i = loss_scale * d(value_i)/dpred * inv_count.
+template <int MODE>
+__global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const float* __restrict__ p,
+                                               const float* __restrict__ weight, int wstride, float wscale, int C,
+                                               float label, float inv_count, float* __restrict__ dpred,
+                                               float loss_scale, int64_t n, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v, g;
+        if (MODE == 0) {
+            const float d = p[i] - t[i];
+            const float w = weight != nullptr ? weight[(i / C) * wstride] * wscale : 1.f;
+            v = w * d * d;
+            g = 2.f * w * d;
+        } else if (MODE == 1) {
+            const float d = p[i] - t[i];
+            v = fabsf(d);
+            g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        } else if (MODE == 2) {
+            const float eps = 1e-7f;
+            const float q0 = p[i];
+            const float q = fminf(fmaxf(q0, eps), 1.f - eps);
+            v = -(label * logf(q + eps) + (1.f - label) * logf(1.f - q + eps));
+            g = (q0 >= eps && q0 <= 1.f - eps) ? -(label / (q + eps) - (1.f - label) / (1.f - q + eps)) : 0.f;
+        } else {
+            const float z = p[i];
+            v = fmaxf(z, 0.f) - z * label + log1pf(expf(-fabsf(z)));
+            g = 1.f / (1.f + expf(-z)) - label;
+        }
+        acc += v;
+        if (dpred != nullptr) dpred[i] = loss_scale * g * inv_count;
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void loss_fold_k(const float* __restrict__ partials, int nblocks, float inv_count, float* __restrict__ out,
+                            int accumulate) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += (double)partials[b];
+        const float v = (float)(s * (double)inv_count);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+
+__global__ void mse_map_k(const float* __restrict__ t, const float* __restrict__ p, const float* __restrict__ weight,
+                          int wstride, float wscale, float* __restrict__ out, int64_t n_pix, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float d = p[i * C + c] - t[i * C + c];
+            s = fmaf(d, d, s);
+        }
+        s /= (float)C;
+        if (weight != nullptr) s *= weight[i * wstride] * wscale;
+        out[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam (Keras legacy form)
+// state[0] = number of updates applied so far (int64); state[1] holds {alpha, lr} as two floats.
+__global__ void adam_prepare_k(int64_t* __restrict__ state, float lr0, float beta1, float beta2, int decay_steps,
+                               float decay_rate, int staircase) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t it = state[0];
+        double lr = (double)lr0;
+        if (decay_steps > 0) {
+            double e = (double)it / (double)decay_steps;
+            if (staircase) e = floor(e);
+            lr *= pow((double)decay_rate, e);
+        }
+        const double t = (double)(it + 1);
+        const double alpha = lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+        float* f = reinterpret_cast<float*>(state + 1);
+        f[0] = (float)alpha;
+        f[1] = (float)lr;
+        state[0] = it + 1;
+    }
+}
+
+__global__ void adam_apply_k(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, const int64_t* __restrict__ state, float beta1,
+                             float beta2, float eps, float grad_scale) {
+    const float alpha = reinterpret_cast<const float*>(state + 1)[0];
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 g = reinterpret_cast<const float4*>(grad)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float4 th = reinterpret_cast<float4*>(theta)[i];
+#define SV_ADAM1(f)                                        \
+    {                                                      \
+        const float gg = g.f * grad_scale;                 \
+        mm.f = beta1 * mm.f + (1.f - beta1) * gg;          \
+        vv.f = beta2 * vv.f + (1.f - beta2) * gg * gg;     \
+        th.f -= alpha * mm.f / (sqrtf(vv.f) + eps);        \
+    }
+        SV_ADAM1(x) SV_ADAM1(y) SV_ADAM1(z) SV_ADAM1(w)
+#undef SV_ADAM1
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        reinterpret_cast<float4*>(theta)[i] = th;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gg = grad[i] * grad_scale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gg;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gg * gg;
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] -= alpha * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM (Dense)
+// C[m,n] (+)= epi( sum_k A(m,k) * B(k,n) ), element (m,k) of A at a[m*am + k*ak], (k,n) of B at b[k*bk + n*bn].
+// 64x64 tile, BK = 16, 256 threads with a 4x4 register tile each.
+__global__ __launch_bounds__(256) void gemm_k(const float* __restrict__ a, int64_t am, int64_t ak,
+                                               const float* __restrict__ b, int64_t bk, int64_t bn,
+                                               const float* __restrict__ bias, float* __restrict__ c, int M, int N,
+                                               int K, int act, float alpha, int accumulate) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        // 1024 elements per tile, 4 per thread; make the unit-stride dimension the fastest-varying one
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int id = threadIdx.x + e * 256;
+            int mm, kk;
+            if (ak == 1) {
+                kk = id & 15;
+                mm = id >> 4;
+            } else {
+                mm = id & 63;
+                kk = id >> 6;
+            }
+            const int gm = m0 + mm, gk = k0 + kk;
+            As[kk][mm] = (gm < M && gk < K) ? a[gm * am + gk * ak] : 0.f;
+            int nn, k2;
+            if (bk == 1) {
+                k2 = id & 15;
+                nn = id >> 4;
+            } else {
+                nn = id & 63;
+                k2 = id >> 6;
+            }
+            const int gn = n0 + nn, gk2 = k0 + k2;
+            Bs[k2][nn] = (gn < N && gk2 < K) ? b[gk2 * bk + gn * bn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ty * 4 + i;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tx * 4 + j;
+            if (gn >= N) continue;
+            float v = acc[i][j];
+            if (bias != nullptr) v += bias[gn];
+            v = act_apply(v, act, alpha);
+            float* cp = c + (int64_t)gm * N + gn;
+            *cp = accumulate ? *cp + v : v;
+        }
+    }
+}
+
+int launch_gemm(const float* a, int64_t am, int64_t ak, const float* b, int64_t bk, int64_t bn, const float* bias,
+                float* c, int M, int N, int K, int act, float alpha, int accumulate, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64));
+    hipLaunchKernelGGL(gemm_k, grid, dim3(256), 0, st, a, am, ak, b, bk, bn, bias, c, M, N, K, act, alpha,
+                       accumulate);
+    return check_launch("gemm");
+}
+
+// ------------------------------------------------------------------------------------------------ Sampling + KL
+__global__ __launch_bounds__(256) void reparam_fwd_k(const float* __restrict__ mean, const float* __restrict__ logvar,
+                                                      const float* __restrict__ eps_in, float* __restrict__ z,
+                                                      float* __restrict__ eps_out, float* __restrict__ partials,
+                                                      int64_t n, uint64_t seed, uint64_t offset) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float e;
+        if (eps_in != nullptr) {
+            e = eps_in[i];
+        } else {  // Box-Muller on two counter-hash uniforms
+            const float u1 = fmaxf(u01(seed, 2 * (offset + (uint64_t)i)), 5.9604645e-8f);
+            const float u2 = u01(seed, 2 * (offset + (uint64_t)i) + 1);
+            e = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+        }
+        const float mu = mean[i], lv = logvar[i];
+        z[i] = mu + expf(0.5f * lv) * e;
+        if (eps_out != nullptr) eps_out[i] = e;
+        acc += -0.5f * (1.f + lv - mu * mu - expf(lv));
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void reparam_bwd_k(const float* __restrict__ mean, const float* __restrict__ logvar,
+                              const float* __restrict__ eps, const float* __restrict__ dz, float* __restrict__ dmean,
+                              float* __restrict__ dlogvar, float klw_over_b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float mu = mean[i], lv = logvar[i], g = dz[i];
+        dmean[i] = g + klw_over_b * mu;
+        dlogvar[i] = g * 0.5f * expf(0.5f * lv) * eps[i] + klw_over_b * 0.5f * (expf(lv) - 1.f);
+    }
+}
+
+}  // namespace sv
+
+using namespace sv;
+
+extern "C" {
+
+size_t sv_loss_workspace_bytes(void) { return (size_t)kLossBlocks * sizeof(float); }
+
+int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int weight_stride, float weight_scale,
+                float* loss_out, int accumulate, void* dpred, float loss_scale, int64_t n_pix, int C, float* partials,
+                int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_loss_mse");
+    SV_REQUIRE(y_true && y_pred && loss_out && partials && n_pix > 0 && C > 0, "sv_loss_mse: bad arguments");
+    SV_REQUIRE(weight == nullptr || weight_stride > 0, "sv_loss_mse: weight_stride must be positive");
+    const int64_t n = n_pix * C;
+    const int nb = ew_grid(n, 256, kLossBlocks);
+    const float inv = 1.f / (float)n;
+    hipLaunchKernelGGL(loss_k<0>, dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
+                       (const float*)y_pred, weight, weight_stride, weight_scale, C, 0.f, inv, (float*)dpred,
+                       loss_scale, n, partials);
+    int rc = check_launch("sv_loss_mse");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(64), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    return check_launch("sv_loss_mse/fold");
+}
+
+int sv_loss_mse_map(const void* y_true, const void* y_pred, const float* weight, int weight_stride,
+                    float weight_scale, float* out, int64_t n_pix, int C, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_loss_mse_map");
+    SV_REQUIRE(y_true && y_pred && out && n_pix > 0 && C > 0, "sv_loss_mse_map: bad arguments");
+    hipLaunchKernelGGL(mse_map_k, dim3(ew_grid(n_pix, 256, 8192)), dim3(256), 0, to_stream(stream),
+                       (const float*)y_true, (const float*)y_pred, weight, weight_stride, weight_scale, out, n_pix, C);
+    return check_launch("sv_loss_mse_map");
+}
+
+int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int accumulate, void* dpred,
+                float loss_scale, int64_t n, float* partials, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_loss_mae");
+    SV_REQUIRE(y_true && y_pred && loss_out && partials && n > 0, "sv_loss_mae: bad arguments");
+    const int nb = ew_grid(n, 256, kLossBlocks);
+    const float inv = 1.f / (float)n;
+    hipLaunchKernelGGL(loss_k<1>, dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
+                       (const float*)y_pred, (const float*)nullptr, 1, 1.f, 1, 0.f, inv, (float*)dpred, loss_scale, n,
+                       partials);
+    int rc = check_launch("sv_loss_mae");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(64), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    return check_launch("sv_loss_mae/fold");
+}
+
+int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out, int accumulate, void* dpred,
+                float loss_scale, int64_t n, float* partials, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_loss_bce");
+    SV_REQUIRE(pred && loss_out && partials && n > 0, "sv_loss_bce: bad arguments");
+    const int nb = ew_grid(n, 256, kLossBlocks);
+    const float inv = 1.f / (float)n;
+    if (from_logits)
+        hipLaunchKernelGGL(loss_k<3>, dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
+                           (const float*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (float*)dpred,
+                           loss_scale, n, partials);
+    else
+        hipLaunchKernelGGL(loss_k<2>, dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
+                           (const float*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (float*)dpred,
+                           loss_scale, n, partials);
+    int rc = check_launch("sv_loss_bce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(64), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    return check_launch("sv_loss_bce/fold");
+}
+
+int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float beta2, int decay_steps,
+                          float decay_rate, int staircase, sv_stream_t stream) {
+    SV_REQUIRE(step_state != nullptr, "sv_adam_keras_prepare: null state");
+    SV_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "sv_adam_keras_prepare: betas out of range");
+    hipLaunchKernelGGL(adam_prepare_k, dim3(1), dim3(64), 0, to_stream(stream), step_state, lr0, beta1, beta2,
+                       decay_steps, decay_rate, staircase);
+    return check_launch("sv_adam_keras_prepare");
+}
+
+int sv_adam_keras_apply(float* theta, const float* grad, float* m, float* v, int64_t n, const int64_t* step_state,
+                        float beta1, float beta2, float eps, float grad_scale, sv_stream_t stream) {
+    SV_REQUIRE(theta && grad && m && v && step_state && n > 0, "sv_adam_keras_apply: bad arguments");
+    SV_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                   ((uintptr_t)v % 16 == 0),
+               "sv_adam_keras_apply: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_apply_k, dim3(ew_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, to_stream(stream), theta,
+                       grad, m, v, n, step_state, beta1, beta2, eps, grad_scale);
+    return check_launch("sv_adam_keras_apply");
+}
+
+int sv_dense_fwd(const void* x, const void* w, const void* bias, void* y, int M, int K, int N, int act, float alpha,
+                 int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_dense_fwd");
+    SV_REQUIRE(x && w && y && M > 0 && K > 0 && N > 0, "sv_dense_fwd: bad arguments");
+    return launch_gemm((const float*)x, K, 1, (const float*)w, N, 1, (const float*)bias, (float*)y, M, N, K, act,
+                       alpha, 0, to_stream(stream));
+}
+
+// dx[M,K] = dz[M,N] w[K,N]^T
+int sv_dense_dgrad(const void* dz, const void* w, void* dx, int M, int K, int N, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_dense_dgrad");
+    SV_REQUIRE(dz && w && dx && M > 0 && K > 0 && N > 0, "sv_dense_dgrad: bad arguments");
+    return launch_gemm((const float*)dz, N, 1, (const float*)w, 1, N, nullptr, (float*)dx, M, K, N, SV_ACT_NONE, 0.f,
+                       0, to_stream(stream));
+}
+
+// dw[K,N] (+)= x[M,K]^T dz[M,N]
+int sv_dense_wgrad(const void* x, const void* dz, void* dw, int accumulate, int M, int K, int N, int dtype,
+                   sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_dense_wgrad");
+    SV_REQUIRE(x && dz && dw && M > 0 && K > 0 && N > 0, "sv_dense_wgrad: bad arguments");
+    return launch_gemm((const float*)x, 1, K, (const float*)dz, N, 1, nullptr, (float*)dw, K, N, M, SV_ACT_NONE, 0.f,
+                       accumulate, to_stream(stream));
+}
+
+int sv_reparam_kl_fwd(const float* mean, const float* logvar, const float* eps_in, float* z, float* eps_out,
+                      float* kl_out, float* partials, int B, int D, uint64_t seed, uint64_t offset,
+                      sv_stream_t stream) {
+    SV_REQUIRE(mean && logvar && z && kl_out && partials && B > 0 && D > 0, "sv_reparam_kl_fwd: bad arguments");
+    const int64_t n = (int64_t)B * D;
+    const int nb = ew_grid(n, 256, kLossBlocks);
+    hipLaunchKernelGGL(reparam_fwd_k, dim3(nb), dim3(256), 0, to_stream(stream), mean, logvar, eps_in, z, eps_out,
+                       partials, n, seed, offset);
+    int rc = check_launch("sv_reparam_kl_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(64), 0, to_stream(stream), partials, nb, 1.f / (float)B, kl_out, 0);
+    return check_launch("sv_reparam_kl_fwd/fold");
+}
+
+int sv_reparam_kl_bwd(const float* mean, const float* logvar, const float* eps, const float* dz, float* dmean,
+                      float* dlogvar, float kl_weight, int B, int D, sv_stream_t stream) {
+    SV_REQUIRE(mean && logvar && eps && dz && dmean && dlogvar && B > 0 && D > 0, "sv_reparam_kl_bwd: bad arguments");
+    const int64_t n = (int64_t)B * D;
+    hipLaunchKernelGGL(reparam_bwd_k, dim3(ew_grid(n)), dim3(256), 0, to_stream(stream), mean, logvar, eps, dz,
+                       dmean, dlogvar, kl_weight / (float)B, n);
+    return check_launch("sv_reparam_kl_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,443 @@
+"""tf.keras.Model look-alike: build / call / compile / fit / predict on the HIP layer engine.
+
+Reference surface being mirrored (what the three drivers call): ``model.build_graph((1,H,W,C))``,
+``model.encoder.summary()``, ``model(x, training=True)``, ``model.trainable_variables``,
+``model.compile(optimizer=, loss=)``, ``model.fit(X, Y, epochs=, shuffle=, validation_data=, callbacks=,
+batch_size=)`` -> ``.history["loss"|"val_loss"]``, ``model.predict(X, batch_size=32)`` -> NumPy
+(run_model.py:65-72,140-148,281-300,356-357; run_context_encoder.py:130-139,242-258,399,491).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import losses as losses_mod
+from . import ops
+from .losses import to_device_f32
+from .nn import DEFAULT_SEED, BufferPool, CallCtx, DTensor, Layer, Sequential, Variable, as_dtensor, default_device
+
+ALIGN = 4  # floats; every variable starts on a 16-byte boundary of the flat buffer
+
+
+class History:
+    def __init__(self):
+        self.history: Dict[str, List[float]] = {}
+        self.epoch: List[int] = []
+
+    def record(self, epoch, **vals):
+        self.epoch.append(epoch)
+        for k, v in vals.items():
+            self.history.setdefault(k, []).append(float(v))
+
+
+class EarlyStopping:
+    """tf.keras.callbacks.EarlyStopping(monitor=, patience=) (run_model.py:278)."""
+
+    def __init__(self, monitor="val_loss", patience=0, min_delta=0.0):
+        self.monitor, self.patience, self.min_delta = monitor, int(patience), abs(float(min_delta))
+        self.best = math.inf
+        self.wait = 0
+        self.stopped_epoch = 0
+
+    def on_train_begin(self):
+        self.best, self.wait, self.stopped_epoch = math.inf, 0, 0
+
+    def on_epoch_end(self, epoch: int, logs: Dict[str, float]) -> bool:
+        cur = logs.get(self.monitor)
+        if cur is None:
+            return False
+        self.wait += 1
+        if cur < self.best - self.min_delta:
+            self.best, self.wait = cur, 0
+        if self.wait >= self.patience and epoch > 0:
+            self.stopped_epoch = epoch
+            return True
+        return False
+
+
+class Model(Layer):
+    """Base of every model class.  Subclasses create their sublayers in ``__init__`` and implement
+    ``_build`` (shape propagation), ``forward`` and ``backward``; a Sequential-only model can simply
+    set ``self._stack``."""
+
+    def __init__(self, name: Optional[str] = None, seed: int = DEFAULT_SEED):
+        super().__init__(name)
+        self._seed = seed
+        self._pool = BufferPool()
+        self._params: Optional[torch.Tensor] = None
+        self._grads: Optional[torch.Tensor] = None
+        self._state: Optional[torch.Tensor] = None
+        self._calls: List[CallCtx] = []
+        self._infer_slot = 0
+        self.optimizer = None
+        self.loss = None
+        self._reducer = None  # data-parallel gradient reducer (parallel.GradReducer)
+        self._graphs: Dict[tuple, object] = {}
+        self.use_graphs = True
+        self.stop_training = False
+
+    # ------------------------------------------------------------------ structure
+    def sublayers(self) -> List[Layer]:
+        out = []
+        for v in self.__dict__.values():
+            if isinstance(v, Layer) and v is not self:
+                out.append(v)
+            elif isinstance(v, (list, tuple)):
+                out.extend(l for l in v if isinstance(l, Layer))
+        return out
+
+    def build(self, input_shape):
+        """Keras ``Model.build`` takes the shape WITH the batch axis."""
+        shape = tuple(input_shape)
+        if len(shape) >= 2 and (shape[0] is None or len(shape) in (2, 3, 4)):
+            shape = shape[1:]
+        return Layer.build(self, shape)
+
+    def build_graph(self, test_shape):
+        """Shape-propagation smoke test of the reference (autoencoder.py:538-547 and siblings)."""
+        self.build(tuple(test_shape))
+
+    @property
+    def variables(self) -> List[Variable]:
+        return self.all_variables()
+
+    @property
+    def trainable_variables(self) -> List[Variable]:
+        return [v for v in self.all_variables() if v.trainable]
+
+    @property
+    def non_trainable_variables(self) -> List[Variable]:
+        return [v for v in self.all_variables() if not v.trainable]
+
+    def summary(self, print_fn=print):
+        if not self.built:
+            raise ValueError("This model has not yet been built. Call build_graph() first.")
+        print_fn(f'Model: "{self.name}"')
+        for l in self.sublayers():
+            if isinstance(l, Sequential):
+                l.summary(print_fn)
+        print_fn(f"Total params: {self.count_params()}")
+
+    # ------------------------------------------------------------------ parameters on the device
+    def _materialize(self, device: Optional[torch.device] = None):
+        if self._params is not None:
+            return
+        if not self.built:
+            raise ValueError("build the model (build_graph / first call) before running it")
+        device = device or default_device()
+        self._pool.device = device
+        tv, ntv = self.trainable_variables, self.non_trainable_variables
+        rng = np.random.default_rng(self._seed)
+
+        def layout(vs):
+            off = 0
+            for v in vs:
+                v.offset = off
+                off += -(-v.size // ALIGN) * ALIGN
+            return max(off, ALIGN)
+
+        n_t, n_s = layout(tv), layout(ntv)
+        host_p = np.zeros(n_t, np.float32)
+        for v in tv:
+            host_p[v.offset:v.offset + v.size] = v.initial_value(rng).ravel()
+        host_s = np.zeros(n_s, np.float32)
+        for v in ntv:
+            host_s[v.offset:v.offset + v.size] = v.initial_value(rng).ravel()
+        self._params = torch.from_numpy(host_p).to(device)
+        self._grads = torch.zeros(n_t, dtype=torch.float32, device=device)
+        self._state = torch.from_numpy(host_s).to(device)
+        for v in tv:
+            v.data = self._params[v.offset:v.offset + v.size].view(v.shape)
+            v.grad = self._grads[v.offset:v.offset + v.size].view(v.shape)
+            v.owner = self
+        for v in ntv:
+            v.data = self._state[v.offset:v.offset + v.size].view(v.shape)
+            v.owner = self
+        for l in self._all_layers():
+            if isinstance(l, Sequential):
+                l._owner_model = self
+
+    def _all_layers(self) -> List[Layer]:
+        out, stack = [], [self]
+        while stack:
+            l = stack.pop()
+            out.append(l)
+            stack.extend(l.sublayers())
+        return out
+
+    def get_weights(self) -> List[np.ndarray]:
+        self._materialize()
+        return [v.numpy() for v in self.variables]
+
+    def set_weights(self, weights: Sequence[np.ndarray]):
+        self._materialize()
+        vs = self.variables
+        if len(weights) != len(vs):
+            raise ValueError(f"expected {len(vs)} arrays, got {len(weights)}")
+        for v, w in zip(vs, weights):
+            if tuple(np.shape(w)) != v.shape:
+                raise ValueError(f"{v.name}: expected shape {v.shape}, got {np.shape(w)}")
+            v.assign(w)
+
+    def set_trainable_weights(self, weights: Sequence[np.ndarray]):
+        self._materialize()
+        tv = self.trainable_variables
+        if len(weights) != len(tv):
+            raise ValueError(f"expected {len(tv)} arrays, got {len(weights)}")
+        for v, w in zip(tv, weights):
+            v.assign(w)
+
+    def state_dict(self) -> dict:
+        self._materialize()
+        return {"params": self._params.cpu().clone(), "state": self._state.cpu().clone()}
+
+    def load_state_dict(self, sd: dict):
+        self._materialize()
+        self._params.copy_(sd["params"].to(self._params.device))
+        self._state.copy_(sd["state"].to(self._state.device))
+
+    # ------------------------------------------------------------------ execution
+    def _prep_input(self, x) -> torch.Tensor:
+        if isinstance(x, (list, tuple)):
+            raise TypeError(f"{self.name}: list inputs are not accepted here")
+        t = to_device_f32(x, self._pool.device or default_device())
+        if not self.built:
+            self.build(tuple(t.shape))
+        self._materialize(t.device)
+        if tuple(t.shape[1:]) != self.input_shape_:
+            raise ValueError(f"{self.name}: input {tuple(t.shape[1:])} does not match the built shape {self.input_shape_}")
+        return t
+
+    def __call__(self, x, training: bool = False):
+        """Eager call: returns a copy of the output (internal buffers are reused by later calls).
+        A training-mode call is remembered until ``zero_grad``/the optimizer step so ``backward`` can run."""
+        t = self._prep_input(x)
+        y = self.forward_raw(t, training)
+        return as_dtensor(y.clone())
+
+    def call(self, x, training: bool = False):
+        return self.__call__(x, training=training)
+
+    def forward_raw(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+        """Forward on a prepared device tensor; the result aliases the model's buffer pool."""
+        if training:
+            ctx = CallCtx(self._pool, len(self._calls), True)
+            self._calls.append(ctx)
+        else:
+            ctx = CallCtx(self._pool, "infer", False)
+        return self.forward(ctx, x)
+
+    def backward_raw(self, dy: torch.Tensor, call: int = -1, need_dx: bool = False):
+        """Backward of the ``call``-th remembered training call; parameter gradients accumulate."""
+        return self.backward(self._calls[call], dy, need_dx=need_dx)
+
+    def zero_grad(self):
+        self._materialize()
+        self._grads.zero_()
+        self._calls.clear()
+
+    def _run_sub(self, seq: Sequential, x, training: bool):
+        """``model.encoder(x)`` / ``model.decoder(z)``: run one sub-stack on its own."""
+        t = to_device_f32(x, self._pool.device or default_device())
+        self._materialize(t.device)
+        ctx = CallCtx(self._pool, ("sub", id(seq)), False)
+        if training:
+            raise NotImplementedError("sub-model calls are inference-only; train through the owning model")
+        return as_dtensor(seq.forward(ctx, t).clone())
+
+    # default forward/backward for models that are one stack of layers
+    def forward(self, ctx, x):
+        return self._stack.forward(ctx, x)
+
+    def backward(self, ctx, dy, need_dx=True):
+        return self._stack.backward(ctx, dy, need_dx)
+
+    def _build(self, in_shape):
+        return self._stack.build(in_shape)
+
+    # ------------------------------------------------------------------ compile / fit / predict
+    def compile(self, optimizer=None, loss=None, **_):
+        self.optimizer = optimizer
+        self.loss = losses_mod.get(loss) if loss is not None else None
+        self._graphs.clear()
+
+    def distribute(self, reducer):
+        """Attach a data-parallel gradient reducer (see ``parallel.GradReducer``)."""
+        self._reducer = reducer
+        self._graphs.clear()
+
+    def _step_buffers(self, bs: int, y_shape: tuple):
+        p = self._pool
+        return {
+            "x": p.get(("fit", "x"), (bs,) + self.input_shape_),
+            "y": p.get(("fit", "y"), (bs,) + tuple(y_shape)),
+            "dpred": p.get(("fit", "dpred"), (bs,) + self.output_shape_),
+            "loss": p.get(("fit", "loss"), (1,)),
+            "acc": p.get(("fit", "acc"), (1,)),
+        }
+
+    def _train_step_body(self, b: dict, same_xy: bool, weight: float):
+        """fwd -> loss (+dL/dpred) -> bwd -> [all-reduce] -> Adam, all enqueued on the current stream."""
+        self.zero_grad_raw()
+        pred = self.forward_raw(b["x"], True)
+        yt = b["x"] if same_xy else b["y"]
+        self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0)
+        ops.axpy(b["acc"], b["loss"], weight)
+        self.backward_raw(b["dpred"], -1, need_dx=False)
+        scale = 1.0
+        if self._reducer is not None:
+            scale = self._reducer.all_reduce(self._grads)
+        self.optimizer.apply_model(self, scale)
+        self._calls.clear()
+
+    def zero_grad_raw(self):
+        ops.fill(self._grads, 0.0)
+        self._calls.clear()
+
+    def train_on_device_batch(self, b: dict, same_xy: bool, weight: float):
+        """One optimizer step on the batch already sitting in ``b['x']`` / ``b['y']``; replays a captured
+        HIP graph after the first (eager, buffer-allocating) step at this batch size."""
+        bs = b["x"].shape[0]
+        key = (bs, same_xy, float(weight), id(self.optimizer), id(self.loss))
+        capturable = self.use_graphs and self._reducer is None and self.graph_safe()
+        if not capturable:
+            self._train_step_body(b, same_xy, weight)
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            self._train_step_body(b, same_xy, weight)  # eager: allocates every buffer this batch size needs
+            self._graphs[key] = "warm"
+            return
+        if g == "warm":
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._train_step_body(b, same_xy, weight)
+            self._graphs[key] = graph
+            g = graph
+        g.replay()
+
+    def graph_safe(self) -> bool:
+        """A step can be frozen into a HIP graph when no layer needs fresh host-side arguments per call."""
+        from .nn import Dropout
+        return not any(isinstance(l, Dropout) and l.rate > 0 for l in self._all_layers())
+
+    def _to_resident(self, a, device):
+        """Training data lives in HBM in its original precision (float64 stays float64; the batch gather
+        casts to float32, as Keras does on the way into the model)."""
+        if isinstance(a, torch.Tensor):
+            t = a.as_subclass(torch.Tensor)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a))
+        if t.dtype not in (torch.float32, torch.float64):
+            t = t.to(torch.float32)
+        return t.to(device).contiguous()
+
+    def fit(self, x, y=None, epochs=1, shuffle=True, validation_data=None, callbacks=None, batch_size=32,
+            verbose=1, seed: Optional[int] = None):
+        if self.optimizer is None or self.loss is None:
+            raise RuntimeError("compile(optimizer=..., loss=...) must be called before fit")
+        device = default_device()
+        same_xy = y is None or y is x
+        X = self._to_resident(x, device)
+        Y = X if same_xy else self._to_resident(y, device)
+        if not self.built:
+            self.build((None,) + tuple(X.shape[1:]))
+        self._materialize(device)
+        n = X.shape[0]
+        if Y.shape[0] != n:
+            raise ValueError("x and y have different numbers of samples")
+        if n == 0:
+            raise ValueError("fit: empty training set")
+        bs = int(batch_size)
+        hist = History()
+        cbs = list(callbacks or [])
+        for cb in cbs:
+            cb.on_train_begin()
+        gen = torch.Generator(device=device)
+        gen.manual_seed(self._seed if seed is None else seed)
+        y_shape = tuple(Y.shape[1:])
+        for epoch in range(int(epochs)):
+            perm = torch.randperm(n, device=device, generator=gen) if shuffle else None
+            acc = None
+            for start in range(0, n, bs):
+                cur = min(bs, n - start)
+                b = self._step_buffers(cur, y_shape)
+                if start == 0:
+                    acc = self._pool.get(("fit", "acc"), (1,))
+                    ops.fill(acc, 0.0)
+                b["acc"] = acc
+                idx = perm[start:start + cur] if perm is not None else None
+                src_x = X if idx is not None else X[start:start + cur]
+                ops.gather_rows(src_x, idx, b["x"])
+                if not same_xy:
+                    ops.gather_rows(Y if idx is not None else Y[start:start + cur], idx, b["y"])
+                self.train_on_device_batch(b, same_xy, float(cur))
+            logs = {"loss": float(acc.item()) / n}  # one host sync per epoch
+            if validation_data is not None:
+                vx, vy = validation_data[0], validation_data[1]
+                logs["val_loss"] = self.evaluate(vx, None if vy is vx else vy, batch_size=bs)
+            hist.record(epoch, **logs)
+            if verbose:
+                msg = " - ".join(f"{k}: {v:.6f}" for k, v in logs.items())
+                print(f"Epoch {epoch + 1}/{epochs} - {msg}")
+            stop = False
+            for cb in cbs:
+                stop = cb.on_epoch_end(epoch, logs) or stop
+            if stop or self.stop_training:
+                break
+        self.history = hist
+        return hist
+
+    def evaluate(self, x, y=None, batch_size=32) -> float:
+        """Mean loss over a data set in inference mode (``training=False``), sample-weighted over batches."""
+        device = default_device()
+        same_xy = y is None or y is x
+        X = self._to_resident(x, device)
+        Y = X if same_xy else self._to_resident(y, device)
+        if not self.built:
+            self.build((None,) + tuple(X.shape[1:]))
+        self._materialize(device)
+        n, bs = X.shape[0], int(batch_size)
+        acc = self._pool.get(("eval", "acc"), (1,))
+        loss = self._pool.get(("eval", "loss"), (1,))
+        ops.fill(acc, 0.0)
+        for start in range(0, n, bs):
+            cur = min(bs, n - start)
+            xb = self._pool.get(("eval", "x"), (cur,) + self.input_shape_)
+            ops.gather_rows(X[start:start + cur], None, xb)
+            if same_xy:
+                yb = xb
+            else:
+                yb = self._pool.get(("eval", "y"), (cur,) + tuple(Y.shape[1:]))
+                ops.gather_rows(Y[start:start + cur], None, yb)
+            pred = self.forward_raw(xb, False)
+            self.loss.value_and_grad(yb, pred, loss, None, 1.0)
+            ops.axpy(acc, loss, float(cur))
+        return float(acc.item()) / max(n, 1)
+
+    def predict(self, x, batch_size=32, verbose=0) -> np.ndarray:
+        device = default_device()
+        X = self._to_resident(x, device)
+        if not self.built:
+            self.build((None,) + tuple(X.shape[1:]))
+        self._materialize(device)
+        n, bs = X.shape[0], int(batch_size)
+        out = torch.empty((n,) + self.output_shape_, dtype=torch.float32, device=device)
+        for start in range(0, n, bs):
+            cur = min(bs, n - start)
+            xb = self._pool.get(("predict", "x"), (cur,) + self.input_shape_)
+            ops.gather_rows(X[start:start + cur], None, xb)
+            out[start:start + cur].copy_(self.forward_raw(xb, False))
+        return out.cpu().numpy()
+
+
+class SequentialModel(Model):
+    """A Model that is exactly one Sequential stack."""
+
+    def __init__(self, layers: Sequence[Layer], name=None, seed: int = DEFAULT_SEED):
+        super().__init__(name, seed)
+        self._stack = Sequential(list(layers), name=(name or "model") + "_stack")

@@ -1,0 +1,726 @@
+"""Layer engine behind the tf.keras-shaped model classes.
+
+Every layer has an explicit ``forward`` and ``backward`` that enqueue kernels of
+``libspectrum_hip.so`` on the current HIP stream; there is no autograd tracer.
+Parameters of a model live in ONE flat float32 device buffer (gradients, Adam
+moments likewise), so the optimizer step is a single launch and the
+data-parallel exchange is a single all-reduce.  Activations and gradients live
+in a per-model buffer pool keyed by (layer, role, call slot, shape): after the
+first step at a given batch size nothing is allocated, which is what makes a
+training step capturable into a HIP graph.
+
+The classes mirror the tf.keras layers the reference builds its models from
+(``autoencoder.py``, ``unet.py``, ``context_encoder.py``): same constructor
+arguments, NHWC activations, Keras weight layouts and weight ordering.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+DEFAULT_SEED = 1833  # global_vars.py:11
+
+
+# --------------------------------------------------------------------------- small utilities
+class DTensor(torch.Tensor):
+    """Device tensor whose ``numpy()`` copies to the host, as tf.Tensor.numpy() does
+    (run_context_encoder.py:406-410 prints ``loss.numpy()``)."""
+
+    def numpy(self):  # noqa: D401
+        return torch.Tensor.numpy(self.detach().as_subclass(torch.Tensor).cpu())
+
+
+def as_dtensor(t: torch.Tensor) -> "DTensor":
+    return t.as_subclass(DTensor)
+
+
+def _pair(v) -> Tuple[int, int]:
+    if isinstance(v, (tuple, list)):
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
+def _act_name(activation) -> Tuple[Optional[str], float]:
+    """Normalise a keras ``activation=`` argument: a name, None, or a LeakyReLU layer instance."""
+    if activation is None:
+        return None, 0.0
+    if isinstance(activation, LeakyReLU):
+        return "lrelu", activation.alpha
+    if isinstance(activation, str):
+        a = activation.lower()
+        if a in ("linear", "none"):
+            return None, 0.0
+        if a in ("relu", "elu", "tanh", "sigmoid"):
+            return a, 1.0
+        raise ValueError(f"unsupported activation {activation!r}")
+    raise TypeError(f"unsupported activation object {activation!r}")
+
+
+def default_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("spectrum_vae_amd needs a GPU: the HIP kernels are the only execution path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Variable:
+    """One weight tensor: a view into the owning model's flat parameter buffer."""
+
+    def __init__(self, name: str, shape: Sequence[int], init: str, trainable: bool = True):
+        self.name = name
+        self.shape = tuple(int(s) for s in shape)
+        self.init = init
+        self.trainable = trainable
+        self.size = int(np.prod(self.shape))
+        self.offset = -1
+        self.data: Optional[torch.Tensor] = None  # view, set by Model._materialize
+        self.grad: Optional[torch.Tensor] = None
+        self.owner = None
+
+    def initial_value(self, rng: np.random.Generator) -> np.ndarray:
+        if self.init == "zeros":
+            return np.zeros(self.shape, np.float32)
+        if self.init == "ones":
+            return np.ones(self.shape, np.float32)
+        if self.init == "glorot_uniform":
+            if len(self.shape) == 2:
+                fan_in, fan_out = self.shape
+            else:
+                rf = int(np.prod(self.shape[:-2]))
+                fan_in, fan_out = self.shape[-2] * rf, self.shape[-1] * rf
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            return rng.uniform(-lim, lim, self.shape).astype(np.float32)
+        if self.init == "normal0.02":  # tf.random_normal_initializer(0., 0.02), unet.py:36,65,121
+            return (rng.standard_normal(self.shape) * 0.02).astype(np.float32)
+        raise ValueError(self.init)
+
+    def numpy(self) -> np.ndarray:
+        return self.data.detach().cpu().numpy().copy()
+
+    def assign(self, value):
+        v = torch.as_tensor(np.asarray(value, dtype=np.float32)).reshape(self.shape)
+        self.data.copy_(v.to(self.data.device))
+
+    def __repr__(self):
+        return f"<Variable {self.name} {self.shape}>"
+
+
+class BufferPool:
+    """Persistent device buffers keyed by (owner, role, slot, shape, dtype)."""
+
+    def __init__(self):
+        self.bufs: Dict[tuple, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
+        self.device: Optional[torch.device] = None
+
+    def get(self, key, shape, dtype=torch.float32) -> torch.Tensor:
+        k = (key, tuple(shape), dtype)
+        t = self.bufs.get(k)
+        if t is None:
+            t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+            self.bufs[k] = t
+        return t
+
+    def workspace(self, nbytes: int) -> torch.Tensor:
+        """Shared scratch for reductions; grows, never shrinks.  Kernels using it run on one stream."""
+        nbytes = max(int(nbytes), 256)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class CallCtx:
+    """State of one forward call: what each layer saved for its backward."""
+
+    def __init__(self, pool: BufferPool, slot: int, training: bool):
+        self.pool = pool
+        self.slot = slot
+        self.training = training
+        self.saved: Dict[int, dict] = {}
+
+    def buf(self, layer, role, shape, dtype=torch.float32):
+        return self.pool.get((id(layer), role, self.slot), shape, dtype)
+
+
+# --------------------------------------------------------------------------- base layer
+class Layer:
+    _counters: Dict[str, int] = {}
+
+    def __init__(self, name: Optional[str] = None):
+        cls = type(self).__name__
+        if name is None:
+            n = Layer._counters.get(cls, 0)
+            Layer._counters[cls] = n + 1
+            name = f"{cls.lower()}_{n}" if n else cls.lower()
+        self.name = name
+        self.built = False
+        self.input_shape_: Optional[tuple] = None
+        self.output_shape_: Optional[tuple] = None
+        self._own_vars: List[Variable] = []
+
+    # ---- building (pure host logic; runs without a GPU)
+    def build(self, in_shape: tuple) -> tuple:
+        """Create Variables for an input of ``in_shape`` (no batch axis); return the output shape."""
+        in_shape = tuple(int(s) for s in in_shape)
+        if self.built:
+            if in_shape != self.input_shape_:
+                raise ValueError(f"{self.name}: built for input {self.input_shape_}, called with {in_shape}")
+            return self.output_shape_
+        self.input_shape_ = in_shape
+        self.output_shape_ = tuple(int(s) for s in self._build(in_shape))
+        self.built = True
+        return self.output_shape_
+
+    def _build(self, in_shape):
+        return in_shape
+
+    def add_weight(self, suffix, shape, init, trainable=True) -> Variable:
+        v = Variable(f"{self.name}/{suffix}", shape, init, trainable)
+        self._own_vars.append(v)
+        return v
+
+    def sublayers(self) -> List["Layer"]:
+        return []
+
+    def all_variables(self) -> List[Variable]:
+        out = list(self._own_vars)
+        for l in self.sublayers():
+            out.extend(l.all_variables())
+        return out
+
+    def count_params(self) -> int:
+        return sum(v.size for v in self.all_variables())
+
+    # ---- execution (HIP only)
+    def forward(self, ctx: CallCtx, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def backward(self, ctx: CallCtx, dy: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
+        raise NotImplementedError
+
+
+class InputLayer(Layer):
+    """layers.Input(shape=...) placeholder at the head of the reference's Sequentials."""
+
+    def __init__(self, shape=None, name=None):
+        super().__init__(name)
+        if isinstance(shape, int):
+            shape = (shape,)
+        self.shape = tuple(shape) if shape is not None else None
+
+    def _build(self, in_shape):
+        if self.shape is not None and tuple(self.shape) != tuple(in_shape):
+            raise ValueError(f"Input layer expects {self.shape}, got {in_shape}")
+        return in_shape
+
+    def forward(self, ctx, x):
+        return x
+
+    def backward(self, ctx, dy, need_dx=True):
+        return dy
+
+
+def Input(shape=None, **_):
+    return InputLayer(shape)
+
+
+# --------------------------------------------------------------------------- convolution
+class _ConvBase(Layer):
+    transposed = False
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", activation=None, use_bias=True,
+                 kernel_initializer="glorot_uniform", input_shape=None, name=None):
+        super().__init__(name)
+        self.filters = int(filters)  # Keras-2 casts float filter counts (autoencoder.py:508 divides with /=)
+        self.kernel_size = _pair(kernel_size)
+        self.strides = _pair(strides)
+        self.padding = padding.lower()
+        self.act, self.alpha = _act_name(activation)
+        self.use_bias = use_bias
+        self.kernel_initializer = kernel_initializer
+        self.declared_input_shape = input_shape
+        self.up = (1, 1)  # nearest-upsampling folded into this conv's gather (set by Sequential's planner)
+        self._geoms: Dict[int, ops.ConvGeom] = {}
+
+    def _build(self, in_shape):
+        if len(in_shape) != 3:
+            raise ValueError(f"{self.name}: expected (H, W, C) input, got {in_shape}")
+        h, w, cin = in_shape
+        kh, kw = self.kernel_size
+        sh, sw = self.strides
+        cout = self.filters
+        if self.transposed:
+            ho = ops.deconv_out_size(h, kh, sh, self.padding)
+            wo = ops.deconv_out_size(w, kw, sw, self.padding)
+            self.kernel = self.add_weight("kernel", (kh, kw, cout, cin), self.kernel_initializer)
+        else:
+            g = ops.conv_geom(1, h * self.up[0], w * self.up[1], cin, kh, kw, sh, sw, self.padding, cout, self.up)
+            ho, wo = g.Ho, g.Wo
+            self.kernel = self.add_weight("kernel", (kh, kw, cin, cout), self.kernel_initializer)
+        self.bias = self.add_weight("bias", (cout,), "zeros") if self.use_bias else None
+        return (ho, wo, cout)
+
+    def geom(self, n: int) -> ops.ConvGeom:
+        g = self._geoms.get(n)
+        if g is None:
+            h, w, cin = self.input_shape_
+            kh, kw = self.kernel_size
+            sh, sw = self.strides
+            if self.transposed:
+                g = ops.deconv_geom(n, h, w, cin, kh, kw, sh, sw, self.padding, self.filters)
+            else:
+                g = ops.conv_geom(n, h * self.up[0], w * self.up[1], cin, kh, kw, sh, sw, self.padding, self.filters,
+                                  self.up)
+            self._geoms[n] = g
+        return g
+
+    def macs_per_sample(self) -> int:
+        """Multiply-accumulates of the forward pass for one sample (the GEMM view of the layer)."""
+        kh, kw = self.kernel_size
+        if self.transposed:
+            h, w, cin = self.input_shape_
+            return h * w * cin * kh * kw * self.filters
+        ho, wo, cout = self.output_shape_
+        return ho * wo * cout * kh * kw * self.input_shape_[2]
+
+    def forward(self, ctx, x):
+        n = x.shape[0]
+        g = self.geom(n)
+        y = ctx.buf(self, "y", (n,) + self.output_shape_)
+        b = self.bias.data if self.bias is not None else None
+        if self.transposed:
+            ops.conv2d_transpose_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha)
+        else:
+            ops.conv2d_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha)
+        if ctx.training:
+            ctx.saved[id(self)] = {"x": x, "y": y}
+        return y
+
+    def backward(self, ctx, dy, need_dx=True):
+        s = ctx.saved[id(self)]
+        x, y = s["x"], s["y"]
+        n = x.shape[0]
+        g = self.geom(n)
+        ho, wo, cout = self.output_shape_
+        rows = n * ho * wo
+        dz = dy  # the activation backward runs in place on the incoming gradient buffer
+        if self.act is not None or self.bias is not None:
+            ws = ctx.pool.workspace(ops.colreduce_workspace(rows, cout)) if self.bias is not None else None
+            if self.act is not None:
+                ops.act_bwd(dy, y, dz, self.bias.grad if self.bias is not None else None, True, rows, cout, self.act,
+                            self.alpha, ws)
+            else:
+                ops.bias_grad(dz, self.bias.grad, True, rows, cout, ws)
+        wsb = ops.conv2d_wgrad_workspace(g)
+        ws = ctx.pool.workspace(wsb)
+        if self.transposed:
+            ops.conv2d_transpose_wgrad(g, x, dz, self.kernel.grad, True, ws)
+        else:
+            ops.conv2d_wgrad(g, x, dz, self.kernel.grad, True, ws)
+        if not need_dx:
+            return None
+        dx = ctx.buf(self, "dx", tuple(x.shape))
+        if self.transposed:
+            ops.conv2d_transpose_dgrad(g, dz, self.kernel.data, dx)
+        else:
+            ops.conv2d_dgrad(g, dz, self.kernel.data, dx)
+        return dx
+
+
+class Conv2D(_ConvBase):
+    """layers.Conv2D (autoencoder.py:443,510,521; unet.py:40; context_encoder.py:57,72,172,185,230,242,334,346)."""
+
+
+class Conv2DTranspose(_ConvBase):
+    """layers.Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290)."""
+    transposed = True
+
+
+# --------------------------------------------------------------------------- pooling / resampling
+class MaxPooling2D(Layer):
+    """layers.MaxPooling2D with the default stride == pool size (autoencoder.py:33,98,167,319,451)."""
+
+    def __init__(self, pool_size=(2, 2), strides=None, padding="valid", name=None):
+        super().__init__(name)
+        self.pool = _pair(pool_size)
+        if strides is not None and _pair(strides) != self.pool:
+            raise NotImplementedError("MaxPooling2D: only stride == pool size (the reference's use) is built")
+        self.padding = padding.lower()
+
+    def _build(self, in_shape):
+        h, w, c = in_shape
+        ph, pw = self.pool
+        if self.padding == "same":
+            ho, self.pt, _ = ops.same_pads(h, ph, ph)
+            wo, self.pl, _ = ops.same_pads(w, pw, pw)
+        else:
+            ho, wo, self.pt, self.pl = (h - ph) // ph + 1, (w - pw) // pw + 1, 0, 0
+        if ho <= 0 or wo <= 0:
+            raise ValueError(f"{self.name}: pooling {self.pool} of a {h}x{w} map leaves nothing")
+        return (ho, wo, c)
+
+    def forward(self, ctx, x):
+        n = x.shape[0]
+        h, w, c = self.input_shape_
+        ho, wo, _ = self.output_shape_
+        y = ctx.buf(self, "y", (n, ho, wo, c))
+        idx = ctx.buf(self, "idx", (n, ho, wo, c), torch.uint8) if ctx.training else None
+        ops.maxpool2d_fwd(x, y, idx, n, h, w, c, self.pool[0], self.pool[1], self.pt, self.pl, ho, wo)
+        if ctx.training:
+            ctx.saved[id(self)] = {"idx": idx}
+        return y
+
+    def backward(self, ctx, dy, need_dx=True):
+        if not need_dx:
+            return None
+        n = dy.shape[0]
+        h, w, c = self.input_shape_
+        ho, wo, _ = self.output_shape_
+        dx = ctx.buf(self, "dx", (n, h, w, c))
+        ops.maxpool2d_bwd(dy, ctx.saved[id(self)]["idx"], dx, n, h, w, c, self.pool[0], self.pool[1], self.pt,
+                          self.pl, ho, wo)
+        return dx
+
+
+class UpSampling2D(Layer):
+    """layers.UpSampling2D, nearest (autoencoder.py:364,503)."""
+
+    def __init__(self, size=(2, 2), name=None):
+        super().__init__(name)
+        self.size = _pair(size)
+        self.folded = False  # True when the following Conv2D gathers through the repetition itself
+
+    def _build(self, in_shape):
+        h, w, c = in_shape
+        return (h * self.size[0], w * self.size[1], c)
+
+    def forward(self, ctx, x):
+        if self.folded:
+            return x
+        n = x.shape[0]
+        h, w, c = self.input_shape_
+        y = ctx.buf(self, "y", (n,) + self.output_shape_)
+        ops.upsample2d_fwd(x, y, n, h, w, c, self.size[0], self.size[1])
+        return y
+
+    def backward(self, ctx, dy, need_dx=True):
+        if self.folded or not need_dx:
+            return dy if need_dx else None
+        n = dy.shape[0]
+        h, w, c = self.input_shape_
+        dx = ctx.buf(self, "dx", (n, h, w, c))
+        ops.upsample2d_bwd(dy, dx, n, h, w, c, self.size[0], self.size[1])
+        return dx
+
+
+# --------------------------------------------------------------------------- normalisation / activations
+class BatchNormalization(Layer):
+    """layers.BatchNormalization() with Keras-2 defaults: axis -1, momentum 0.99, epsilon 1e-3
+    (autoencoder.py:318,450,468; unet.py:51; context_encoder.py:64,88,179,237,267,283,341).
+
+    ``unbiased_moving_var``: the fused kernel Keras 2 uses on 4-D inputs feeds the unbiased batch
+    variance into the moving variance; 2-D inputs use the biased one.  Only inference after training
+    sees the difference."""
+
+    def __init__(self, momentum=0.99, epsilon=1e-3, unbiased_moving_var: Optional[bool] = None, name=None):
+        super().__init__(name)
+        self.momentum = float(momentum)
+        self.epsilon = float(epsilon)
+        self._unbiased = unbiased_moving_var
+
+    def _build(self, in_shape):
+        c = in_shape[-1]
+        self.gamma = self.add_weight("gamma", (c,), "ones")
+        self.beta = self.add_weight("beta", (c,), "zeros")
+        self.moving_mean = self.add_weight("moving_mean", (c,), "zeros", trainable=False)
+        self.moving_variance = self.add_weight("moving_variance", (c,), "ones", trainable=False)
+        self.unbiased = (len(in_shape) == 3) if self._unbiased is None else bool(self._unbiased)
+        return in_shape
+
+    def forward(self, ctx, x):
+        c = self.input_shape_[-1]
+        rows = x.numel() // c
+        y = ctx.buf(self, "y", tuple(x.shape))
+        if ctx.training:
+            mean = ctx.buf(self, "mean", (c,))
+            invstd = ctx.buf(self, "invstd", (c,))
+            ws = ctx.pool.workspace(ops.colreduce_workspace(rows, c))
+            ops.batchnorm_fwd_train(x, self.gamma.data, self.beta.data, y, mean, invstd, self.moving_mean.data,
+                                    self.moving_variance.data, rows, c, self.epsilon, self.momentum, self.unbiased,
+                                    ws)
+            ctx.saved[id(self)] = {"x": x, "mean": mean, "invstd": invstd}
+        else:
+            ops.batchnorm_fwd_infer(x, self.gamma.data, self.beta.data, self.moving_mean.data,
+                                    self.moving_variance.data, y, rows, c, self.epsilon)
+        return y
+
+    def backward(self, ctx, dy, need_dx=True):
+        s = ctx.saved[id(self)]
+        x = s["x"]
+        c = self.input_shape_[-1]
+        rows = x.numel() // c
+        dx = ctx.buf(self, "dx", tuple(x.shape))
+        ws = ctx.pool.workspace(ops.colreduce_workspace(rows, c))
+        ops.batchnorm_bwd(x, dy, self.gamma.data, s["mean"], s["invstd"], dx, self.gamma.grad, self.beta.grad, True,
+                          rows, c, ws)
+        return dx
+
+
+class Activation(Layer):
+    def __init__(self, activation, name=None):
+        super().__init__(name)
+        self.act, self.alpha = _act_name(activation)
+
+    def forward(self, ctx, x):
+        if self.act is None:
+            return x
+        y = ctx.buf(self, "y", tuple(x.shape))
+        ops.act_fwd(x, y, self.act, self.alpha)
+        if ctx.training:
+            ctx.saved[id(self)] = {"y": y}
+        return y
+
+    def backward(self, ctx, dy, need_dx=True):
+        if self.act is None or not need_dx:
+            return dy if need_dx else None
+        y = ctx.saved[id(self)]["y"]
+        c = y.shape[-1]
+        ops.act_bwd(dy, y, dy, None, False, y.numel() // c, c, self.act, self.alpha, None)
+        return dy
+
+
+class LeakyReLU(Activation):
+    """layers.LeakyReLU(alpha) as a layer (unet.py:53,79) or as an ``activation=`` argument
+    (context_encoder.py:61,177,234,246,339)."""
+
+    def __init__(self, alpha=0.3, name=None):
+        Layer.__init__(self, name)
+        self.act, self.alpha = "lrelu", float(alpha)
+
+
+# --------------------------------------------------------------------------- dense / reshaping
+class Flatten(Layer):
+    def _build(self, in_shape):
+        return (int(np.prod(in_shape)),)
+
+    def forward(self, ctx, x):
+        return x.view(x.shape[0], -1)
+
+    def backward(self, ctx, dy, need_dx=True):
+        return dy.view((dy.shape[0],) + self.input_shape_) if need_dx else None
+
+
+class Reshape(Layer):
+    def __init__(self, target_shape, name=None):
+        super().__init__(name)
+        self.target_shape = tuple(int(s) for s in target_shape)
+
+    def _build(self, in_shape):
+        if int(np.prod(in_shape)) != int(np.prod(self.target_shape)):
+            raise ValueError(f"{self.name}: cannot reshape {in_shape} into {self.target_shape}")
+        return self.target_shape
+
+    def forward(self, ctx, x):
+        return x.view((x.shape[0],) + self.target_shape)
+
+    def backward(self, ctx, dy, need_dx=True):
+        return dy.view((dy.shape[0],) + self.input_shape_) if need_dx else None
+
+
+class Dense(Layer):
+    """layers.Dense (autoencoder.py:38-40,107,110,176,179,222-241,330-352,466-492): x W + b, W (in, out)."""
+
+    def __init__(self, units, activation=None, name=None):
+        super().__init__(name)
+        self.units = int(units)
+        self.act, self.alpha = _act_name(activation)
+
+    def _build(self, in_shape):
+        if len(in_shape) != 1:
+            raise ValueError(f"{self.name}: Dense is built for flattened inputs, got {in_shape}")
+        self.kernel = self.add_weight("kernel", (in_shape[0], self.units), "glorot_uniform")
+        self.bias = self.add_weight("bias", (self.units,), "zeros")
+        return (self.units,)
+
+    def macs_per_sample(self) -> int:
+        return self.input_shape_[0] * self.units
+
+    def forward(self, ctx, x):
+        m, k = x.shape
+        y = ctx.buf(self, "y", (m, self.units))
+        ops.dense_fwd(x, self.kernel.data, self.bias.data, y, m, k, self.units, self.act, self.alpha)
+        if ctx.training:
+            ctx.saved[id(self)] = {"x": x, "y": y}
+        return y
+
+    def backward(self, ctx, dy, need_dx=True):
+        s = ctx.saved[id(self)]
+        x, y = s["x"], s["y"]
+        m, k = x.shape
+        n = self.units
+        ws = ctx.pool.workspace(ops.colreduce_workspace(m, n))
+        if self.act is not None:
+            ops.act_bwd(dy, y, dy, self.bias.grad, True, m, n, self.act, self.alpha, ws)
+        else:
+            ops.bias_grad(dy, self.bias.grad, True, m, n, ws)
+        ops.dense_wgrad(x, dy, self.kernel.grad, True, m, k, n)
+        if not need_dx:
+            return None
+        dx = ctx.buf(self, "dx", (m, k))
+        ops.dense_dgrad(dy, self.kernel.data, dx, m, k, n)
+        return dx
+
+
+class Dropout(Layer):
+    """layers.Dropout (autoencoder.py:108,177,223,331): inverted dropout in training, identity otherwise.
+    The keep mask is a pure function of (seed, call counter, element index), so backward regenerates it."""
+
+    def __init__(self, rate, seed: Optional[int] = None, name=None):
+        super().__init__(name)
+        self.rate = float(rate)
+        self.seed = DEFAULT_SEED if seed is None else int(seed)
+        self.calls = 0
+
+    def forward(self, ctx, x):
+        if not ctx.training or self.rate <= 0.0:
+            return x
+        y = ctx.buf(self, "y", tuple(x.shape))
+        offset = self.calls * x.numel()
+        self.calls += 1
+        ops.dropout_fwd(x, y, self.rate, self.seed + (id(self) % 65521), offset)
+        ctx.saved[id(self)] = {"offset": offset}
+        return y
+
+    def backward(self, ctx, dy, need_dx=True):
+        if not need_dx:
+            return None
+        if self.rate <= 0.0:
+            return dy
+        dx = ctx.buf(self, "dx", tuple(dy.shape))
+        ops.dropout_bwd(dy, dx, self.rate, self.seed + (id(self) % 65521), ctx.saved[id(self)]["offset"])
+        return dx
+
+
+class ReduceSumH(Layer):
+    """layers.Lambda(lambda x: tf.reduce_sum(x, axis=1)) (autoencoder.py:36)."""
+
+    def _build(self, in_shape):
+        return (in_shape[1], in_shape[2])
+
+    def forward(self, ctx, x):
+        n = x.shape[0]
+        h, w, c = self.input_shape_
+        y = ctx.buf(self, "y", (n, w, c))
+        ops.reduce_sum_h_fwd(x, y, n, h, w, c)
+        return y
+
+    def backward(self, ctx, dy, need_dx=True):
+        if not need_dx:
+            return None
+        n = dy.shape[0]
+        h, w, c = self.input_shape_
+        dx = ctx.buf(self, "dx", (n, h, w, c))
+        ops.reduce_sum_h_bwd(dy, dx, n, h, w, c)
+        return dx
+
+
+# --------------------------------------------------------------------------- containers
+class Sequential(Layer):
+    """tf.keras.Sequential: a list of layers run in order, with ``summary()``."""
+
+    def __init__(self, layers: Optional[Sequence[Layer]] = None, name=None, fold_upsampling: bool = True):
+        super().__init__(name)
+        self.layers: List[Layer] = []
+        self.fold_upsampling = fold_upsampling
+        for l in layers or []:
+            self.add(l)
+
+    def add(self, layer: Layer):
+        if self.built:
+            raise RuntimeError("cannot add layers to a built Sequential")
+        self.layers.append(layer)
+
+    def sublayers(self):
+        return self.layers
+
+    def declared_input_shape(self) -> Optional[tuple]:
+        if self.layers and isinstance(self.layers[0], InputLayer) and self.layers[0].shape is not None:
+            return tuple(self.layers[0].shape)
+        if self.layers and getattr(self.layers[0], "declared_input_shape", None) is not None:
+            return tuple(self.layers[0].declared_input_shape)
+        return None
+
+    def _build(self, in_shape):
+        shape = in_shape
+        for i, l in enumerate(self.layers):
+            if (self.fold_upsampling and isinstance(l, UpSampling2D) and i + 1 < len(self.layers)
+                    and type(self.layers[i + 1]) is Conv2D and not self.layers[i + 1].built):
+                # UpSampling2D directly followed by a Conv2D: the conv reads through the repetition, the
+                # upsampled tensor is never written (and its backward never read).
+                l.folded = True
+                l.build(shape)
+                self.layers[i + 1].up = l.size
+                continue  # the conv sees the *stored* (small) tensor's shape
+            shape = l.build(shape)
+        return shape
+
+    def forward(self, ctx, x):
+        for l in self.layers:
+            x = l.forward(ctx, x)
+        return x
+
+    def backward(self, ctx, dy, need_dx=True):
+        first = 0
+        while first < len(self.layers) and not self.layers[first].all_variables():
+            first += 1  # layers before the first weighted one only matter if the caller wants dx
+        for i in range(len(self.layers) - 1, -1, -1):
+            want = need_dx or i > first
+            dy = self.layers[i].backward(ctx, dy, need_dx=want)
+            if dy is None:
+                return None
+        return dy
+
+    # ---- keras-style introspection
+    def summary_rows(self):
+        rows = []
+        for l in self.layers:
+            if isinstance(l, InputLayer):
+                continue
+            shp = l.output_shape_
+            if isinstance(l, UpSampling2D) and l.folded:
+                shp = l.output_shape_
+            elif isinstance(l, Conv2D) and l.up != (1, 1):
+                shp = l.output_shape_
+            rows.append((f"{l.name} ({type(l).__name__})", (None,) + tuple(shp), l.count_params()))
+        return rows
+
+    def summary(self, print_fn=print):
+        if not self.built:
+            raise ValueError("This model has not yet been built. Call build_graph() first.")
+        rows = self.summary_rows()
+        print_fn(f'Model: "{self.name}"')
+        print_fn("_" * 65)
+        print_fn(f"{'Layer (type)':<29}{'Output Shape':<26}{'Param #':<10}")
+        print_fn("=" * 65)
+        for n, s, p in rows:
+            print_fn(f"{n:<29}{str(s):<26}{p:<10}")
+        total = self.count_params()
+        trainable = sum(v.size for v in self.all_variables() if v.trainable)
+        print_fn("=" * 65)
+        print_fn(f"Total params: {total}")
+        print_fn(f"Trainable params: {trainable}")
+        print_fn(f"Non-trainable params: {total - trainable}")
+        print_fn("_" * 65)
+
+    def __call__(self, x, training: bool = False):
+        owner = getattr(self, "_owner_model", None)
+        if owner is None:
+            raise RuntimeError(f"{self.name} is not attached to a built Model")
+        return owner._run_sub(self, x, training)

@@ -1,0 +1,289 @@
+"""Tensor-level wrappers over the C ABI: shape checks on the host, raw device
+pointers and the current HIP stream into ``libspectrum_hip.so``.
+
+torch supplies device memory and streams only; every wrapper refuses tensors
+that are not contiguous float32 on a GPU, so a silent CPU path cannot exist.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT, F32, ConvGeom, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.SpectrumHipError(f"{name} is on {t.device}: the HIP path needs device tensors (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+# --------------------------------------------------------------------------- geometry (host logic, GPU-free)
+def same_pads(in_size: int, k: int, s: int) -> Tuple[int, int, int]:
+    """tf SAME: out = ceil(in/s), total = max((out-1)s + k - in, 0), before = total//2."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return out, total // 2, total - total // 2
+
+
+def conv_geom(n, h, w, cin, kh, kw, sh, sw, padding, cout, up=(1, 1)) -> ConvGeom:
+    """Geometry of a Conv2D on a logical input of (h, w) (already multiplied by ``up``)."""
+    if padding == "same":
+        ho, pt, _ = same_pads(h, kh, sh)
+        wo, pl, _ = same_pads(w, kw, sw)
+    elif padding == "valid":
+        ho, wo, pt, pl = (h - kh) // sh + 1, (w - kw) // sw + 1, 0, 0
+    else:
+        raise ValueError(f"padding {padding!r}")
+    if ho <= 0 or wo <= 0:
+        raise ValueError(f"conv output would be empty: input {h}x{w}, kernel {kh}x{kw}, padding {padding}")
+    return ConvGeom(n, h, w, cin, kh, kw, sh, sw, pt, pl, ho, wo, cout, up[0], up[1])
+
+
+def deconv_out_size(in_size: int, k: int, s: int, padding: str) -> int:
+    return in_size * s if padding == "same" else in_size * s + max(k - s, 0)
+
+
+def deconv_geom(n, h, w, cin, kh, kw, sh, sw, padding, cout) -> ConvGeom:
+    """Geometry struct for a Conv2DTranspose with input (h, w, cin) and ``cout`` filters:
+    the forward conv it is the input-gradient of maps (Hout, Wout, cout) -> (h, w, cin)."""
+    ho = deconv_out_size(h, kh, sh, padding)
+    wo = deconv_out_size(w, kw, sw, padding)
+    g = conv_geom(n, ho, wo, cout, kh, kw, sh, sw, padding, cin)
+    if (g.Ho, g.Wo) != (h, w):
+        raise ValueError("transposed-conv geometry does not round-trip")
+    return g
+
+
+# --------------------------------------------------------------------------- conv family
+def conv2d_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float):
+    check(lib.sv_conv2d_fwd(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha, F32, _stream()),
+          "sv_conv2d_fwd")
+
+
+def conv2d_dgrad(g: ConvGeom, dz, w, dx):
+    check(lib.sv_conv2d_dgrad(C.byref(g), _ptr(dz), _ptr(w), _ptr(dx), F32, _stream()), "sv_conv2d_dgrad")
+
+
+def conv2d_wgrad_workspace(g: ConvGeom) -> int:
+    return int(lib.sv_conv2d_wgrad_workspace_bytes(C.byref(g)))
+
+
+def conv2d_wgrad(g: ConvGeom, x, dz, dw, accumulate: bool, ws: torch.Tensor):
+    check(lib.sv_conv2d_wgrad(C.byref(g), _ptr(x), _ptr(dz), _ptr(dw), int(accumulate), _ptr(ws, torch.uint8),
+                              ws.numel(), F32, _stream()), "sv_conv2d_wgrad")
+
+
+def conv2d_transpose_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float):
+    check(lib.sv_conv2d_transpose_fwd(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha, F32,
+                                      _stream()), "sv_conv2d_transpose_fwd")
+
+
+def conv2d_transpose_dgrad(g: ConvGeom, dz, w, dx):
+    check(lib.sv_conv2d_transpose_dgrad(C.byref(g), _ptr(dz), _ptr(w), _ptr(dx), F32, _stream()),
+          "sv_conv2d_transpose_dgrad")
+
+
+def conv2d_transpose_wgrad(g: ConvGeom, x, dz, dw, accumulate: bool, ws: torch.Tensor):
+    check(lib.sv_conv2d_transpose_wgrad(C.byref(g), _ptr(x), _ptr(dz), _ptr(dw), int(accumulate),
+                                        _ptr(ws, torch.uint8), ws.numel(), F32, _stream()),
+          "sv_conv2d_transpose_wgrad")
+
+
+# --------------------------------------------------------------------------- elementwise / reductions
+def act_fwd(x, y, act: str, alpha: float):
+    check(lib.sv_act_fwd(_ptr(x), _ptr(y), x.numel(), ACT[act], alpha, F32, _stream()), "sv_act_fwd")
+
+
+def colreduce_workspace(rows: int, c: int) -> int:
+    return int(lib.sv_colreduce_workspace_bytes(rows, c))
+
+
+def act_bwd(dy, y, dz, db, db_accumulate: bool, rows: int, c: int, act: str, alpha: float, ws):
+    check(lib.sv_act_bwd(_ptr(dy), _ptr(y), _ptr(dz), _ptr(db), int(db_accumulate), rows, c, ACT[act], alpha,
+                         _ptr(ws, torch.uint8) if ws is not None else None, ws.numel() if ws is not None else 0,
+                         F32, _stream()), "sv_act_bwd")
+
+
+def bias_grad(dz, db, accumulate: bool, rows: int, c: int, ws):
+    check(lib.sv_bias_grad(_ptr(dz), _ptr(db), int(accumulate), rows, c, _ptr(ws, torch.uint8), ws.numel(), F32,
+                           _stream()), "sv_bias_grad")
+
+
+def maxpool2d_fwd(x, y, idx, n, h, w, c, ph, pw, pt, pl, ho, wo):
+    check(lib.sv_maxpool2d_fwd(_ptr(x), _ptr(y), _ptr(idx, torch.uint8), n, h, w, c, ph, pw, pt, pl, ho, wo, F32,
+                               _stream()), "sv_maxpool2d_fwd")
+
+
+def maxpool2d_bwd(dy, idx, dx, n, h, w, c, ph, pw, pt, pl, ho, wo):
+    check(lib.sv_maxpool2d_bwd(_ptr(dy), _ptr(idx, torch.uint8), _ptr(dx), n, h, w, c, ph, pw, pt, pl, ho, wo, F32,
+                               _stream()), "sv_maxpool2d_bwd")
+
+
+def upsample2d_fwd(x, y, n, h, w, c, uh, uw):
+    check(lib.sv_upsample2d_fwd(_ptr(x), _ptr(y), n, h, w, c, uh, uw, F32, _stream()), "sv_upsample2d_fwd")
+
+
+def upsample2d_bwd(dy, dx, n, h, w, c, uh, uw):
+    check(lib.sv_upsample2d_bwd(_ptr(dy), _ptr(dx), n, h, w, c, uh, uw, F32, _stream()), "sv_upsample2d_bwd")
+
+
+def batchnorm_fwd_train(x, gamma, beta, y, save_mean, save_invstd, moving_mean, moving_var, rows, c, eps, momentum,
+                        unbiased: bool, ws):
+    check(lib.sv_batchnorm_fwd_train(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(save_mean), _ptr(save_invstd),
+                                     _ptr(moving_mean), _ptr(moving_var), rows, c, eps, momentum, int(unbiased),
+                                     _ptr(ws, torch.uint8), ws.numel(), F32, _stream()), "sv_batchnorm_fwd_train")
+
+
+def batchnorm_fwd_infer(x, gamma, beta, moving_mean, moving_var, y, rows, c, eps):
+    check(lib.sv_batchnorm_fwd_infer(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var), _ptr(y),
+                                     rows, c, eps, F32, _stream()), "sv_batchnorm_fwd_infer")
+
+
+def batchnorm_bwd(x, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta, accumulate: bool, rows, c, ws):
+    check(lib.sv_batchnorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd), _ptr(dx),
+                               _ptr(dgamma), _ptr(dbeta), int(accumulate), rows, c, _ptr(ws, torch.uint8),
+                               ws.numel(), F32, _stream()), "sv_batchnorm_bwd")
+
+
+def concat_channels_fwd(a, b, y, rows, ca, cb):
+    check(lib.sv_concat_channels_fwd(_ptr(a), _ptr(b), _ptr(y), rows, ca, cb, F32, _stream()),
+          "sv_concat_channels_fwd")
+
+
+def concat_channels_bwd(dy, da, db, rows, ca, cb):
+    check(lib.sv_concat_channels_bwd(_ptr(dy), _ptr(da), _ptr(db), rows, ca, cb, F32, _stream()),
+          "sv_concat_channels_bwd")
+
+
+def dense_fwd(x, w, bias, y, m, k, n, act: str, alpha: float):
+    check(lib.sv_dense_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), m, k, n, ACT[act], alpha, F32, _stream()),
+          "sv_dense_fwd")
+
+
+def dense_dgrad(dz, w, dx, m, k, n):
+    check(lib.sv_dense_dgrad(_ptr(dz), _ptr(w), _ptr(dx), m, k, n, F32, _stream()), "sv_dense_dgrad")
+
+
+def dense_wgrad(x, dz, dw, accumulate: bool, m, k, n):
+    check(lib.sv_dense_wgrad(_ptr(x), _ptr(dz), _ptr(dw), int(accumulate), m, k, n, F32, _stream()),
+          "sv_dense_wgrad")
+
+
+def dropout_fwd(x, y, rate, seed, offset):
+    check(lib.sv_dropout_fwd(_ptr(x), _ptr(y), x.numel(), rate, seed, offset, F32, _stream()), "sv_dropout_fwd")
+
+
+def dropout_bwd(dy, dx, rate, seed, offset):
+    check(lib.sv_dropout_bwd(_ptr(dy), _ptr(dx), dy.numel(), rate, seed, offset, F32, _stream()), "sv_dropout_bwd")
+
+
+def reduce_sum_h_fwd(x, y, n, h, w, c):
+    check(lib.sv_reduce_sum_h_fwd(_ptr(x), _ptr(y), n, h, w, c, F32, _stream()), "sv_reduce_sum_h_fwd")
+
+
+def reduce_sum_h_bwd(dy, dx, n, h, w, c):
+    check(lib.sv_reduce_sum_h_bwd(_ptr(dy), _ptr(dx), n, h, w, c, F32, _stream()), "sv_reduce_sum_h_bwd")
+
+
+def reparam_kl_fwd(mean, logvar, eps_in, z, eps_out, kl_out, partials, seed=0, offset=0):
+    b, d = mean.shape
+    check(lib.sv_reparam_kl_fwd(_ptr(mean), _ptr(logvar), _ptr(eps_in), _ptr(z), _ptr(eps_out), _ptr(kl_out),
+                                _ptr(partials), b, d, seed, offset, _stream()), "sv_reparam_kl_fwd")
+
+
+def reparam_kl_bwd(mean, logvar, eps, dz, dmean, dlogvar, kl_weight: float):
+    b, d = mean.shape
+    check(lib.sv_reparam_kl_bwd(_ptr(mean), _ptr(logvar), _ptr(eps), _ptr(dz), _ptr(dmean), _ptr(dlogvar), kl_weight,
+                                b, d, _stream()), "sv_reparam_kl_bwd")
+
+
+# --------------------------------------------------------------------------- losses / optimiser
+def loss_workspace_floats() -> int:
+    return int(lib.sv_loss_workspace_bytes()) // 4
+
+
+def loss_mse(y_true, y_pred, loss_out, partials, dpred=None, loss_scale=1.0, weight=None, weight_stride=1,
+             weight_scale=1.0, accumulate=False):
+    c = y_pred.shape[-1]
+    n_pix = y_pred.numel() // c
+    if y_true.numel() != y_pred.numel():
+        raise ValueError(f"MSE: y_true {tuple(y_true.shape)} vs y_pred {tuple(y_pred.shape)}")
+    check(lib.sv_loss_mse(_ptr(y_true), _ptr(y_pred), _ptr(weight), weight_stride, weight_scale, _ptr(loss_out),
+                          int(accumulate), _ptr(dpred), loss_scale, n_pix, c, _ptr(partials), F32, _stream()),
+          "sv_loss_mse")
+
+
+def loss_mse_map(y_true, y_pred, out, weight=None, weight_stride=1, weight_scale=1.0):
+    c = y_pred.shape[-1]
+    check(lib.sv_loss_mse_map(_ptr(y_true), _ptr(y_pred), _ptr(weight), weight_stride, weight_scale, _ptr(out),
+                              y_pred.numel() // c, c, F32, _stream()), "sv_loss_mse_map")
+
+
+def loss_mae(y_true, y_pred, loss_out, partials, dpred=None, loss_scale=1.0, accumulate=False):
+    if y_true.numel() != y_pred.numel():
+        raise ValueError(f"MAE: y_true {tuple(y_true.shape)} vs y_pred {tuple(y_pred.shape)}")
+    check(lib.sv_loss_mae(_ptr(y_true), _ptr(y_pred), _ptr(loss_out), int(accumulate), _ptr(dpred), loss_scale,
+                          y_pred.numel(), _ptr(partials), F32, _stream()), "sv_loss_mae")
+
+
+def loss_bce(pred, label: float, from_logits: bool, loss_out, partials, dpred=None, loss_scale=1.0,
+             accumulate=False):
+    check(lib.sv_loss_bce(_ptr(pred), label, int(from_logits), _ptr(loss_out), int(accumulate), _ptr(dpred),
+                          loss_scale, pred.numel(), _ptr(partials), F32, _stream()), "sv_loss_bce")
+
+
+def adam_prepare(state, lr0, beta1, beta2, decay_steps, decay_rate, staircase):
+    check(lib.sv_adam_keras_prepare(_ptr(state, torch.int64), lr0, beta1, beta2, int(decay_steps or 0), decay_rate,
+                                    int(staircase), _stream()), "sv_adam_keras_prepare")
+
+
+def adam_apply(theta, grad, m, v, state, beta1, beta2, eps, grad_scale=1.0):
+    if not (theta.numel() == grad.numel() == m.numel() == v.numel()):
+        raise ValueError("adam: buffer sizes differ")
+    check(lib.sv_adam_keras_apply(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), _ptr(state, torch.int64),
+                                  beta1, beta2, eps, grad_scale, _stream()), "sv_adam_keras_apply")
+
+
+# --------------------------------------------------------------------------- batching helpers
+def gather_rows(src, idx, dst):
+    """dst[i] = float32(src[idx[i]]); src float32 or float64, idx int64 or None (identity)."""
+    if src.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"gather_rows: source dtype {src.dtype}")
+    n_rows = dst.shape[0]
+    row = dst.numel() // n_rows
+    if src.numel() // src.shape[0] != row:
+        raise ValueError("gather_rows: row sizes differ")
+    if idx is None and src.shape[0] < n_rows:
+        raise ValueError("gather_rows: source has fewer rows than destination")
+    check(lib.sv_gather_rows(_ptr(src, src.dtype), int(src.dtype == torch.float64), _ptr(idx, torch.int64), _ptr(dst),
+                             n_rows, row, _stream()), "sv_gather_rows")
+
+
+def mask_input(x, mask, y):
+    if not (x.numel() == mask.numel() == y.numel()):
+        raise ValueError("mask_input: sizes differ")
+    check(lib.sv_mask_input(_ptr(x), _ptr(mask), _ptr(y), x.numel(), _stream()), "sv_mask_input")
+
+
+def fill(t, value: float):
+    check(lib.sv_fill_f32(_ptr(t), value, t.numel(), _stream()), "sv_fill_f32")
+
+
+def axpy(y, x, a: float):
+    if x.numel() != y.numel():
+        raise ValueError("axpy: sizes differ")
+    check(lib.sv_axpy_f32(_ptr(y), _ptr(x), a, x.numel(), _stream()), "sv_axpy_f32")

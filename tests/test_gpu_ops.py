@@ -1,0 +1,385 @@
+"""GPU parity: every C-ABI primitive against the float64 NumPy oracle on the same seeded inputs.
+
+Tolerance: the north star's fp32 bar, relative error <= 1e-4 measured as
+max|hip - oracle| / max(1, max|oracle|) (float32 arithmetic vs a float64 oracle).
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device="cuda", dtype=dtype).contiguous()
+
+
+def close(got: torch.Tensor, want: np.ndarray, tol=RTOL, what=""):
+    g = got.detach().cpu().numpy().astype(np.float64)
+    assert g.shape == want.shape, (what, g.shape, want.shape)
+    err = np.max(np.abs(g - want)) / max(1.0, np.max(np.abs(want)))
+    assert np.isfinite(g).all(), what
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol}"
+
+
+# every (kh, kw, sh, sw, padding, H, W) variant the reference's models instantiate, plus odd sizes
+CONV_CASES = [
+    (3, 3, 1, 1, "same", 32, 32), (5, 5, 1, 1, "same", 16, 16), (1, 3, 1, 1, "valid", 8, 32),
+    (1, 5, 1, 1, "valid", 4, 32), (2, 2, 2, 2, "same", 32, 32), (4, 4, 2, 2, "same", 32, 32),
+    (4, 4, 1, 1, "valid", 4, 4), (1, 4, 1, 2, "same", 4, 32), (4, 4, 1, 1, "same", 6, 6),
+    (3, 3, 2, 2, "same", 7, 9), (3, 3, 1, 1, "valid", 5, 7),
+]
+CHANNELS = [(3, 8), (8, 3), (1, 64), (16, 32), (5, 7)]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("ch", CHANNELS)
+def test_conv2d_fwd_dgrad_wgrad(case, ch):
+    from spectrum_vae_amd import ops
+    kh, kw, sh, sw, pad, H, W = case
+    cin, cout = ch
+    rng = np.random.default_rng(zlib.crc32(repr((case, ch)).encode()))
+    n = 3
+    x = rng.standard_normal((n, H, W, cin))
+    w = rng.standard_normal((kh, kw, cin, cout)) * 0.3
+    b = rng.standard_normal(cout)
+    g = ops.conv_geom(n, H, W, cin, kh, kw, sh, sw, pad, cout)
+    for act in ("elu", None, "tanh"):
+        y = torch.empty((n, g.Ho, g.Wo, cout), device="cuda")
+        ops.conv2d_fwd(g, dev(x), dev(w), dev(b), y, act, 1.0)
+        close(y, np_ops.act_fwd(np_ops.conv2d(x, w, b, (sh, sw), pad), act), what=f"fwd {act}")
+    dz = rng.standard_normal((n, g.Ho, g.Wo, cout))
+    dx_o, dw_o, _ = np_ops.conv2d_grads(x, w, dz, (sh, sw), pad)
+    dx = torch.empty((n, H, W, cin), device="cuda")
+    ops.conv2d_dgrad(g, dev(dz), dev(w), dx)
+    close(dx, dx_o, what="dgrad")
+    ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device="cuda")
+    dw = torch.full((kh, kw, cin, cout), 7.0, device="cuda")
+    ops.conv2d_wgrad(g, dev(x), dev(dz), dw, False, ws)
+    close(dw, dw_o, what="wgrad")
+    ops.conv2d_wgrad(g, dev(x), dev(dz), dw, True, ws)
+    close(dw, 2 * dw_o, what="wgrad accumulate")
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if not (c[4] == "same" and c[2] == 1 and c[0] == 4)])
+@pytest.mark.parametrize("ch", [(3, 8), (64, 3), (1000 // 8, 16)])
+def test_conv2d_transpose(case, ch):
+    from spectrum_vae_amd import ops
+    kh, kw, sh, sw, pad, H, W = case
+    H, W = max(H // 4, 1), max(W // 4, 1)
+    cin, cout = ch
+    rng = np.random.default_rng(zlib.crc32(repr((case, ch, "T")).encode()))
+    n = 2
+    x = rng.standard_normal((n, H, W, cin))
+    w = rng.standard_normal((kh, kw, cout, cin)) * 0.3
+    b = rng.standard_normal(cout)
+    g = ops.deconv_geom(n, H, W, cin, kh, kw, sh, sw, pad, cout)
+    y = torch.empty((n, g.H, g.W, cout), device="cuda")
+    ops.conv2d_transpose_fwd(g, dev(x), dev(w), dev(b), y, "relu", 1.0)
+    y_o = np_ops.conv2d_transpose(x, w, b, (sh, sw), pad)
+    close(y, np_ops.act_fwd(y_o, "relu"), what="convT fwd")
+    dz = rng.standard_normal(y_o.shape)
+    dx_o, dw_o, _ = np_ops.conv2d_transpose_grads(x, w, dz, (sh, sw), pad)
+    dx = torch.empty((n, H, W, cin), device="cuda")
+    ops.conv2d_transpose_dgrad(g, dev(dz), dev(w), dx)
+    close(dx, dx_o, what="convT dgrad")
+    ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device="cuda")
+    dw = torch.empty((kh, kw, cout, cin), device="cuda")
+    ops.conv2d_transpose_wgrad(g, dev(x), dev(dz), dw, False, ws)
+    close(dw, dw_o, what="convT wgrad")
+
+
+@pytest.mark.parametrize("up", [(2, 2), (1, 2)])
+def test_conv2d_folded_upsampling(up):
+    """UpSampling2D folded into the conv gather == explicit upsample then conv, forward and both gradients."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(5)
+    n, h, w, cin, cout = 2, 4, 8, 16, 8
+    x = rng.standard_normal((n, h, w, cin))
+    k = rng.standard_normal((3, 3, cin, cout)) * 0.2
+    b = rng.standard_normal(cout)
+    xu = np_ops.upsample2d(x, up)
+    g = ops.conv_geom(n, h * up[0], w * up[1], cin, 3, 3, 1, 1, "same", cout, up)
+    y = torch.empty((n, g.Ho, g.Wo, cout), device="cuda")
+    ops.conv2d_fwd(g, dev(x), dev(k), dev(b), y, "elu", 1.0)
+    close(y, np_ops.act_fwd(np_ops.conv2d(xu, k, b, (1, 1), "same"), "elu"), what="fwd")
+    dz = rng.standard_normal((n, g.Ho, g.Wo, cout))
+    dxu, dw_o, _ = np_ops.conv2d_grads(xu, k, dz, (1, 1), "same")
+    dx = torch.empty((n, h, w, cin), device="cuda")
+    ops.conv2d_dgrad(g, dev(dz), dev(k), dx)
+    close(dx, np_ops.upsample2d_bwd(dxu, up), what="dgrad")
+    ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device="cuda")
+    dw = torch.empty((3, 3, cin, cout), device="cuda")
+    ops.conv2d_wgrad(g, dev(x), dev(dz), dw, False, ws)
+    close(dw, dw_o, what="wgrad")
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "lrelu", "tanh", "sigmoid"])
+@pytest.mark.parametrize("shape", [(1000, 8), (37, 3), (5, 300), (4096, 64)])
+def test_act_fwd_bwd_bias(act, shape):
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(3)
+    rows, c = shape
+    z = rng.standard_normal(shape) * 2
+    y = torch.empty(shape, device="cuda")
+    ops.act_fwd(dev(z), y, act, 0.2)
+    y_o = np_ops.act_fwd(z, act, 0.2)
+    close(y, y_o, what="act fwd")
+    dy = rng.standard_normal(shape)
+    dz_o = dy * np_ops.act_bwd_from_output(y_o, act, 0.2)
+    d = dev(dy)
+    db = torch.ones(c, device="cuda")
+    ws = torch.empty(ops.colreduce_workspace(rows, c), dtype=torch.uint8, device="cuda")
+    ops.act_bwd(d, dev(y_o), d, db, True, rows, c, act, 0.2, ws)  # in place, accumulating into ones
+    close(d, dz_o, what="act bwd")
+    close(db, 1.0 + dz_o.sum(axis=0), what="bias grad")
+    db2 = torch.empty(c, device="cuda")
+    ops.bias_grad(dev(dz_o), db2, False, rows, c, ws)
+    close(db2, dz_o.sum(axis=0), what="bias_grad")
+
+
+@pytest.mark.parametrize("cfg", [((2, 2), "same", 32, 32, 8), ((2, 2), "valid", 7, 9, 5), ((1, 2), "valid", 4, 30, 16),
+                                 ((2, 2), "same", 5, 5, 3)])
+def test_maxpool(cfg):
+    from spectrum_vae_amd import ops
+    pool, pad, H, W, C = cfg
+    rng = np.random.default_rng(11)
+    n = 3
+    x = rng.standard_normal((n, H, W, C))
+    y_o, arg_o = np_ops.maxpool2d(x, pool, pad)
+    ho, wo = y_o.shape[1:3]
+    pt = np_ops.same_pads(H, pool[0], pool[0])[1] if pad == "same" else 0
+    pl = np_ops.same_pads(W, pool[1], pool[1])[1] if pad == "same" else 0
+    y = torch.empty(y_o.shape, device="cuda")
+    idx = torch.empty(y_o.shape, dtype=torch.uint8, device="cuda")
+    ops.maxpool2d_fwd(dev(x), y, idx, n, H, W, C, pool[0], pool[1], pt, pl, ho, wo)
+    close(y, y_o, tol=0, what="maxpool fwd")
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), arg_o)
+    dy = rng.standard_normal(y_o.shape)
+    dx = torch.empty(x.shape, device="cuda")
+    ops.maxpool2d_bwd(dev(dy), idx, dx, n, H, W, C, pool[0], pool[1], pt, pl, ho, wo)
+    close(dx, np_ops.maxpool2d_bwd(dy, arg_o, x.shape, pool, pad), tol=1e-7, what="maxpool bwd")
+
+
+@pytest.mark.parametrize("size", [(2, 2), (1, 2)])
+def test_upsample(size):
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(12)
+    n, h, w, c = 2, 4, 5, 7
+    x = rng.standard_normal((n, h, w, c))
+    y = torch.empty((n, h * size[0], w * size[1], c), device="cuda")
+    ops.upsample2d_fwd(dev(x), y, n, h, w, c, size[0], size[1])
+    close(y, np_ops.upsample2d(x, size), tol=0)
+    dy = rng.standard_normal(tuple(y.shape))
+    dx = torch.empty(x.shape, device="cuda")
+    ops.upsample2d_bwd(dev(dy), dx, n, h, w, c, size[0], size[1])
+    close(dx, np_ops.upsample2d_bwd(dy, size), tol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 16, 64), (64, 100), (2, 3, 5, 7), (1024, 4, 4, 128), (3, 2, 2, 1000)])
+def test_batchnorm(shape):
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(13)
+    c = shape[-1]
+    rows = int(np.prod(shape[:-1]))
+    x = rng.standard_normal(shape) * 3 + 5  # offset mean stresses the one-pass variance
+    gamma, beta = rng.standard_normal(c), rng.standard_normal(c)
+    mm, mv = rng.standard_normal(c), rng.random(c) + 0.5
+    y_o, mean_o, var_o = np_ops.batchnorm_train(x, gamma, beta)
+    unb = len(shape) == 4
+    mm_o, mv_o = np_ops.batchnorm_moving_update(mm, mv, mean_o, var_o, rows, unbiased_var=unb)
+    ws = torch.empty(ops.colreduce_workspace(rows, c), dtype=torch.uint8, device="cuda")
+    y = torch.empty(shape, device="cuda")
+    sm, si = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    dmm, dmv = dev(mm), dev(mv)
+    ops.batchnorm_fwd_train(dev(x), dev(gamma), dev(beta), y, sm, si, dmm, dmv, rows, c, 1e-3, 0.99, unb, ws)
+    close(y, y_o, what="bn train")
+    close(sm, mean_o, what="bn mean")
+    close(si, 1 / np.sqrt(var_o + 1e-3), what="bn invstd")
+    close(dmm, mm_o, what="moving mean")
+    close(dmv, mv_o, what="moving var")
+    yi = torch.empty(shape, device="cuda")
+    ops.batchnorm_fwd_infer(dev(x), dev(gamma), dev(beta), dev(mm), dev(mv), yi, rows, c, 1e-3)
+    close(yi, np_ops.batchnorm_infer(x, gamma, beta, mm, mv), what="bn infer")
+    dy = rng.standard_normal(shape)
+    dx_o, dg_o, db_o = np_ops.batchnorm_train_bwd(x, gamma, dy)
+    dx = torch.empty(shape, device="cuda")
+    dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    ops.batchnorm_bwd(dev(x), dev(dy), dev(gamma), sm, si, dx, dg, db, True, rows, c, ws)
+    close(dx, dx_o, what="bn dx")
+    close(dg, dg_o, tol=2e-4, what="bn dgamma")
+    close(db, db_o, what="bn dbeta")
+
+
+def test_concat_and_misc():
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(14)
+    a, b = rng.standard_normal((2, 4, 4, 64)), rng.standard_normal((2, 4, 4, 3))
+    y = torch.empty((2, 4, 4, 67), device="cuda")
+    ops.concat_channels_fwd(dev(a), dev(b), y, 32, 64, 3)
+    close(y, np.concatenate([a, b], axis=-1), tol=0)
+    da, db = torch.empty(a.shape, device="cuda"), torch.empty(b.shape, device="cuda")
+    ops.concat_channels_bwd(y, da, db, 32, 64, 3)
+    close(da, a.astype(np.float32).astype(np.float64), tol=0)
+    close(db, b.astype(np.float32).astype(np.float64), tol=0)
+    # gather with cast from float64 and an index vector
+    src = rng.standard_normal((10, 6))
+    idx = torch.tensor([9, 0, 3], device="cuda")
+    dst = torch.empty((3, 6), device="cuda")
+    ops.gather_rows(dev(src, torch.float64), idx, dst)
+    close(dst, src[[9, 0, 3]].astype(np.float32).astype(np.float64), tol=0)
+    m = (rng.random((3, 6)) > 0.5).astype(np.float64)
+    out = torch.empty((3, 6), device="cuda")
+    ops.mask_input(dst, dev(m), out)
+    close(out, dst.cpu().numpy().astype(np.float64) * (1 - m), tol=0)
+    # reduce_sum over H
+    x = rng.standard_normal((2, 5, 3, 4))
+    r = torch.empty((2, 3, 4), device="cuda")
+    ops.reduce_sum_h_fwd(dev(x), r, 2, 5, 3, 4)
+    close(r, x.sum(axis=1), tol=1e-6)
+    dx = torch.empty(x.shape, device="cuda")
+    ops.reduce_sum_h_bwd(r, dx, 2, 5, 3, 4)
+    close(dx, np.repeat(r.cpu().numpy().astype(np.float64)[:, None], 5, axis=1), tol=0)
+
+
+@pytest.mark.parametrize("mkn", [(32, 2048, 1000), (7, 33, 5), (64, 512, 64), (130, 70, 129)])
+def test_dense(mkn):
+    from spectrum_vae_amd import ops
+    m, k, n = mkn
+    rng = np.random.default_rng(15)
+    x, w, b = rng.standard_normal((m, k)), rng.standard_normal((k, n)) / np.sqrt(k), rng.standard_normal(n)
+    y = torch.empty((m, n), device="cuda")
+    ops.dense_fwd(dev(x), dev(w), dev(b), y, m, k, n, "elu", 1.0)
+    close(y, np_ops.act_fwd(np_ops.dense(x, w, b), "elu"), what="dense fwd")
+    dz = rng.standard_normal((m, n))
+    dx_o, dw_o, _ = np_ops.dense_grads(x, w, dz)
+    dx = torch.empty((m, k), device="cuda")
+    ops.dense_dgrad(dev(dz), dev(w), dx, m, k, n)
+    close(dx, dx_o, what="dense dgrad")
+    dw = torch.zeros((k, n), device="cuda")
+    ops.dense_wgrad(dev(x), dev(dz), dw, True, m, k, n)
+    close(dw, dw_o, what="dense wgrad")
+
+
+def test_losses():
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(16)
+    shape = (5, 8, 8, 3)
+    t, p = rng.standard_normal(shape), rng.standard_normal(shape)
+    part = torch.empty(ops.loss_workspace_floats(), device="cuda")
+    out = torch.empty(1, device="cuda")
+    dp = torch.empty(shape, device="cuda")
+    ops.loss_mse(dev(t), dev(p), out, part, dp)
+    close(out, np.array([np_ops.mse(t, p)]), what="mse")
+    close(dp, np_ops.mse_grad(t, p), tol=1e-6, what="mse grad")
+    # masked, x10, weight read with a stride from channel 0 of an NHWC mask (run_context_encoder.py:198)
+    mask = np.zeros(shape)
+    mask[:, 1:5, 2:6, :] = 1
+    ops.loss_mse(dev(t), dev(p), out, part, dp, 1.0, dev(mask), 3, 10.0)
+    close(out, np.array([np_ops.mse_weighted(t, p, mask[..., 0] * 10)]), what="masked mse")
+    close(dp, np_ops.mse_weighted_grad(t, p, mask[..., 0] * 10), tol=1e-6, what="masked mse grad")
+    # all-ones mask == 10 * MSE
+    ops.loss_mse(dev(t), dev(p), out, part, None, 1.0, dev(np.ones(shape)), 3, 10.0)
+    close(out, np.array([10 * np_ops.mse(t, p)]), what="ones mask")
+    mp = torch.empty(shape[:-1], device="cuda")
+    ops.loss_mse_map(dev(t), dev(p), mp, dev(mask), 3, 10.0)
+    close(mp, np_ops.mse_per_pixel(t, p, mask[..., 0] * 10), what="mse map")
+    ops.loss_mae(dev(t), dev(p), out, part, dp, 100.0)
+    close(out, np.array([np_ops.mae(t, p)]), what="mae")
+    close(dp, 100 * np_ops.mae_grad(t, p), tol=1e-6, what="mae grad")
+    z = rng.standard_normal((64, 1)) * 3
+    pr = 1 / (1 + np.exp(-z))
+    pr[0], pr[1] = 0.0, 1.0  # saturated predictions hit the clip
+    d1 = torch.empty((64, 1), device="cuda")
+    for label in (0.0, 1.0):
+        ops.loss_bce(dev(pr), label, False, out, part, d1)
+        close(out, np.array([np_ops.bce_probs(np.full_like(pr, label), pr)]), what="bce probs")
+        close(d1, np_ops.bce_probs_grad(np.full_like(pr, label), pr), tol=1e-3, what="bce probs grad")
+        ops.loss_bce(dev(z), label, True, out, part, d1)
+        close(out, np.array([np_ops.bce_logits(np.full_like(z, label), z)]), what="bce logits")
+        close(d1, np_ops.bce_logits_grad(np.full_like(z, label), z), tol=1e-6, what="bce logits grad")
+    # accumulate
+    ops.loss_mse(dev(t), dev(p), out, part)
+    ops.loss_mse(dev(t), dev(p), out, part, accumulate=True)
+    close(out, np.array([2 * np_ops.mse(t, p)]), what="accumulate")
+
+
+def test_adam_keras_and_schedule():
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(17)
+    n = 1003
+    theta = rng.standard_normal(n)
+    th = dev(theta)
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    state = torch.zeros(2, dtype=torch.int64, device="cuda")
+    th_o, m_o, v_o = theta.copy(), np.zeros(n), np.zeros(n)
+    for it in range(25):
+        g = rng.standard_normal(n)
+        ops.adam_prepare(state, 5e-4, 0.9, 0.999, 10, 0.96, True)
+        ops.adam_apply(th, dev(g), m, v, state, 0.9, 0.999, 1e-7, 1.0)
+        lr = np_ops.exponential_decay(5e-4, it, 10, 0.96, True)
+        th_o, m_o, v_o = np_ops.adam_keras_step(th_o, g.astype(np.float32).astype(np.float64), m_o, v_o, it, lr)
+    assert int(state[0].item()) == 25
+    close(th, th_o, tol=1e-6, what="adam theta")
+    close(m, m_o, tol=1e-6, what="adam m")
+    # closed form of the first step: delta = -lr * g / (|g| + eps / sqrt(1 - b2))
+    th1 = torch.zeros(8, device="cuda")
+    g1 = np.array([1.0, -2.0, 0.5, 1e-3, -1e-3, 3.0, -0.1, 10.0])
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    ops.adam_prepare(st, 1e-3, 0.9, 0.999, 0, 1.0, False)
+    ops.adam_apply(th1, dev(g1), torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda"), st, 0.9, 0.999, 1e-7)
+    close(th1, -1e-3 * g1 / (np.abs(g1) + 1e-7 / np.sqrt(1 - 0.999)), tol=1e-7, what="adam closed form")
+
+
+def test_reparam_kl():
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(18)
+    b, d = 64, 8
+    mu, lv, eps = rng.standard_normal((b, d)), rng.standard_normal((b, d)) * 0.5, rng.standard_normal((b, d))
+    z, kl = torch.empty((b, d), device="cuda"), torch.empty(1, device="cuda")
+    part = torch.empty(ops.loss_workspace_floats(), device="cuda")
+    ops.reparam_kl_fwd(dev(mu), dev(lv), dev(eps), z, None, kl, part)
+    close(z, np_ops.sampling(mu, lv, eps), what="sampling")
+    close(kl, np.array([np_ops.kl_standard_normal(mu, lv)]), what="kl")
+    dz = rng.standard_normal((b, d))
+    dmu, dlv = torch.empty((b, d), device="cuda"), torch.empty((b, d), device="cuda")
+    ops.reparam_kl_bwd(dev(mu), dev(lv), dev(eps), dev(dz), dmu, dlv, 1.0)
+    close(dmu, dz + mu / b, what="dmu")
+    close(dlv, dz * 0.5 * np.exp(0.5 * lv) * eps + 0.5 * (np.exp(lv) - 1) / b, what="dlogvar")
+    # generated epsilon: standard normal, replayable from (seed, offset)
+    big = torch.zeros((4096, 64), device="cuda")
+    e1, e2 = torch.empty_like(big), torch.empty_like(big)
+    ops.reparam_kl_fwd(big, big, None, torch.empty_like(big), e1, kl, part, 1833, 0)
+    ops.reparam_kl_fwd(big, big, None, torch.empty_like(big), e2, kl, part, 1833, 0)
+    assert torch.equal(e1, e2)
+    assert abs(float(e1.mean())) < 0.01 and abs(float(e1.std()) - 1.0) < 0.01
+
+
+def test_dropout():
+    from spectrum_vae_amd import ops
+    x = torch.ones(1 << 18, device="cuda")
+    y = torch.empty_like(x)
+    ops.dropout_fwd(x, y, 0.25, 7, 0)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.01
+    assert torch.allclose(y[y != 0], torch.tensor(1 / 0.75, device="cuda"))
+    dx = torch.empty_like(x)
+    ops.dropout_bwd(x, dx, 0.25, 7, 0)
+    assert torch.equal(dx, y)
+
+
+def test_errors_are_loud():
+    from spectrum_vae_amd import _lib, ops
+    with pytest.raises(_lib.SpectrumHipError):
+        ops.act_fwd(torch.zeros(4), torch.zeros(4), "relu", 0.0)  # CPU tensors: refused, no fallback
+    g = ops.conv_geom(1, 8, 8, 3, 3, 3, 1, 1, "same", 4)
+    x = torch.zeros((1, 8, 8, 3), device="cuda")
+    with pytest.raises(_lib.SpectrumHipError, match="workspace"):
+        ops.conv2d_wgrad(g, x, torch.zeros((1, 8, 8, 4), device="cuda"), torch.zeros((3, 3, 3, 4), device="cuda"),
+                         False, torch.empty(8, dtype=torch.uint8, device="cuda"))
