@@ -398,12 +398,17 @@ def mae_grad(y_true, y_pred):
 KERAS_EPS = 1e-7
 
 
-def bce_probs(y_true, p):
+def bce_probs(y_true, p, dtype=F64):
     """BinaryCrossentropy(from_logits=False): clip p to [eps, 1-eps], eps = 1e-7;
-    -mean(t*log(p+eps) + (1-t)*log(1-p+eps)) (keras backend adds eps inside the logs)."""
-    t = np.asarray(y_true, F64)
-    p = np.clip(np.asarray(p, F64), KERAS_EPS, 1.0 - KERAS_EPS)
-    return float(np.mean(-(t * np.log(p + KERAS_EPS) + (1 - t) * np.log(1 - p + KERAS_EPS))))
+    -mean(t*log(p+eps) + (1-t)*log(1-p+eps)) (keras backend adds eps inside the logs).
+    ``dtype=np.float32`` evaluates the clip and the logs in float32 as TensorFlow does: for saturated
+    predictions 1-p+eps is a handful of float32 ulps, so the two precisions differ visibly there."""
+    t = np.asarray(y_true, dtype)
+    eps = dtype(KERAS_EPS)
+    one = dtype(1.0)
+    p = np.clip(np.asarray(p, dtype), eps, one - eps)
+    per = -(t * np.log(p + eps) + (one - t) * np.log(one - p + eps))
+    return float(np.mean(per.astype(F64)))
 
 
 def bce_probs_grad(y_true, p):

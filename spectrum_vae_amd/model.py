@@ -279,46 +279,64 @@ class Model(Layer):
             "acc": p.get(("fit", "acc"), (1,)),
         }
 
-    def _train_step_body(self, b: dict, same_xy: bool, weight: float):
-        """fwd -> loss (+dL/dpred) -> bwd -> [all-reduce] -> Adam, all enqueued on the current stream."""
+    def _fwd_bwd(self, b: dict, same_xy: bool, weight: float):
+        """zero grads -> forward -> loss (+dL/dpred) -> backward, all enqueued on the current stream."""
         self.zero_grad_raw()
         pred = self.forward_raw(b["x"], True)
         yt = b["x"] if same_xy else b["y"]
         self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0)
         ops.axpy(b["acc"], b["loss"], weight)
         self.backward_raw(b["dpred"], -1, need_dx=False)
+        self._calls.clear()
+
+    def _train_step_body(self, b: dict, same_xy: bool, weight: float):
+        self._fwd_bwd(b, same_xy, weight)
         scale = 1.0
         if self._reducer is not None:
             scale = self._reducer.all_reduce(self._grads)
         self.optimizer.apply_model(self, scale)
-        self._calls.clear()
 
     def zero_grad_raw(self):
         ops.fill(self._grads, 0.0)
         self._calls.clear()
 
     def train_on_device_batch(self, b: dict, same_xy: bool, weight: float):
-        """One optimizer step on the batch already sitting in ``b['x']`` / ``b['y']``; replays a captured
-        HIP graph after the first (eager, buffer-allocating) step at this batch size."""
+        """One optimizer step on the batch already sitting in ``b['x']`` / ``b['y']``.  The first step at a
+        batch size runs eagerly (it allocates every buffer), the second is captured into HIP graphs, later
+        ones replay them.  With a data-parallel reducer the step is two graphs (forward/backward, optimizer)
+        with the gradient all-reduce issued between them on the same stream."""
         bs = b["x"].shape[0]
-        key = (bs, same_xy, float(weight), id(self.optimizer), id(self.loss))
-        capturable = self.use_graphs and self._reducer is None and self.graph_safe()
-        if not capturable:
+        key = (bs, same_xy, float(weight), id(self.optimizer), id(self.loss), id(self._reducer))
+        if not (self.use_graphs and self.graph_safe()):
             self._train_step_body(b, same_xy, weight)
             return
         g = self._graphs.get(key)
         if g is None:
-            self._train_step_body(b, same_xy, weight)  # eager: allocates every buffer this batch size needs
+            self._train_step_body(b, same_xy, weight)
             self._graphs[key] = "warm"
             return
         if g == "warm":
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._train_step_body(b, same_xy, weight)
-            self._graphs[key] = graph
-            g = graph
-        g.replay()
+            if self._reducer is None:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._train_step_body(b, same_xy, weight)
+                g = (graph,)
+            else:
+                scale = 1.0 / self._reducer.world
+                g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb):
+                    self._fwd_bwd(b, same_xy, weight)
+                with torch.cuda.graph(g_opt):
+                    self.optimizer.apply_model(self, scale)
+                g = (g_fb, g_opt)
+            self._graphs[key] = g
+        if len(g) == 1:
+            g[0].replay()
+        else:
+            g[0].replay()
+            self._reducer.all_reduce(self._grads)
+            g[1].replay()
 
     def graph_safe(self) -> bool:
         """A step can be frozen into a HIP graph when no layer needs fresh host-side arguments per call."""

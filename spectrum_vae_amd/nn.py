@@ -144,6 +144,9 @@ class CallCtx:
         self.slot = slot
         self.training = training
         self.saved: Dict[int, dict] = {}
+        # False: backward only propagates to the inputs (a generator's gradient THROUGH a discriminator);
+        # weight/bias gradients are skipped, BatchNorm's go to scratch.
+        self.param_grads = True
 
     def buf(self, layer, role, shape, dtype=torch.float32):
         return self.pool.get((id(layer), role, self.slot), shape, dtype)
@@ -311,19 +314,19 @@ class _ConvBase(Layer):
         ho, wo, cout = self.output_shape_
         rows = n * ho * wo
         dz = dy  # the activation backward runs in place on the incoming gradient buffer
-        if self.act is not None or self.bias is not None:
-            ws = ctx.pool.workspace(ops.colreduce_workspace(rows, cout)) if self.bias is not None else None
+        want_db = self.bias is not None and ctx.param_grads
+        if self.act is not None or want_db:
+            ws = ctx.pool.workspace(ops.colreduce_workspace(rows, cout)) if want_db else None
             if self.act is not None:
-                ops.act_bwd(dy, y, dz, self.bias.grad if self.bias is not None else None, True, rows, cout, self.act,
-                            self.alpha, ws)
+                ops.act_bwd(dy, y, dz, self.bias.grad if want_db else None, True, rows, cout, self.act, self.alpha, ws)
             else:
                 ops.bias_grad(dz, self.bias.grad, True, rows, cout, ws)
-        wsb = ops.conv2d_wgrad_workspace(g)
-        ws = ctx.pool.workspace(wsb)
-        if self.transposed:
-            ops.conv2d_transpose_wgrad(g, x, dz, self.kernel.grad, True, ws)
-        else:
-            ops.conv2d_wgrad(g, x, dz, self.kernel.grad, True, ws)
+        if ctx.param_grads:
+            ws = ctx.pool.workspace(ops.conv2d_wgrad_workspace(g))
+            if self.transposed:
+                ops.conv2d_transpose_wgrad(g, x, dz, self.kernel.grad, True, ws)
+            else:
+                ops.conv2d_wgrad(g, x, dz, self.kernel.grad, True, ws)
         if not need_dx:
             return None
         dx = ctx.buf(self, "dx", tuple(x.shape))
@@ -468,8 +471,11 @@ class BatchNormalization(Layer):
         rows = x.numel() // c
         dx = ctx.buf(self, "dx", tuple(x.shape))
         ws = ctx.pool.workspace(ops.colreduce_workspace(rows, c))
-        ops.batchnorm_bwd(x, dy, self.gamma.data, s["mean"], s["invstd"], dx, self.gamma.grad, self.beta.grad, True,
-                          rows, c, ws)
+        if ctx.param_grads:
+            dg, db, acc = self.gamma.grad, self.beta.grad, True
+        else:
+            dg, db, acc = ctx.buf(self, "dg_scratch", (c,)), ctx.buf(self, "db_scratch", (c,)), False
+        ops.batchnorm_bwd(x, dy, self.gamma.data, s["mean"], s["invstd"], dx, dg, db, acc, rows, c, ws)
         return dx
 
 
@@ -566,11 +572,13 @@ class Dense(Layer):
         m, k = x.shape
         n = self.units
         ws = ctx.pool.workspace(ops.colreduce_workspace(m, n))
+        pg = ctx.param_grads
         if self.act is not None:
-            ops.act_bwd(dy, y, dy, self.bias.grad, True, m, n, self.act, self.alpha, ws)
-        else:
+            ops.act_bwd(dy, y, dy, self.bias.grad if pg else None, True, m, n, self.act, self.alpha, ws)
+        elif pg:
             ops.bias_grad(dy, self.bias.grad, True, m, n, ws)
-        ops.dense_wgrad(x, dy, self.kernel.grad, True, m, k, n)
+        if pg:
+            ops.dense_wgrad(x, dy, self.kernel.grad, True, m, k, n)
         if not need_dx:
             return None
         dx = ctx.buf(self, "dx", (m, k))

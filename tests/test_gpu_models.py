@@ -1,0 +1,379 @@
+"""GPU parity at model level: the HIP engine against the torch-CPU restatement with IDENTICAL weights.
+
+Bars (the north star's): activations and gradients at relative error <= 1e-4 (fp32), loss trajectory
+within 1e-3 over 100 fixed-seed optimizer steps.  Relative error of a tensor is
+max|hip - ref| / max(max|ref|, floor) with a small floor so all-zero gradients do not divide by zero.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as omodels
+from oracle import torch_ref
+from oracle.torch_ref import KerasAdam, RefSequential
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, want, floor=1e-3):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.isfinite(got).all()
+    return float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), floor))
+
+
+def data(n, seed=1833, c=3):
+    from spectrum_vae_amd.data import synth_training_tensor
+    return synth_training_tensor(n, seed)[..., :c]
+
+
+def load_into_ref(ref, model):
+    ref.load_params([v.numpy() for v in model.trainable_variables])
+
+
+def grads_of(model):
+    return [v.grad.detach().cpu().numpy().copy() for v in model.trainable_variables]
+
+
+def check_fwd_bwd(model, ref, x, tol=1e-4, target=None):
+    """Forward output, training-mode loss gradient for every weight, inference output."""
+    from spectrum_vae_amd import losses
+    from spectrum_vae_amd.losses import to_device_f32
+    xd = to_device_f32(x)
+    model.build((None,) + tuple(x.shape[1:]))
+    model._materialize()
+    load_into_ref(ref, model)
+    tgt = np.asarray(x if target is None else target, np.float32)
+    # training forward + MSE backward
+    model.zero_grad()
+    pred = model.forward_raw(xd, True)
+    out = torch.empty(1, device="cuda")
+    dpred = torch.empty_like(pred)
+    losses.MeanSquaredError().value_and_grad(to_device_f32(tgt), pred, out, dpred)
+    pred_host = pred.cpu().numpy()
+    model.backward_raw(dpred, -1, need_dx=False)
+    xt = torch.from_numpy(np.asarray(x, np.float32))
+    for p in ref.params:
+        p.grad = None
+    pr = ref(xt, training=True)
+    loss = torch_ref.mse(torch.from_numpy(tgt), pr)
+    loss.backward()
+    assert rel(pred_host, pr.detach().numpy()) <= tol, "training forward"
+    assert abs(float(out) - float(loss)) <= tol * max(1.0, abs(float(loss))), "loss"
+    for v, g, p in zip(model.trainable_variables, grads_of(model), ref.params):
+        e = rel(g, p.grad.numpy(), floor=1e-6 + 1e-3 * float(p.grad.abs().max()))
+        assert e <= tol, f"grad of {v.name}: {e:.2e}"
+    # BatchNorm moving statistics after the training call
+    for v, s in zip(model.non_trainable_variables, ref.state):
+        assert rel(v.numpy(), s.numpy()) <= tol, f"state {v.name}"
+    # inference forward
+    y_inf = model.predict(x, batch_size=max(1, x.shape[0] // 2 + 1))
+    assert rel(y_inf, ref(xt, training=False).detach().numpy()) <= tol, "inference forward"
+    model._calls.clear()
+
+
+RUN_MODEL_DEFAULTS = dict(conv_layers=3, conv_layer_multiplier=2, initial_filters=8, activation="elu", kernel_size=3,
+                          conv_operations=1, fc_layers=0, fc_layer_size=256, dropout=0.2, latent_dimensions=0,
+                          batch_norm=False)
+
+
+@pytest.mark.parametrize("cfg", [
+    RUN_MODEL_DEFAULTS,
+    dict(RUN_MODEL_DEFAULTS, batch_norm=True, activation="relu", conv_operations=2, kernel_size=5),
+    dict(RUN_MODEL_DEFAULTS, conv_layers=4, conv_layer_multiplier=1, initial_filters=16, conv_operations=3),
+    dict(RUN_MODEL_DEFAULTS, latent_dimensions=8, fc_layers=2, fc_layer_size=64, batch_norm=True),
+    dict(),  # constructor defaults
+])
+def test_caepadded_matches_oracle(cfg):
+    from spectrum_vae_amd import autoencoder
+    x = data(6)
+    model = autoencoder.CAEPadded(**cfg)
+    enc, dec = omodels.caepadded(**cfg)
+    ref = RefSequential(enc + dec, (32, 32, 3))
+    model.build((None, 32, 32, 3))
+    assert model.count_params() - sum(v.size for v in model.non_trainable_variables) == ref.num_params()
+    check_fwd_bwd(model, ref, x)
+
+
+def test_caepadded_per_layer_activations():
+    """Every conv output of the default model, layer by layer."""
+    from spectrum_vae_amd import autoencoder
+    from spectrum_vae_amd.losses import to_device_f32
+    from spectrum_vae_amd.nn import Conv2D
+    x = data(4)
+    model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+    model.build((None, 32, 32, 3))
+    model._materialize()
+    enc, dec = omodels.caepadded(**RUN_MODEL_DEFAULTS)
+    ref = RefSequential(enc + dec, (32, 32, 3))
+    load_into_ref(ref, model)
+    model.forward_raw(to_device_f32(x), True)
+    ctx = model._calls[-1]
+    taps = {}
+    ref(torch.from_numpy(x), training=True, taps=taps)
+    ref_convs = [taps[i].detach().numpy() for i, l in enumerate(ref.layers) if l["type"] == "conv2d"]
+    hip_convs = [ctx.saved[id(l)]["y"].cpu().numpy() for l in model.encoder.layers + model.decoder.layers
+                 if isinstance(l, Conv2D)]
+    assert len(ref_convs) == len(hip_convs) == 6
+    for i, (a, b) in enumerate(zip(hip_convs, ref_convs)):
+        assert rel(a, b) <= 1e-4, f"conv {i}"
+    model._calls.clear()
+
+
+def test_cae1d_and_classifiers():
+    from spectrum_vae_amd import autoencoder
+    x = data(4)
+    m = autoencoder.CAE1D(conv_layers=2, conv_operations=1, latent_dimensions=0)
+    enc, dec = omodels.cae1d(conv_layers=2, conv_operations=1, latent_dimensions=0)
+    ref = RefSequential(enc + dec, (32, 32, 3))
+    m.build((None, 32, 32, 3))
+    tgt = np.random.default_rng(0).standard_normal((4,) + m.output_shape_).astype(np.float32)
+    check_fwd_bwd(m, ref, x, target=tgt)
+    for cls, layers in ((autoencoder.CNNRiley, omodels.cnnriley()),
+                        (autoencoder.CNNPadded, omodels.cnnpadded(dropout=0.0)),
+                        (autoencoder.CNN1D, omodels.cnn1d(conv_layers=2, dropout=0.0))):
+        kw = {} if cls is autoencoder.CNNRiley else {"dropout": 0.0}
+        if cls is autoencoder.CNN1D:
+            kw["conv_layers"] = 2
+        m = cls(**kw)
+        ref = RefSequential(layers, (32, 32, 3))
+        tgt = np.random.default_rng(1).standard_normal((4, 1)).astype(np.float32)
+        check_fwd_bwd(m, ref, x, target=tgt)
+    a = autoencoder.AE(dropout=0.0)
+    enc, dec = omodels.ae(dropout=0.0)
+    check_fwd_bwd(a, RefSequential(enc + dec, (32, 3)), data(4)[:, 0])
+
+
+def test_unet_matches_oracle():
+    from spectrum_vae_amd import unet
+    x = data(4, c=1)
+    y = data(4)
+    model = unet.ContextEncoder()
+    ref = omodels.RefUNet()
+    model.build((None, 32, 32, 1))
+    assert sum(v.size for v in model.trainable_variables) == ref.num_params() == 133_379
+    check_fwd_bwd(model, ref, x, target=y)
+
+
+def test_context_encoder_and_discriminator_match_oracle():
+    from spectrum_vae_amd import context_encoder
+    x = data(4)
+    ce = context_encoder.ContextEncoder()
+    enc, dec = omodels.context_encoder()
+    ref = RefSequential(enc + dec, (32, 32, 3))
+    ce.build((None, 32, 32, 3))
+    assert sum(v.size for v in ce.trainable_variables) == ref.num_params() == 4_497_899
+    check_fwd_bwd(ce, ref, x)
+    d = context_encoder.Discriminator()
+    rd = RefSequential(omodels.discriminator(), (32, 32, 3))
+    d.build((None, 32, 32, 3))
+    assert sum(v.size for v in d.trainable_variables) == rd.num_params() == 202_497
+    check_fwd_bwd(d, rd, x, target=np.full((4, 1), 0.3, np.float32))
+    oh = context_encoder.ContextEncoderOneHot()
+    enc, dec = omodels.context_encoder_onehot()
+    xo = np.random.default_rng(3).standard_normal((4, 4, 32, 3)).astype(np.float32)
+    ro = RefSequential(enc + dec, (4, 32, 3))
+    oh.build((None, 4, 32, 3))
+    tgt = np.random.default_rng(4).standard_normal((4,) + oh.output_shape_).astype(np.float32)
+    check_fwd_bwd(oh, ro, xo, target=tgt)
+    do = context_encoder.DiscriminatorOneHot()
+    check_fwd_bwd(do, RefSequential(omodels.discriminator_onehot(), (4, 16, 3)), xo[:, :, :16],
+                  target=np.full((4, 1), 0.7, np.float32))
+
+
+def test_trajectory_100_steps_run_model_config():
+    """100 optimizer steps of the run_model.py configuration (MSE, Adam lr 5e-4, decay .96/10 steps, batch 32,
+    fixed batch order): loss trajectory within 1e-3 of the CPU restatement.  Steps 3..100 replay a HIP graph."""
+    from spectrum_vae_amd import autoencoder, losses, ops
+    from spectrum_vae_amd.run_model import build_optimizer
+    X = data(32 * 10)
+    model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+    model.build((None, 32, 32, 3))
+    model._materialize()
+    enc, dec = omodels.caepadded(**RUN_MODEL_DEFAULTS)
+    ref = RefSequential(enc + dec, (32, 32, 3))
+    load_into_ref(ref, model)
+    opt_ref = KerasAdam(ref.params, 5e-4, decay_steps=10, decay_rate=0.96, staircase=True)
+    model.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
+    Xd = torch.from_numpy(X).cuda()
+    b = model._step_buffers(32, (32, 32, 3))
+    hip, cpu = [], []
+    for step in range(100):
+        sl = slice((step % 10) * 32, (step % 10 + 1) * 32)
+        ops.gather_rows(Xd[sl], None, b["x"])
+        model.train_on_device_batch(b, True, 32.0)
+        hip.append(float(b["loss"].item()))
+        xb = torch.from_numpy(X[sl])
+        cpu.append(torch_ref.train_step_mse(ref, opt_ref, xb, xb))
+    hip, cpu = np.array(hip), np.array(cpu)
+    assert len(model._graphs) == 1 and not isinstance(next(iter(model._graphs.values())), str), "graph not captured"
+    assert np.max(np.abs(hip - cpu) / np.maximum(np.abs(cpu), 1e-6)) <= 1e-3, (hip[-5:], cpu[-5:])
+    assert cpu[-1] < cpu[0]
+    assert model.optimizer.iterations == 100
+    for v, p in zip(model.trainable_variables, ref.params):
+        assert rel(v.numpy(), p.detach().numpy()) <= 1e-3, v.name
+
+
+def test_fit_predict_history_and_early_stopping():
+    from spectrum_vae_amd import EarlyStopping, losses
+    from spectrum_vae_amd.run_model import build_optimizer, default_model, pad_height
+    X = pad_height(data(200), 3)  # float64, as the reference's np.concatenate with np.zeros produces
+    assert X.dtype == np.float64
+    Xtr, Xte = X[:150], X[150:]
+    model = default_model(X.shape[1:], verbose=False)
+    model.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
+    h = model.fit(Xtr, Xtr, epochs=4, shuffle=True, validation_data=(Xte, Xte),
+                  callbacks=[EarlyStopping(monitor="loss", patience=3)], batch_size=32, verbose=0)
+    assert len(h.history["loss"]) == 4 and len(h.history["val_loss"]) == 4
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    # 150 samples = 4 full batches + a partial one of 22 per epoch: 5 updates per epoch
+    assert model.optimizer.iterations == 20
+    pred = model.predict(Xte)
+    assert pred.shape == Xte.shape and pred.dtype == np.float32
+    # val_loss of the last epoch equals the MSE of predict() on the validation set
+    assert abs(np.mean((pred - Xte) ** 2) - h.history["val_loss"][-1]) <= 1e-5
+    # encoder / decoder sub-models are callable on their own and compose to the model
+    z = model.encoder(Xte[:8])
+    assert tuple(z.shape) == (8, 4, 4, 32)
+    assert rel(model.decoder(z).numpy(), pred[:8]) <= 1e-6
+    # early stopping on a loss that cannot improve
+    model2 = default_model(X.shape[1:], verbose=False)
+    from spectrum_vae_amd.optimizers import Adam
+    model2.compile(optimizer=Adam(0.0), loss=losses.MeanSquaredError())
+    h2 = model2.fit(Xtr, Xtr, epochs=10, shuffle=False, callbacks=[EarlyStopping(monitor="loss", patience=3)],
+                    batch_size=50, verbose=0)
+    assert len(h2.history["loss"]) == 4  # epoch 0 sets the best, epochs 1-3 do not improve
+
+
+def ref_ce_step(ce, disc, opt_ce, opt_d, X, mask, l2w=0.999):
+    """CPU restatement of run_context_encoder.train_step (run_context_encoder.py:225-260)."""
+    for p in ce.params + disc.params:
+        p.grad = None
+    pred = ce(X * (1 - mask), training=True)
+    l2 = torch_ref.mse_weighted(X, pred, mask[:, :, :, 0] * 10)
+    p_real = disc(X, training=True)
+    p_fake = disc(pred, training=True)
+    dl = (torch_ref.bce_probs(torch.ones_like(p_real), p_real) + torch_ref.bce_probs(torch.zeros_like(p_fake), p_fake)) / 2
+    total = l2 * l2w + dl * (1 - l2w)
+    d_grads = torch.autograd.grad(dl, disc.params, retain_graph=True)
+    c_grads = torch.autograd.grad(l2, ce.params)
+    opt_d.apply_gradients(d_grads)
+    opt_ce.apply_gradients(c_grads)
+    return float(dl), float(l2), float(total)
+
+
+def test_context_encoder_train_step_trajectory():
+    from spectrum_vae_amd import context_encoder
+    from spectrum_vae_amd.run_context_encoder import batch_random_mask, build_optimizer, train_step
+    rng = np.random.default_rng(7)
+    X = data(64)
+    mask = batch_random_mask(X, 0.25, rng).astype(np.float32)
+    assert (mask[:, 4:12, 4:12, :] == 1).all() and (mask[..., 0].mean(axis=(1, 2)) >= 0.25).all()
+    ce, disc = context_encoder.ContextEncoder(), context_encoder.Discriminator()
+    ce.build((None, 32, 32, 3)); disc.build((None, 32, 32, 3))
+    ce._materialize(); disc._materialize()
+    e, d = omodels.context_encoder()
+    rce, rd = RefSequential(e + d, (32, 32, 3)), RefSequential(omodels.discriminator(), (32, 32, 3))
+    load_into_ref(rce, ce); load_into_ref(rd, disc)
+    LR = 2e-4
+    oce, od = build_optimizer(learning_rate=LR * 10), build_optimizer(learning_rate=LR)
+    roce = KerasAdam(rce.params, LR * 10, beta1=0.5, decay_steps=50, decay_rate=0.96)
+    rod = KerasAdam(rd.params, LR, beta1=0.5, decay_steps=50, decay_rate=0.96)
+    Xt, Mt = torch.from_numpy(X), torch.from_numpy(mask)
+    for step in range(6):
+        sl = slice((step % 4) * 16, (step % 4 + 1) * 16)
+        got = [float(v) for v in train_step(ce, disc, oce, od, X[sl], mask[sl])]
+        want = ref_ce_step(rce, rd, roce, rod, Xt[sl], Mt[sl])
+        for name, g, w in zip(("disc", "l2", "total"), got, want):
+            assert abs(g - w) <= 2e-3 * max(1.0, abs(w)), (step, name, g, w)
+    for v, s in zip(disc.non_trainable_variables, rd.state):  # D's BatchNorm saw two training calls per step
+        assert rel(v.numpy(), s.numpy()) <= 1e-3, v.name
+
+
+def ref_unet_step(gen, disc, opt_g, opt_d, X, y, lam=100.0):
+    """CPU restatement of run_unet.train_step (run_unet.py:164-203) with the build's generator/discriminator."""
+    for p in gen.params + disc.params:
+        p.grad = None
+    g_out = gen(X, training=True)
+    z_real = disc(torch.cat([X, y], dim=-1), training=True)
+    z_fake = disc(torch.cat([X, g_out], dim=-1), training=True)
+    gan = torch_ref.bce_logits(torch.ones_like(z_fake), z_fake)
+    l1 = torch_ref.mae(y, g_out)
+    g_total = gan + lam * l1
+    d_loss = torch_ref.bce_logits(torch.ones_like(z_real), z_real) + torch_ref.bce_logits(torch.zeros_like(z_fake), z_fake)
+    d_grads = torch.autograd.grad(d_loss, disc.params, retain_graph=True)
+    g_grads = torch.autograd.grad(g_total, gen.params)
+    opt_d.apply_gradients(d_grads)
+    opt_g.apply_gradients(g_grads)
+    return float(d_loss), float(g_total), float(gan), float(l1)
+
+
+class RefUNetDisc:
+    """Oracle twin of unet.Discriminator (the build's own structure; no reference definition exists)."""
+
+    def __init__(self):
+        k = (4, 4)
+        blocks = [omodels.unet_down_block(64, k, (2, 2), apply_batchnorm=False), omodels.unet_down_block(128, k, (2, 2)),
+                  omodels.unet_down_block(256, k, (2, 2))]
+        head = [dict(type="conv2d", filters=1, kernel=k, strides=(1, 1), padding="valid", activation=None,
+                     use_bias=True, init="normal0.02"), dict(type="flatten")]
+        self.seq = RefSequential([l for b in blocks for l in b] + head, (32, 32, 4))
+        self.params, self.state = self.seq.params, self.seq.state
+
+    def __call__(self, x, training=False):
+        return self.seq(x, training)
+
+
+def test_unet_gan_train_step():
+    from spectrum_vae_amd import unet
+    from spectrum_vae_amd.run_unet import build_optimizer, train_step
+    full = data(48)
+    X, y = full[..., :1].copy(), full
+    gen, disc = unet.Generator(), unet.Discriminator()
+    gen.build((None, 32, 32, 1)); disc.build((None, 32, 32, 4))
+    gen._materialize(); disc._materialize()
+    rg, rd = omodels.RefUNet(), RefUNetDisc()
+    rg.load_params([v.numpy() for v in gen.trainable_variables])
+    rd.seq.load_params([v.numpy() for v in disc.trainable_variables])
+    og, od = build_optimizer(learning_rate=2e-4), build_optimizer(learning_rate=2e-4)
+    rog = KerasAdam(rg.params, 2e-4, beta1=0.5, decay_steps=10, decay_rate=0.96)
+    rod = KerasAdam(rd.params, 2e-4, beta1=0.5, decay_steps=10, decay_rate=0.96)
+    Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
+    for step in range(5):
+        sl = slice((step % 3) * 16, (step % 3 + 1) * 16)
+        got = [float(v) for v in train_step(gen, disc, og, od, X[sl], y[sl])]
+        want = ref_unet_step(rg, rd, rog, rod, Xt[sl], yt[sl])
+        for name, g, w in zip(("disc", "gen_total", "gan", "l1"), got, want):
+            assert abs(g - w) <= 2e-3 * max(1.0, abs(w)), (step, name, g, w)
+    for v, p in zip(gen.trainable_variables, rg.params):
+        assert rel(v.numpy(), p.detach().numpy()) <= 2e-3, v.name
+
+
+def test_keras_surface_apply_gradients_and_losses():
+    """optimizer.apply_gradients(zip(grads, model.trainable_variables)) and the callable loss objects."""
+    from spectrum_vae_amd import autoencoder, losses
+    from spectrum_vae_amd.losses import to_device_f32
+    from spectrum_vae_amd.optimizers import Adam
+    x = data(8)
+    m = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+    pred = m(x, training=True)
+    assert tuple(pred.shape) == (8, 32, 32, 3) and isinstance(pred.numpy(), np.ndarray)
+    loss = losses.MeanSquaredError()(x, pred)
+    assert abs(float(loss.numpy()) - float(np.mean((pred.numpy() - x) ** 2))) < 1e-6
+    dpred = to_device_f32(2 * (pred.numpy() - x) / x.size)
+    before = [v.numpy() for v in m.trainable_variables]
+    m.backward_raw(dpred, -1, need_dx=False)
+    opt = Adam(1e-3)
+    opt.apply_gradients(zip([v.grad for v in m.trainable_variables], m.trainable_variables))
+    assert opt.iterations == 1
+    after = [v.numpy() for v in m.trainable_variables]
+    assert all(np.abs(a - b).max() > 0 for a, b in zip(after, before))
+    # per-variable path: a subset of the variables with free-standing gradient tensors
+    sub = m.trainable_variables[:2]
+    opt2 = Adam(1e-2)
+    opt2.apply_gradients([(torch.ones(v.shape, device="cuda"), v) for v in sub])
+    for v, a in zip(sub, after[:2]):
+        assert np.allclose(v.numpy(), a - 1e-2 * 1.0 / (1.0 + 1e-7 / np.sqrt(1 - 0.999)), atol=1e-6)
+    per_pixel = losses.mse(pred, x)
+    assert tuple(per_pixel.shape) == (8, 32, 32)

