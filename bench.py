@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Throughput bench of the hot path: training steps of the run_model.py auto-encoder on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One step = one optimizer step of ``CAEPadded`` at the run_model.py hyper-parameters (3 conv blocks, 8 initial
+filters, x2 multiplier, elu, 3x3, one conv per block, no bottleneck, no BatchNorm; 12 035 weights), float32,
+per-GPU batch 1024: batch gather from the HBM-resident training tensor -> forward -> MSE (+dL/dprediction) ->
+backward -> [gradient all-reduce over RCCL when N > 1] -> Keras-form Adam with its decayed learning rate.
+Inputs are synthetic tensors in the reference's training format, resident in HBM before the clock starts.
+
+Prints ONE JSON line (rank 0): train samples/s over all GPUs, plus
+  roofline     - the step's dominant kernel timed with HIP events on the launch stream, its algorithmic FLOPs
+                 (or bytes) per launch, and the fraction of the matching peak;
+  cpu_baseline - the torch-CPU restatement of the same step timed on this box's host cores (rank 0, N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 1024
+DATASET = 8192  # samples resident in HBM per rank
+RUN_MODEL_CFG = dict(conv_layers=3, conv_layer_multiplier=2, initial_filters=8, activation="elu", kernel_size=3,
+                     conv_operations=1, fc_layers=0, fc_layer_size=256, dropout=0.2, latent_dimensions=0,
+                     batch_norm=False)
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X f32-input MFMA == f32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_data(n: int, seed: int) -> np.ndarray:
+    """(n, 32, 32, 3) float32 in the reference's training format; a pool of 512 distinct regions is generated
+    through the data-prep path and tiled with per-sample row permutations (permuting haplotypes keeps the
+    format) so start-up stays short."""
+    from spectrum_vae_amd.data import synth_training_tensor
+    base = synth_training_tensor(min(n, 512), seed)
+    if n <= base.shape[0]:
+        return base[:n]
+    rng = np.random.default_rng(seed + 1)
+    out = np.empty((n,) + base.shape[1:], np.float32)
+    for i in range(n):
+        out[i] = base[i % base.shape[0]][rng.permutation(32)]
+    return out
+
+
+def conv_flops_per_sample(model) -> dict:
+    """Algorithmic FLOPs (2 x MAC) of the conv GEMMs: forward, input-gradient (none for the first layer),
+    kernel-gradient."""
+    from spectrum_vae_amd.nn import Conv2D, Conv2DTranspose, Dense
+    layers = [l for l in model._all_layers() if isinstance(l, (Conv2D, Conv2DTranspose, Dense))]
+    order = {id(l): i for i, l in enumerate(model.encoder.layers + model.decoder.layers)}
+    layers.sort(key=lambda l: order.get(id(l), 0))
+    fwd = sum(2 * l.macs_per_sample() for l in layers)
+    dgrad = sum(2 * l.macs_per_sample() for l in layers[1:])
+    return {"fwd": fwd, "fwd_bwd": 2 * fwd + dgrad, "per_layer_macs": [l.macs_per_sample() for l in layers]}
+
+
+class OpTimer:
+    """Times every C-ABI call of one eager step with HIP events recorded on the launch stream."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        from spectrum_vae_amd import _lib
+        self._lib = _lib.lib
+        self._orig = {}
+        for name in _lib.SIGNATURES:
+            fn = getattr(self._lib, name)
+            if fn.restype is not None and name.startswith("sv_") and "workspace" not in name and name not in (
+                    "sv_last_error", "sv_version"):
+                self._orig[name] = fn
+                setattr(self._lib, name, self._wrap(name, fn))
+        return self
+
+    def _wrap(self, name, fn):
+        def call(*args):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            geom = None
+            if "conv2d" in name:
+                g = args[0]._obj
+                geom = {f: getattr(g, f) for f, _ in g._fields_}
+            self.records.append((name, geom, s, e))
+            return rc
+        return call
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(self._lib, name, fn)
+        torch.cuda.synchronize()
+        self.table = [(n, g, s.elapsed_time(e) * 1e3) for n, g, s, e in self.records]  # microseconds
+
+
+def conv_call_flops(name: str, g: dict) -> float:
+    macs = g["N"] * g["Ho"] * g["Wo"] * g["Cout"] * g["KH"] * g["KW"] * g["Cin"]
+    return 2.0 * macs
+
+
+def run_cpu_baseline(budget_s: float = 20.0, batch: int = PER_GPU_BATCH) -> dict:
+    """The torch-CPU restatement of the same training step (oracle/torch_ref.py), timed on the host cores."""
+    from oracle import models as omodels
+    from oracle import torch_ref
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    cfg = {k: v for k, v in RUN_MODEL_CFG.items()}
+    enc, dec = omodels.caepadded(**cfg)
+    ref = torch_ref.RefSequential(enc + dec, (32, 32, 3))
+    opt = torch_ref.KerasAdam(ref.params, 5e-4, decay_steps=10, decay_rate=0.96)
+    x = torch.from_numpy(synth_data(batch, 1833))
+    torch_ref.train_step_mse(ref, opt, x, x)  # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        torch_ref.train_step_mse(ref, opt, x, x)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 200:
+            break
+    return {"value": round(steps * batch / el, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} training steps at batch {batch} of the torch-CPU restatement of the reference step "
+                      f"(TensorFlow is not installable here) in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile-out", default=None, help="write the per-call HIP-event table to this JSON file")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    from spectrum_vae_amd import autoencoder, losses, ops, parallel
+    from spectrum_vae_amd.run_model import build_optimizer
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    model = autoencoder.CAEPadded(**RUN_MODEL_CFG)
+    model.build((None, 32, 32, 3))
+    model._materialize(device)
+    model.use_graphs = not args.no_graph
+    model.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
+    if world > 1:
+        red = parallel.GradReducer()
+        red.broadcast_(model._params)
+        model.distribute(red)
+
+    X = torch.from_numpy(synth_data(DATASET, 1833 + rank)).to(device)
+    bs = args.batch
+    b = model._step_buffers(bs, (32, 32, 3))
+    ops.fill(b["acc"], 0.0)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1833 + rank)
+    n_batches = DATASET // bs
+    perm = torch.randperm(DATASET, device=device, generator=gen)
+
+    def step(i):
+        idx = perm[(i % n_batches) * bs:(i % n_batches + 1) * bs]
+        ops.gather_rows(X, idx, b["x"])
+        model.train_on_device_batch(b, True, float(bs))
+
+    for i in range(max(args.warmup, 3)):  # step 0 is eager (allocates), step 1 captures the graphs
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(b["loss"].item())
+
+    # ---- per-kernel timing of one eager step with HIP events (rank 0)
+    roofline, table = None, None
+    if rank == 0:
+        model.use_graphs = False
+        saved_red = model._reducer
+        model._reducer = None
+        agg = {}
+        reps = 20
+        for r in range(reps):
+            with OpTimer() as ot:
+                step(r)
+            for name, g, us in ot.table:
+                key = (name, json.dumps(g, sort_keys=True) if g else "")
+                a = agg.setdefault(key, {"us": 0.0, "calls": 0, "geom": g})
+                a["us"] += us
+                a["calls"] += 1
+        model._reducer = saved_red
+        table = sorted(({"call": k[0], "geom": v["geom"], "avg_us": v["us"] / v["calls"],
+                         "calls_per_step": v["calls"] / reps} for k, v in agg.items()), key=lambda d: -d["avg_us"])
+        top = table[0]
+        if top["geom"] is not None:
+            fl = conv_call_flops(top["call"], top["geom"])
+            ach = fl / (top["avg_us"] * 1e-6) / 1e12
+            roofline = {"bound": "mfma", "kernel": top["call"], "achieved": round(ach, 3),
+                        "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(top["avg_us"], 2), "flops_per_launch": fl, "geom": top["geom"]}
+        else:
+            roofline = {"bound": "hbm", "kernel": top["call"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": None, "traffic": None, "avg_launch_us": round(top["avg_us"], 2)}
+        if args.profile_out:
+            with open(args.profile_out, "w") as f:
+                json.dump({"batch": bs, "per_call": table}, f, indent=1)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = run_cpu_baseline()
+
+    if rank == 0:
+        fl = conv_flops_per_sample(model)
+        samples = args.steps * bs * world
+        out = {
+            "metric": "train samples/sec (fwd+bwd+loss+optimizer)",
+            "value": round(samples / elapsed, 1),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "CAEPadded run_model.py defaults (12035 weights), MSE + Keras Adam, "
+                                   f"per-GPU batch {bs}, 32x32x3 inputs", "global_batch": bs * world,
+                       "parallelism": f"dp{world}", "hip_graph": bool(model.use_graphs or not args.no_graph),
+                       "conv_flops_per_sample_fwd_bwd": fl["fwd_bwd"]},
+            "model_tflops": round(fl["fwd_bwd"] * samples / elapsed / 1e12, 3),
+            "final_loss": final_loss,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
