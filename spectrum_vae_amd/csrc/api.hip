@@ -17,6 +17,19 @@ size_t wgrad_direct_workspace(const sv_conv_geom& g);
 int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, float* dw, int accumulate, void* ws,
                         size_t ws_bytes, hipStream_t st);
 
+// conv_tiled.hip
+int launch_tiled_s1(const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int N, int Hs, int Ws,
+                    int Cin, int Cout, int K, int UP, int wflip, int epi, int act, float alpha, hipStream_t st);
+size_t tiled_wgrad_workspace(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP);
+int launch_tiled_wgrad(const float* x, const float* dz, float* dw, int accumulate, void* ws, size_t ws_bytes, int N,
+                       int Hs, int Ws, int Cin, int Cout, int K, int UP, hipStream_t st);
+
+// Stride-1 SAME conv with an odd square kernel and an isotropic folded upsampling: the LDS-tiled family.
+static bool tiled_shape(const sv_conv_geom& g) {
+    return g.KH == g.KW && (g.KH == 3 || g.KH == 5) && g.SH == 1 && g.SW == 1 && g.pad_t == (g.KH - 1) / 2 &&
+           g.pad_l == (g.KW - 1) / 2 && g.Ho == g.H && g.Wo == g.W && g.up_h == g.up_w && (g.up_h == 1 || g.up_h == 2);
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -33,6 +46,12 @@ int sv_conv2d_fwd(const sv_conv_geom* g, const void* x, const void* w, const voi
     int rc = validate_geom(g, "sv_conv2d_fwd");
     if (rc) return rc;
     SV_REQUIRE(x && w && y, "sv_conv2d_fwd: null tensor");
+    if (tiled_shape(*g)) {
+        rc = launch_tiled_s1((const float*)x, (const float*)w, (const float*)bias, (float*)y, nullptr, g->N,
+                             g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, 0, 0, act, alpha,
+                             to_stream(stream));
+        if (rc <= 0) return rc;
+    }
     return launch_fwd_direct(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, act, alpha,
                              to_stream(stream));
 }
@@ -42,13 +61,25 @@ int sv_conv2d_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* 
     int rc = validate_geom(g, "sv_conv2d_dgrad");
     if (rc) return rc;
     SV_REQUIRE(dz && w && dx, "sv_conv2d_dgrad: null tensor");
+    if (tiled_shape(*g)) {
+        // a conv of dz (Cout channels, logical resolution) with mirrored taps and swapped channel roles; a folded
+        // upsampling turns into a 2x2 sum of the result
+        rc = launch_tiled_s1((const float*)dz, (const float*)w, nullptr, (float*)dx, nullptr, g->N, g->H, g->W, g->Cout,
+                             g->Cin, g->KH, 1, 1, g->up_h == 2 ? 2 : 0, SV_ACT_NONE, 0.f, to_stream(stream));
+        if (rc <= 0) return rc;
+    }
     return launch_dgrad_direct(*g, (const float*)dz, (const float*)w, nullptr, (float*)dx, SV_ACT_NONE, 0.f,
                                to_stream(stream));
 }
 
 size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g) {
     if (validate_geom(g, "sv_conv2d_wgrad_workspace_bytes")) return 0;
-    return wgrad_direct_workspace(*g);
+    size_t need = wgrad_direct_workspace(*g);
+    if (tiled_shape(*g)) {
+        const size_t t = tiled_wgrad_workspace(g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h);
+        if (t > need) need = t;
+    }
+    return need;
 }
 
 int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate, void* workspace,
@@ -57,6 +88,11 @@ int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* 
     int rc = validate_geom(g, "sv_conv2d_wgrad");
     if (rc) return rc;
     SV_REQUIRE(x && dz && dw, "sv_conv2d_wgrad: null tensor");
+    if (tiled_shape(*g)) {
+        rc = launch_tiled_wgrad((const float*)x, (const float*)dz, (float*)dw, accumulate, workspace, workspace_bytes,
+                                g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, to_stream(stream));
+        if (rc <= 0) return rc;
+    }
     return launch_wgrad_direct(*g, (const float*)x, (const float*)dz, (float*)dw, accumulate, workspace,
                                workspace_bytes, to_stream(stream));
 }
