@@ -61,6 +61,23 @@ size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g);
 int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate,
                     void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
 
+/* ---- fused forms for stride-1 SAME convs with a 3x3 or 5x5 kernel (every conv of CAEPadded,
+ *      autoencoder.py:438-459,496-526).  sv_conv2d_fused_supported tells whether a geometry is in the family
+ *      (pooled != 0: also that the output extent is even).
+ *  sv_conv2d_pool_fwd: y = maxpool2x2(act(conv(x, w) + bias)) with the argmax (0..3, row-major in the window, first
+ *      maximum wins) in idx; the full-resolution activation is never written (conv -> MaxPooling2D((2,2)) pairs,
+ *      autoencoder.py:443-451).
+ *  sv_conv2d_bwd: whole backward of one conv layer.  dz = dy * act'(y) is formed on the fly from the saved
+ *      activation OUTPUT y; with idx != NULL, dy / y / idx are at the pooled resolution and dz is that product
+ *      placed at each window's argmax, zero elsewhere.  dw += kernel gradient, db += sum(dz) (db may be NULL),
+ *      dx = input gradient (skipped when dx == NULL).  workspace: sv_conv2d_wgrad_workspace_bytes(g). */
+int sv_conv2d_fused_supported(const sv_conv_geom* g, int pooled);
+int sv_conv2d_pool_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y_pooled,
+                       uint8_t* idx, int act, float alpha, int dtype, sv_stream_t stream);
+int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const void* dy, const void* y,
+                  const uint8_t* idx, void* dx, void* dw, void* db, int act, float alpha, void* workspace,
+                  size_t workspace_bytes, int dtype, sv_stream_t stream);
+
 /* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
 /* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */
 int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,

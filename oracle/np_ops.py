@@ -89,7 +89,7 @@ def act_bwd_from_output(y, act, alpha=0.2):
     if act == "elu":
         return np.where(y > 0, 1.0, y + 1.0)
     if act == "lrelu":
-        return np.where(y >= 0, 1.0, alpha)
+        return np.where(y > 0, 1.0, alpha)  # TensorFlow's LeakyReluGrad tests features > 0
     if act == "tanh":
         return 1.0 - y * y
     if act == "sigmoid":

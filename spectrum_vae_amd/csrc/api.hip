@@ -18,11 +18,17 @@ int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, 
                         size_t ws_bytes, hipStream_t st);
 
 // conv_tiled.hip
+bool tiled_s1_supported(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP);
 int launch_tiled_s1(const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int N, int Hs, int Ws,
-                    int Cin, int Cout, int K, int UP, int wflip, int epi, int act, float alpha, hipStream_t st);
+                    int Cin, int Cout, int K, int UP, int wflip, int epi, int act, float alpha, hipStream_t st,
+                    int zmode = 0, const float* zy = nullptr, const uint8_t* zidx = nullptr, int zact = 0,
+                    float zalpha = 0.f);
 size_t tiled_wgrad_workspace(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP);
-int launch_tiled_wgrad(const float* x, const float* dz, float* dw, int accumulate, void* ws, size_t ws_bytes, int N,
-                       int Hs, int Ws, int Cin, int Cout, int K, int UP, hipStream_t st);
+bool tiled_wgrad_supported(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP);
+int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, int accumulate, void* ws,
+                       size_t ws_bytes, int N, int Hs, int Ws, int Cin, int Cout, int K, int UP, hipStream_t st,
+                       int zmode = 0, const float* zy = nullptr, const uint8_t* zidx = nullptr, int zact = 0,
+                       float zalpha = 0.f);
 
 // Stride-1 SAME conv with an odd square kernel and an isotropic folded upsampling: the LDS-tiled family.
 static bool tiled_shape(const sv_conv_geom& g) {
@@ -89,12 +95,57 @@ int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* 
     if (rc) return rc;
     SV_REQUIRE(x && dz && dw, "sv_conv2d_wgrad: null tensor");
     if (tiled_shape(*g)) {
-        rc = launch_tiled_wgrad((const float*)x, (const float*)dz, (float*)dw, accumulate, workspace, workspace_bytes,
-                                g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, to_stream(stream));
+        rc = launch_tiled_wgrad((const float*)x, (const float*)dz, (float*)dw, nullptr, accumulate, workspace,
+                                workspace_bytes, g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h,
+                                to_stream(stream));
         if (rc <= 0) return rc;
     }
     return launch_wgrad_direct(*g, (const float*)x, (const float*)dz, (float*)dw, accumulate, workspace,
                                workspace_bytes, to_stream(stream));
+}
+
+// ---- fused forms of the stride-1 SAME family
+int sv_conv2d_fused_supported(const sv_conv_geom* g, int pooled) {
+    if (validate_geom(g, "sv_conv2d_fused_supported") || !tiled_shape(*g)) return 0;
+    if (pooled && ((g->Ho | g->Wo) & 1)) return 0;
+    const int Hs = g->H / g->up_h, Ws = g->W / g->up_w;
+    return tiled_s1_supported(g->N, Hs, Ws, g->Cin, g->Cout, g->KH, g->up_h) &&
+           tiled_s1_supported(g->N, g->H, g->W, g->Cout, g->Cin, g->KH, 1) &&
+           tiled_wgrad_supported(g->N, Hs, Ws, g->Cin, g->Cout, g->KH, g->up_h);
+}
+
+int sv_conv2d_pool_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y_pooled,
+                       uint8_t* idx, int act, float alpha, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_pool_fwd");
+    int rc = validate_geom(g, "sv_conv2d_pool_fwd");
+    if (rc) return rc;
+    SV_REQUIRE(x && w && y_pooled, "sv_conv2d_pool_fwd: null tensor");
+    SV_REQUIRE(sv_conv2d_fused_supported(g, 1), "sv_conv2d_pool_fwd: shape is outside the fused family");
+    rc = launch_tiled_s1((const float*)x, (const float*)w, (const float*)bias, (float*)y_pooled, idx, g->N,
+                         g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, 0, 1, act, alpha,
+                         to_stream(stream));
+    return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_pool_fwd: shape not covered") : rc;
+}
+
+int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const void* dy, const void* y,
+                  const uint8_t* idx, void* dx, void* dw, void* db, int act, float alpha, void* workspace,
+                  size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_bwd");
+    int rc = validate_geom(g, "sv_conv2d_bwd");
+    if (rc) return rc;
+    SV_REQUIRE(x && w && dy && y && dw, "sv_conv2d_bwd: null tensor");
+    const int pooled = idx != nullptr;
+    SV_REQUIRE(sv_conv2d_fused_supported(g, pooled), "sv_conv2d_bwd: shape is outside the fused family");
+    const int zmode = pooled ? 2 : 1;
+    rc = launch_tiled_wgrad((const float*)x, (const float*)dy, (float*)dw, (float*)db, 1, workspace, workspace_bytes,
+                            g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, to_stream(stream),
+                            zmode, (const float*)y, idx, act, alpha);
+    if (rc) return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: shape not covered") : rc;
+    if (dx == nullptr) return SV_OK;
+    rc = launch_tiled_s1((const float*)dy, (const float*)w, nullptr, (float*)dx, nullptr, g->N, g->H, g->W, g->Cout,
+                         g->Cin, g->KH, 1, 1, g->up_h == 2 ? 2 : 0, SV_ACT_NONE, 0.f, to_stream(stream), zmode,
+                         (const float*)y, idx, act, alpha);
+    return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: shape not covered") : rc;
 }
 
 // Conv2DTranspose forward is the input-gradient kernel of the described conv, plus bias and activation.

@@ -63,16 +63,39 @@ __device__ __forceinline__ float act_apply(float z, int act, float alpha) {
     }
 }
 
-// d act / d z written in terms of the activation output y.
+// d act / d z written in terms of the activation output y.  At y == 0 the one-sided choice is TensorFlow's
+// (ReluGrad / LeakyReluGrad test `features > 0`).
 __device__ __forceinline__ float act_grad_from_y(float y, int act, float alpha) {
     switch (act) {
         case SV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
         case SV_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
-        case SV_ACT_LRELU: return y >= 0.f ? 1.f : alpha;
+        case SV_ACT_LRELU: return y > 0.f ? 1.f : alpha;
         case SV_ACT_TANH: return 1.f - y * y;
         case SV_ACT_SIGMOID: return y * (1.f - y);
         default: return 1.f;
     }
+}
+
+// The same derivative as a branch-free quadratic in y with one coefficient set per sign of y, so a staging loop
+// does not carry a switch: d = c0 + c1*y + c2*y^2, coefficients chosen by (y > 0).
+struct ActGradCoef {
+    float p0, p1, p2;  // y > 0
+    float n0, n1, n2;  // y <= 0
+};
+inline ActGradCoef act_grad_coef(int act, float alpha) {
+    switch (act) {
+        case SV_ACT_RELU: return {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        case SV_ACT_ELU: return {1.f, 0.f, 0.f, 1.f, 1.f, 0.f};
+        case SV_ACT_LRELU: return {1.f, 0.f, 0.f, alpha, 0.f, 0.f};
+        case SV_ACT_TANH: return {1.f, 0.f, -1.f, 1.f, 0.f, -1.f};
+        case SV_ACT_SIGMOID: return {0.f, 1.f, -1.f, 0.f, 1.f, -1.f};
+        default: return {1.f, 0.f, 0.f, 1.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ float act_grad_q(float y, const ActGradCoef& k) {
+    const bool pos = y > 0.f;
+    const float c0 = pos ? k.p0 : k.n0, c1 = pos ? k.p1 : k.n1, c2 = pos ? k.p2 : k.n2;
+    return fmaf(fmaf(c2, y, c1), y, c0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

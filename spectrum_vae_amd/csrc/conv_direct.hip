@@ -160,12 +160,33 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct(sv_conv_geom g, const
     }
 }
 
-__global__ void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int64_t kc, int n_split,
-                             int accumulate) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < kc; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = accumulate ? dw[i] : 0.f;
-        for (int sp = 0; sp < n_split; ++sp) s += part[(int64_t)sp * kc + i];
-        dw[i] = s;
+// dw[i] (+)= sum_sp part[sp][i].  64 consecutive outputs per block (one coalesced 256-byte row per slab),
+// 16 waves each summing every 16th slab with 8 loads in flight, then a fixed-order fold through LDS:
+// latency-parallel and bitwise reproducible.
+__global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
+                                                      int64_t kc, int n_split, int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (i < kc) {
+        int sp = grp;
+        for (; sp + 7 * 16 < n_split; sp += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(sp + u * 16) * kc + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; sp < n_split; sp += 16) s += part[(int64_t)sp * kc + i];
+    }
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && i < kc) {
+        float t = accumulate ? dw[i] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][lane];
+        dw[i] = t;
     }
 }
 
@@ -250,7 +271,7 @@ int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, 
         hipLaunchKernelGGL(conv2d_wgrad_direct<4>, grid, dim3(256), 0, st, g, x, dz, part, pps);
     int rc = check_launch("conv2d_wgrad_direct");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(ew_grid(kc)), dim3(256), 0, st, part, dw, kc, ns, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, part, dw, kc, ns, accumulate);
     return check_launch("wgrad_reduce");
 }
 

@@ -37,7 +37,20 @@ struct TiledArgs {
     int plane;    // floats per LDS channel plane
     int wp;       // floats per LDS row
     int halo;     // stored halo (rows/cols of zeros around the image)
+    // The staged input may be a gradient formed on the fly (input-gradient launches):
+    //   zmode 0: x as is;  1: x * act'(zy) elementwise;  2: x, zy, zidx live at the POOLED resolution
+    //   (Hs/2 x Ws/2) and the staged value is x*act'(zy) at the argmax position of each 2x2 window, 0 elsewhere.
+    const float* zy;
+    const uint8_t* zidx;
+    int zmode;
+    ActGradCoef zk;
+    int lgW, lgH;  // log2 of Ws / Hs when they are powers of two, else -1
 };
+
+// n / d and n % d for a divisor that is usually a power of two (image extents, channel counts): lg >= 0 selects
+// the shift form, lg < 0 the general division.
+__device__ __forceinline__ int fdiv(int n, int d, int lg) { return lg >= 0 ? (n >> lg) : n / d; }
+inline int ilog2_exact(int v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctz(v) : -1; }
 
 __host__ __device__ constexpr int floordiv_c(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
@@ -45,31 +58,113 @@ __host__ __device__ constexpr int floordiv_c(int a, int b) { return (a >= 0) ? a
 template <int UP, int PADL>
 __host__ __device__ constexpr int patch_row(int q) { return floordiv_c(q - PADL, UP) - floordiv_c(-PADL, UP); }
 
+// ---- staging helpers (nt = threads in the block) -------------------------------------------------------------
+// Input chunk [ci0, ci0+cic) of samples [n0, n0+ns) -> planar LDS image inside the zero halo.
+__device__ __forceinline__ void stage_input(const TiledArgs& a, float* in_lds, int n0, int ns, int ci0, int cic,
+                                            int nt) {
+    const int Hs = a.Hs, Ws = a.Ws;
+    const int tid = threadIdx.x;
+    const int C4 = cic >> 2;
+    const bool vec = (cic & 3) == 0 && (a.Cin & 3) == 0 && C4 > 0 && (C4 & (C4 - 1)) == 0 && C4 <= nt;
+    if (a.zmode != 2) {
+        if (vec) {  // one float4 = 4 channels of one pixel
+            const int cl = tid & (C4 - 1), pl = tid / C4, PP = nt / C4;
+            const int HW = Hs * Ws;
+            for (int p = pl; p < ns * HW; p += PP) {
+                const int r = fdiv(p, Ws, a.lgW), col = p - r * Ws;
+                const int ss = fdiv(r, Hs, a.lgH), row = r - ss * Hs;
+                const size_t gi = ((size_t)n0 * HW + p) * a.Cin + ci0 + cl * 4;
+                float4 v = *reinterpret_cast<const float4*>(a.x + gi);
+                if (a.zmode == 1) {
+                    const float4 yv = *reinterpret_cast<const float4*>(a.zy + gi);
+                    v.x *= act_grad_q(yv.x, a.zk);
+                    v.y *= act_grad_q(yv.y, a.zk);
+                    v.z *= act_grad_q(yv.z, a.zk);
+                    v.w *= act_grad_q(yv.w, a.zk);
+                }
+                float* q = in_lds + (ss * a.cic + cl * 4) * a.plane + (row + a.halo) * a.wp + col + a.halo;
+                q[0] = v.x; q[a.plane] = v.y; q[2 * a.plane] = v.z; q[3 * a.plane] = v.w;
+            }
+        } else {
+            const int elems = Hs * Ws * cic;
+            for (int i = tid; i < ns * elems; i += nt) {
+                const int ss = i / elems;
+                const int e = i - ss * elems;
+                const int p = e / cic, c = e - p * cic;
+                const int row = p / Ws, col = p - row * Ws;
+                const size_t gi = (((size_t)(n0 + ss) * Hs + row) * Ws + col) * a.Cin + ci0 + c;
+                float v = a.x[gi];
+                if (a.zmode == 1) v *= act_grad_q(a.zy[gi], a.zk);
+                in_lds[(ss * a.cic + c) * a.plane + (row + a.halo) * a.wp + col + a.halo] = v;
+            }
+        }
+    } else {  // pooled gradient: x, zy, zidx at (Hs/2, Ws/2); scatter to the argmax slot of each 2x2 window
+        const int Hq = Hs >> 1, Wq = Ws >> 1;
+        const int elems = Hq * Wq * cic;
+        for (int i = tid; i < ns * elems; i += nt) {
+            const int ss = i / elems;
+            const int e = i - ss * elems;
+            const int p = e / cic, c = e - p * cic;
+            const int row = p / Wq, col = p - row * Wq;
+            const size_t gi = (((size_t)(n0 + ss) * Hq + row) * Wq + col) * a.Cin + ci0 + c;
+            const float v = a.x[gi] * act_grad_q(a.zy[gi], a.zk);
+            const int k = a.zidx[gi];
+            float* q = in_lds + (ss * a.cic + c) * a.plane + (2 * row + a.halo) * a.wp + 2 * col + a.halo;
+            *reinterpret_cast<float2*>(q) = make_float2(k == 0 ? v : 0.f, k == 1 ? v : 0.f);
+            *reinterpret_cast<float2*>(q + a.wp) = make_float2(k == 2 ? v : 0.f, k == 3 ? v : 0.f);
+        }
+    }
+}
+
+// Filter chunk -> w_lds[tap][c][cop] (cop = channel tiles * CO_T, zero padded).
+template <int K>
+__device__ __forceinline__ void stage_weights(const TiledArgs& a, float* w_lds, int ci0, int cic, int co_base, int coc,
+                                              int cop, int nt) {
+    const int cnt = K * K * cic * cop;
+    for (int i = threadIdx.x; i < cnt; i += nt) {
+        const int co = i % cop;
+        const int r = i / cop;
+        const int c = r % cic, tap = r / cic;
+        float v = 0.f;
+        if (co < coc) {
+            const int kh = tap / K, kw = tap - kh * K;
+            if (a.wflip)  // stored [K][K][Cout_launch][Cin_launch], taps mirrored
+                v = a.w[((size_t)((K - 1 - kh) * K + (K - 1 - kw)) * a.Cout + co_base + co) * a.Cin + ci0 + c];
+            else
+                v = a.w[((size_t)tap * a.Cin + ci0 + c) * a.Cout + co_base + co];
+        }
+        w_lds[(tap * a.cic + c) * cop + co] = v;
+    }
+}
+
 template <int K, int UP, int CO_T, int EPI>
 __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
     constexpr int PADL = (K - 1) / 2;
     constexpr int NPR = patch_row<UP, PADL>(K) + 1;  // patch rows == patch cols
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* in_lds = smem;                                   // [S][cic][plane]
-    float* w_lds = smem + (size_t)a.S * a.cic * a.plane;    // [K*K][cic][coc]
+    float* w_lds = smem + (size_t)a.S * a.cic * a.plane;    // [K*K][cic][cop]
+    const int nt = blockDim.x;
 
     const int tiles_x = a.Wo >> 1, tiles_y = a.Ho >> 1;
     const int T = tiles_x * tiles_y;
     const int co_base = blockIdx.y * a.coc;
     const int coc = min(a.coc, a.Cout - co_base);  // channels this block really owns
     const int n_cot = (coc + CO_T - 1) / CO_T;
+    const int cop = n_cot * CO_T;
     const int per_cot = a.S * T;                   // work items per channel tile in one pass
     const int total = n_cot * per_cot;
-    const int Hs = a.Hs, Ws = a.Ws;
+    const bool one_chunk = a.cic >= a.Cin;
 
     // zero once: the halo, the row padding and unused planes are never overwritten afterwards
-    for (int i = threadIdx.x; i < a.S * a.cic * a.plane; i += 256) in_lds[i] = 0.f;
+    for (int i = threadIdx.x; i < a.S * a.cic * a.plane; i += nt) in_lds[i] = 0.f;
+    if (one_chunk) stage_weights<K>(a, w_lds, 0, a.Cin, co_base, coc, cop, nt);
 
     for (int n0 = blockIdx.x * a.S; n0 < a.N; n0 += gridDim.x * a.S) {
         const int ns = min(a.S, a.N - n0);
-        // A thread owns one work item per pass of 256; its accumulators live across the ci-chunk loop.  When a
-        // sample pass has more than 256 items the passes are looped and each re-walks (re-stages) the chunks.
-        for (int item0 = 0; item0 < total; item0 += 256) {
+        // A thread owns one work item per pass of nt; its accumulators live across the ci-chunk loop.  When a
+        // sample pass has more than nt items the passes are looped and each re-walks (re-stages) the chunks.
+        for (int item0 = 0; item0 < total; item0 += nt) {
             const int item = item0 + threadIdx.x;
             const bool live = item < total;
             int cot = 0, s = 0, ty = 0, tx = 0;
@@ -93,53 +188,32 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
             for (int ci0 = 0; ci0 < a.Cin; ci0 += a.cic) {
                 const int cic = min(a.cic, a.Cin - ci0);
                 __syncthreads();  // previous chunk / item pass is done with LDS (and the zero fill has landed)
-                // ---- stage the input chunk: planar image inside the zero halo
-                {
-                    const int elems = Hs * Ws * cic;
-                    for (int i = threadIdx.x; i < ns * elems; i += 256) {
-                        const int ss = i / elems;
-                        const int e = i - ss * elems;
-                        const int c = e % cic;
-                        const int p = e / cic;
-                        const int col = p % Ws, row = p / Ws;
-                        const float v = a.x[(((size_t)(n0 + ss) * Hs + row) * Ws + col) * a.Cin + ci0 + c];
-                        in_lds[(ss * a.cic + c) * a.plane + (row + a.halo) * a.wp + col + a.halo] = v;
-                    }
-                }
-                // ---- stage the filter chunk: w_lds[tap][c][co], co padded with zeros up to n_cot*CO_T
-                {
-                    const int cop = n_cot * CO_T;
-                    const int cnt = K * K * cic * cop;
-                    for (int i = threadIdx.x; i < cnt; i += 256) {
-                        const int co = i % cop;
-                        const int c = (i / cop) % cic;
-                        const int tap = i / (cop * cic);
-                        float v = 0.f;
-                        if (co < coc) {
-                            const int kh = tap / K, kw = tap - kh * K;
-                            if (a.wflip)  // stored [K][K][Cout_launch][Cin_launch], taps mirrored
-                                v = a.w[((size_t)((K - 1 - kh) * K + (K - 1 - kw)) * a.Cout + co_base + co) * a.Cin + ci0 + c];
-                            else
-                                v = a.w[((size_t)tap * a.Cin + ci0 + c) * a.Cout + co_base + co];
-                        }
-                        w_lds[(tap * a.cic + c) * (n_cot * CO_T) + co] = v;
-                    }
-                }
+                if (item0 == 0 || !one_chunk) stage_input(a, in_lds, n0, ns, ci0, cic, nt);
+                if (!one_chunk) stage_weights<K>(a, w_lds, ci0, cic, co_base, coc, cop, nt);
                 __syncthreads();
                 if (work) {
-                    const int cop = n_cot * CO_T;
                     const float* img = in_lds + (size_t)s * a.cic * a.plane;
-                    // patch origin in the padded stored image
+                    // patch origin in the padded stored image (even column when UP == 1: 8-byte aligned rows)
                     const int r0 = (UP == 1 ? 2 * ty : ty) + a.halo + floordiv_c(-PADL, UP);
                     const int c0 = (UP == 1 ? 2 * tx : tx) + a.halo + floordiv_c(-PADL, UP);
                     const float* wbase = w_lds + cot * CO_T;
                     for (int c = 0; c < cic; ++c) {
-                        float patch[NPR][NPR];
+                        float patch[NPR][NPR + 1];
                         const float* pl = img + c * a.plane + r0 * a.wp + c0;
 #pragma unroll
-                        for (int pr = 0; pr < NPR; ++pr)
+                        for (int pr = 0; pr < NPR; ++pr) {
+                            if (UP == 1) {  // NPR = K + 1 is even
 #pragma unroll
-                            for (int pc = 0; pc < NPR; ++pc) patch[pr][pc] = pl[pr * a.wp + pc];
+                                for (int pc = 0; pc < NPR; pc += 2) {
+                                    const float2 v2 = *reinterpret_cast<const float2*>(pl + pr * a.wp + pc);
+                                    patch[pr][pc] = v2.x;
+                                    patch[pr][pc + 1] = v2.y;
+                                }
+                            } else {
+#pragma unroll
+                                for (int pc = 0; pc < NPR; ++pc) patch[pr][pc] = pl[pr * a.wp + pc];
+                            }
+                        }
 #pragma unroll
                         for (int kh = 0; kh < K; ++kh)
 #pragma unroll
@@ -147,7 +221,10 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
                                 float wv[CO_T];
                                 const float* wp = wbase + ((kh * K + kw) * a.cic + c) * cop;
 #pragma unroll
-                                for (int q = 0; q < CO_T; ++q) wv[q] = wp[q];
+                                for (int q = 0; q < CO_T; q += 4) {
+                                    const float4 w4 = *reinterpret_cast<const float4*>(wp + q);
+                                    wv[q] = w4.x; wv[q + 1] = w4.y; wv[q + 2] = w4.z; wv[q + 3] = w4.w;
+                                }
 #pragma unroll
                                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -189,20 +266,24 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
                             }
                         }
                 } else if (EPI == EPI_MAXPOOL) {
+                    // max of the pre-activations first (every activation here is non-decreasing, so the maximum and -
+                    // wherever the activation is strictly increasing - its position are those of the activated
+                    // values), then ONE activation per window.  relu flattens negatives into ties at 0 whose "first
+                    // maximum" is slot 0 in the unfused order; no gradient flows there (relu'(0) = 0), so only the
+                    // recorded slot could differ, and it is made to agree below.
                     const size_t o = (((size_t)n * tiles_y + ty) * tiles_x + tx) * a.Cout + cg;
 #pragma unroll
                     for (int q = 0; q < CO_T; ++q)
                         if (cg + q < a.Cout) {
                             const float b = a.bias != nullptr ? a.bias[cg + q] : 0.f;
-                            float best = act_apply(acc[0][0][q] + b, a.act, a.alpha);
+                            float best = acc[0][0][q];
                             int bi = 0;
-                            const float v1 = act_apply(acc[0][1][q] + b, a.act, a.alpha);
-                            const float v2 = act_apply(acc[1][0][q] + b, a.act, a.alpha);
-                            const float v3 = act_apply(acc[1][1][q] + b, a.act, a.alpha);
-                            if (v1 > best) { best = v1; bi = 1; }
-                            if (v2 > best) { best = v2; bi = 2; }
-                            if (v3 > best) { best = v3; bi = 3; }
-                            a.y[o + q] = best;
+                            if (acc[0][1][q] > best) { best = acc[0][1][q]; bi = 1; }
+                            if (acc[1][0][q] > best) { best = acc[1][0][q]; bi = 2; }
+                            if (acc[1][1][q] > best) { best = acc[1][1][q]; bi = 3; }
+                            const float v = act_apply(best + b, a.act, a.alpha);
+                            if (a.act == SV_ACT_RELU && v <= 0.f) bi = 0;
+                            a.y[o + q] = v;
                             if (a.idx != nullptr) a.idx[o + q] = (uint8_t)bi;
                         }
                 } else {  // EPI_SUM4
@@ -219,7 +300,7 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
 // ------------------------------------------------------------------------------------------------ host side
 struct TiledPlan {
     bool ok;
-    int S, cic, coc, plane, wp, halo, co_t;
+    int S, cic, coc, plane, wp, halo, co_t, nt;
     size_t lds_bytes;
     dim3 grid;
 };
@@ -249,19 +330,24 @@ TiledPlan plan_tiled(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     while (cic > 1 && bytes(1, cic, coc) > kLdsBudget) cic = (cic + 1) / 2;
     if (bytes(1, cic, coc) > kLdsBudget) return p;
     const int n_cot = coc / p.co_t;
-    int S = 256 / (T * n_cot);
-    if (S < 1) S = 1;
+    // One pass should hold ~256 work items; small layers take several samples per pass, but never so few passes
+    // that the grid cannot cover the chip (>= ~3 blocks per CU): then the block shrinks to 128 or 64 threads.
+    const int items1 = T * n_cot;  // items of one sample
+    int S = items1 >= 256 ? 1 : 256 / items1;
+    const int ny = (Cout + coc - 1) / coc;
+    while (S > 1 && (int64_t)((N + S - 1) / S) * ny < 768) S >>= 1;
     while (S > 1 && bytes(S, cic, coc) > kLdsBudget) --S;
     if (S > N) S = N;
-    // accumulators must survive the ci-chunk loop: with several item passes AND several chunks the kernel would
-    // re-stage per pass, which it does (correct), just slower; nothing to forbid here.
+    int nt = 256;
+    while (nt > 64 && S * items1 <= nt / 2) nt >>= 1;
+    p.nt = nt;
     p.S = S;
     p.cic = cic;
     p.coc = coc;
     p.lds_bytes = bytes(S, cic, coc);
     const int passes = (N + S - 1) / S;
-    int gx = passes < 2048 ? passes : 2048;
-    p.grid = dim3((unsigned)gx, (unsigned)((Cout + coc - 1) / coc));
+    int gx = passes < 4096 ? passes : 4096;
+    p.grid = dim3((unsigned)gx, (unsigned)ny);
     p.ok = true;
     return p;
 }
@@ -270,13 +356,13 @@ template <int K, int UP, int CO_T>
 int launch_epi(const TiledArgs& a, int epi, const TiledPlan& p, hipStream_t st) {
     switch (epi) {
         case EPI_STORE:
-            hipLaunchKernelGGL((conv_s1_lds<K, UP, CO_T, EPI_STORE>), p.grid, dim3(256), p.lds_bytes, st, a);
+            hipLaunchKernelGGL((conv_s1_lds<K, UP, CO_T, EPI_STORE>), p.grid, dim3(p.nt), p.lds_bytes, st, a);
             break;
         case EPI_MAXPOOL:
-            hipLaunchKernelGGL((conv_s1_lds<K, UP, CO_T, EPI_MAXPOOL>), p.grid, dim3(256), p.lds_bytes, st, a);
+            hipLaunchKernelGGL((conv_s1_lds<K, UP, CO_T, EPI_MAXPOOL>), p.grid, dim3(p.nt), p.lds_bytes, st, a);
             break;
         default:
-            hipLaunchKernelGGL((conv_s1_lds<K, UP, CO_T, EPI_SUM4>), p.grid, dim3(256), p.lds_bytes, st, a);
+            hipLaunchKernelGGL((conv_s1_lds<K, UP, CO_T, EPI_SUM4>), p.grid, dim3(p.nt), p.lds_bytes, st, a);
             break;
     }
     return check_launch("conv_s1_lds");
@@ -289,17 +375,26 @@ int launch_cot(const TiledArgs& a, int epi, const TiledPlan& p, hipStream_t st) 
 
 // Returns 1 when the shape is not covered (caller falls back to the direct kernels), 0 on success, <0 on error.
 // Logical conv: input (Hs*UP, Ws*UP, Cin) -> output (Hs*UP, Ws*UP, Cout), K x K, stride 1, SAME.
+bool tiled_s1_supported(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
+    if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return false;
+    return plan_tiled(N, Hs, Ws, Cin, Cout, K, UP).ok;
+}
+
 int launch_tiled_s1(const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int N, int Hs, int Ws,
-                    int Cin, int Cout, int K, int UP, int wflip, int epi, int act, float alpha, hipStream_t st) {
+                    int Cin, int Cout, int K, int UP, int wflip, int epi, int act, float alpha, hipStream_t st,
+                    int zmode, const float* zy, const uint8_t* zidx, int zact, float zalpha) {
     if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return 1;
     TiledPlan p = plan_tiled(N, Hs, Ws, Cin, Cout, K, UP);
     if (!p.ok) return 1;
+    if (zmode == 2 && ((Hs | Ws) & 1)) return 1;
     TiledArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.idx = idx;
     a.N = N; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.Cout = Cout;
     a.Ho = Hs * UP; a.Wo = Ws * UP;
     a.wflip = wflip; a.act = act; a.alpha = alpha;
     a.S = p.S; a.cic = p.cic; a.coc = p.coc; a.plane = p.plane; a.wp = p.wp; a.halo = p.halo;
+    a.zmode = zmode; a.zy = zy; a.zidx = zidx; a.zk = act_grad_coef(zact, zalpha);
+    a.lgW = ilog2_exact(Ws); a.lgH = ilog2_exact(Hs);
     if (K == 3) return UP == 1 ? launch_cot<3, 1>(a, epi, p, st) : launch_cot<3, 2>(a, epi, p, st);
     return UP == 1 ? launch_cot<5, 1>(a, epi, p, st) : launch_cot<5, 2>(a, epi, p, st);
 }
@@ -325,6 +420,13 @@ struct WgradArgs {
     int S, cib, cob;  // samples per pass; input channels per block (grid.y); output channels per block (grid.z)
     int PG;           // pixel groups (power of two <= 64)
     int xplane, xwp, zplane;
+    // dz formed on the fly, as in TiledArgs: 0 = dz given; 1 = dz*act'(zy); 2 = pooled (dz, zy, zidx at Ho/2 x Wo/2)
+    const float* zy;
+    const uint8_t* zidx;
+    int zmode;
+    ActGradCoef zk;
+    int lgWs, lgHs, lgHWo;  // log2 of Ws, Hs, Ho*Wo when powers of two, else -1
+    int with_bias;    // also emit sum(dz) per output channel at slab offset K*K*Cin*Cout
 };
 
 template <int K, int CO_T>
@@ -349,10 +451,14 @@ __global__ __launch_bounds__(256) void wgrad_s1_lds(WgradArgs a) {
     const int strips = a.Ho * strips_x;
 
     float acc[K * K][CO_T];
+    float accb[CO_T];
 #pragma unroll
     for (int t = 0; t < K * K; ++t)
 #pragma unroll
         for (int q = 0; q < CO_T; ++q) acc[t][q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < CO_T; ++q) accb[q] = 0.f;
+    const bool do_bias = a.with_bias && live && cil == 0 && blockIdx.y == 0;
 
     // zero once: halo, row padding and padded channels never get overwritten
     const int lds_floats = a.S * (a.cib * a.xplane + n_cot * CO_T * a.zplane);
@@ -362,25 +468,83 @@ __global__ __launch_bounds__(256) void wgrad_s1_lds(WgradArgs a) {
         const int ns = min(a.S, a.N - n0);
         __syncthreads();
         {  // stage x (replicated to the logical resolution when up > 1)
+            const int tid = threadIdx.x;
             const int Hl = a.Hs * a.up, Wl = a.Ws * a.up;
-            const int elems = Hl * Wl * cib;
-            for (int i = threadIdx.x; i < ns * elems; i += 256) {
-                const int ss = i / elems;
-                const int e = i - ss * elems;
-                const int c = e % cib;
-                const int p = e / cib;
-                const int col = p % Wl, row = p / Wl;
-                const float v = a.x[(((size_t)(n0 + ss) * a.Hs + row / a.up) * a.Ws + col / a.up) * a.Cin + ci_base + c];
-                x_lds[(ss * a.cib + c) * a.xplane + (row + PADL) * a.xwp + col + PADL] = v;
+            const int C4 = cib >> 2;
+            if ((cib & 3) == 0 && (a.Cin & 3) == 0 && C4 > 0 && (C4 & (C4 - 1)) == 0) {
+                const int cl = tid & (C4 - 1), pl = tid / C4, PP = 256 / C4;
+                const int HW = a.Hs * a.Ws;
+                for (int p = pl; p < ns * HW; p += PP) {
+                    const int r = fdiv(p, a.Ws, a.lgWs), col = p - r * a.Ws;
+                    const int ss = fdiv(r, a.Hs, a.lgHs), row = r - ss * a.Hs;
+                    const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)n0 * HW + p) * a.Cin + ci_base + cl * 4);
+                    float* q = x_lds + (ss * a.cib + cl * 4) * a.xplane + (row * a.up + PADL) * a.xwp + col * a.up + PADL;
+                    for (int u = 0; u < a.up; ++u)
+                        for (int t = 0; t < a.up; ++t) {
+                            float* qq = q + u * a.xwp + t;
+                            qq[0] = v.x; qq[a.xplane] = v.y; qq[2 * a.xplane] = v.z; qq[3 * a.xplane] = v.w;
+                        }
+                }
+            } else {
+                const int elems = Hl * Wl * cib;
+                for (int i = tid; i < ns * elems; i += 256) {
+                    const int ss = i / elems;
+                    const int e = i - ss * elems;
+                    const int p = e / cib, c = e - p * cib;
+                    const int row = p / Wl, col = p - row * Wl;
+                    const float v = a.x[(((size_t)(n0 + ss) * a.Hs + row / a.up) * a.Ws + col / a.up) * a.Cin + ci_base + c];
+                    x_lds[(ss * a.cib + c) * a.xplane + (row + PADL) * a.xwp + col + PADL] = v;
+                }
             }
-            const int zel = a.Ho * a.Wo * cob;
-            for (int i = threadIdx.x; i < ns * zel; i += 256) {
-                const int ss = i / zel;
-                const int e = i - ss * zel;
-                const int c = e % cob;
-                const int p = e / cob;
-                z_lds[(ss * n_cot * CO_T + c) * a.zplane + p] =
-                    a.dz[((size_t)(n0 + ss) * a.Ho * a.Wo + p) * a.Cout + co_base + c];
+            // dz -> planar [co][Ho*Wo]
+            const int Z4 = cob >> 2;
+            const bool zvec = (cob & 3) == 0 && (a.Cout & 3) == 0 && Z4 > 0 && (Z4 & (Z4 - 1)) == 0;
+            const int zs = n_cot * CO_T;  // planes per sample
+            if (a.zmode != 2) {
+                const int HW = a.Ho * a.Wo;
+                if (zvec) {
+                    const int cl = tid & (Z4 - 1), pl = tid / Z4, PP = 256 / Z4;
+                    for (int p = pl; p < ns * HW; p += PP) {
+                        const int ss = fdiv(p, HW, a.lgHWo), pp = p - ss * HW;
+                        const size_t gi = ((size_t)n0 * HW + p) * a.Cout + co_base + cl * 4;
+                        float4 v = *reinterpret_cast<const float4*>(a.dz + gi);
+                        if (a.zmode == 1) {
+                            const float4 yv = *reinterpret_cast<const float4*>(a.zy + gi);
+                            v.x *= act_grad_q(yv.x, a.zk);
+                            v.y *= act_grad_q(yv.y, a.zk);
+                            v.z *= act_grad_q(yv.z, a.zk);
+                            v.w *= act_grad_q(yv.w, a.zk);
+                        }
+                        float* q = z_lds + (ss * zs + cl * 4) * a.zplane + pp;
+                        q[0] = v.x; q[a.zplane] = v.y; q[2 * a.zplane] = v.z; q[3 * a.zplane] = v.w;
+                    }
+                } else {
+                    const int zel = HW * cob;
+                    for (int i = tid; i < ns * zel; i += 256) {
+                        const int ss = i / zel;
+                        const int e = i - ss * zel;
+                        const int p = e / cob, c = e - p * cob;
+                        const size_t gi = ((size_t)(n0 + ss) * HW + p) * a.Cout + co_base + c;
+                        float v = a.dz[gi];
+                        if (a.zmode == 1) v *= act_grad_q(a.zy[gi], a.zk);
+                        z_lds[(ss * zs + c) * a.zplane + p] = v;
+                    }
+                }
+            } else {
+                const int Hq = a.Ho >> 1, Wq = a.Wo >> 1;
+                const int zel = Hq * Wq * cob;
+                for (int i = tid; i < ns * zel; i += 256) {
+                    const int ss = i / zel;
+                    const int e = i - ss * zel;
+                    const int p = e / cob, c = e - p * cob;
+                    const int row = p / Wq, col = p - row * Wq;
+                    const size_t gi = ((size_t)(n0 + ss) * Hq * Wq + p) * a.Cout + co_base + c;
+                    const float v = a.dz[gi] * act_grad_q(a.zy[gi], a.zk);
+                    const int k = a.zidx[gi];
+                    float* q = z_lds + (ss * zs + c) * a.zplane + (2 * row) * a.Wo + 2 * col;
+                    *reinterpret_cast<float2*>(q) = make_float2(k == 0 ? v : 0.f, k == 1 ? v : 0.f);
+                    *reinterpret_cast<float2*>(q + a.Wo) = make_float2(k == 2 ? v : 0.f, k == 3 ? v : 0.f);
+                }
             }
         }
         __syncthreads();
@@ -407,6 +571,10 @@ __global__ __launch_bounds__(256) void wgrad_s1_lds(WgradArgs a) {
                     const float4 v4 = *reinterpret_cast<const float4*>(zp + q * a.zplane);
                     zv[q][0] = v4.x; zv[q][1] = v4.y; zv[q][2] = v4.z; zv[q][3] = v4.w;
                 }
+                if (do_bias) {
+#pragma unroll
+                    for (int q = 0; q < CO_T; ++q) accb[q] += (zv[q][0] + zv[q][1]) + (zv[q][2] + zv[q][3]);
+                }
 #pragma unroll
                 for (int kh = 0; kh < K; ++kh)
 #pragma unroll
@@ -421,25 +589,45 @@ __global__ __launch_bounds__(256) void wgrad_s1_lds(WgradArgs a) {
             }
         }
     }
-    // fold the PG lanes that share a (ci, co tile); PG is a power of two <= 64 and combos are PG-aligned in the wave
+    // ---- fold the PG partial sums of every (ci, co tile) through LDS (the staging buffers are dead now) and
+    // write this workgroup's slab.  Slots = K*K*CO_T kernel-gradient sums (+ CO_T bias sums), folded in chunks of
+    // RS slots so the scratch stays within the staging footprint: red[thread][RS + 1].
+    constexpr int NSLOT = K * K * CO_T + CO_T;
+    constexpr int RS = 20;
+    constexpr int NCHUNK = (NSLOT + RS - 1) / RS;
+    const size_t kc = (size_t)K * K * a.Cin * a.Cout;
+    const size_t slab_stride = kc + (a.with_bias ? a.Cout : 0);
+    float* out = a.slab + (size_t)blockIdx.x * slab_stride;
+    float* red = smem;  // 256 * (RS + 1) floats = 21 KiB <= any staging footprint the planner accepts
 #pragma unroll
-    for (int t = 0; t < K * K; ++t)
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < CO_T; ++q) {
-            float v = acc[t][q];
-            for (int o = PG >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            acc[t][q] = v;
-        }
-    if (live && pg == 0) {
-        const size_t kc = (size_t)K * K * a.Cin * a.Cout;
-        float* out = a.slab + (size_t)blockIdx.x * kc;
-#pragma unroll
-        for (int t = 0; t < K * K; ++t)
-#pragma unroll
-            for (int q = 0; q < CO_T; ++q) {
-                const int co = co_base + cot * CO_T + q;
-                if (co < a.Cout) out[((size_t)t * a.Cin + ci_base + cil) * a.Cout + co] = acc[t][q];
+        for (int j = 0; j < RS; ++j) {
+            const int slot = ch * RS + j;
+            if (slot < NSLOT) {
+                const float v = slot < K * K * CO_T ? acc[slot / CO_T][slot % CO_T] : accb[(slot - K * K * CO_T) % CO_T];
+                red[threadIdx.x * (RS + 1) + j] = v;
             }
+        }
+        __syncthreads();
+        const int nout = combos * RS;
+        for (int o = threadIdx.x; o < nout; o += 256) {
+            const int cb = o / RS, j = o - cb * RS;
+            const int slot = ch * RS + j;
+            if (slot >= NSLOT) continue;
+            float sum = 0.f;
+            for (int g = 0; g < PG; ++g) sum += red[(cb * PG + g) * (RS + 1) + j];
+            const int ci_l = cb / n_cot, ct = cb - ci_l * n_cot;
+            if (slot < K * K * CO_T) {
+                const int tap = slot / CO_T, q = slot - tap * CO_T;
+                const int co = co_base + ct * CO_T + q;
+                if (co < a.Cout) out[((size_t)tap * a.Cin + ci_base + ci_l) * a.Cout + co] = sum;
+            } else if (a.with_bias && ci_l == 0 && blockIdx.y == 0) {
+                const int co = co_base + ct * CO_T + (slot - K * K * CO_T);
+                if (co < a.Cout) out[kc + co] = sum;
+            }
+        }
     }
 }
 
@@ -467,19 +655,28 @@ WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     auto bytes = [&](int S, int cib_, int cob_) {
         return ((size_t)S * (cib_ * p.xplane + cob_ * p.zplane)) * sizeof(float);
     };
-    while (cib > 1 && bytes(1, cib, cob) > kLdsBudget) cib = (cib + 1) / 2;
-    if (bytes(1, cib, cob) > kLdsBudget) return p;
+    // shrink whichever side holds more LDS until one sample fits
+    while (bytes(1, cib, cob) > kLdsBudget) {
+        const bool x_bigger = (size_t)cib * p.xplane >= (size_t)cob * p.zplane;
+        if (x_bigger && cib > 1) cib = (cib + 1) / 2;
+        else if (cob > p.co_t) cob = ((cob / 2 + p.co_t - 1) / p.co_t) * p.co_t;
+        else if (cib > 1) cib = (cib + 1) / 2;
+        else return p;
+    }
     const int combos = cib * (cob / p.co_t);
     int PG = 1;
     while (PG * 2 * combos <= 256 && PG < 64) PG *= 2;
     // enough strips per pass to feed PG groups a few strips each
     const int strips = Ho * (Wo / 4);
+    const int ny0 = (Cin + cib - 1) / cib, nz0 = (Cout + cob - 1) / cob;
     int S = (4 * PG + strips - 1) / strips;
     if (S < 1) S = 1;
+    while (S > 1 && (int64_t)((N + S - 1) / S) * ny0 * nz0 < 512) S >>= 1;
     while (S > 1 && bytes(S, cib, cob) > kLdsBudget) --S;
     if (S > N) S = N;
     p.S = S; p.cib = cib; p.cob = cob; p.PG = PG;
     p.lds_bytes = bytes(S, cib, cob);
+    if (p.lds_bytes < (size_t)256 * 21 * sizeof(float)) p.lds_bytes = (size_t)256 * 21 * sizeof(float);  // fold scratch
     const int passes = (N + S - 1) / S;
     const int ny = (Cin + cib - 1) / cib, nz = (Cout + cob - 1) / cob;
     int gx = 512 / (ny * nz);
@@ -495,26 +692,63 @@ size_t tiled_wgrad_workspace(int N, int Hs, int Ws, int Cin, int Cout, int K, in
     if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return 0;
     WgradPlan p = plan_wgrad(N, Hs, Ws, Cin, Cout, K, UP);
     if (!p.ok) return 0;
-    return (size_t)p.nblk * K * K * Cin * Cout * sizeof(float);
+    return (size_t)p.nblk * ((size_t)K * K * Cin * Cout + Cout) * sizeof(float);
 }
 
-__global__ void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int64_t kc, int n_split,
-                             int accumulate);
+// out[i] (+)= sum_sp part[sp][i] for i < kc (dw) and, when db != null, db[i - kc] for kc <= i < kc + ncb.
+__global__ __launch_bounds__(1024) void wgrad_reduce2(const float* __restrict__ part, float* __restrict__ dw,
+                                                       float* __restrict__ db, int64_t kc, int ncb, int n_split,
+                                                       int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t stride = kc + ncb;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (i < stride) {
+        int sp = grp;
+        for (; sp + 7 * 16 < n_split; sp += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(sp + u * 16) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; sp < n_split; sp += 16) s += part[(int64_t)sp * stride + i];
+    }
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && i < stride) {
+        float* o = i < kc ? dw + i : db + (i - kc);
+        float t = accumulate ? *o : 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][lane];
+        *o = t;
+    }
+}
 
-// Returns 1 when the shape is not covered, 0 on success, <0 on error.
-int launch_tiled_wgrad(const float* x, const float* dz, float* dw, int accumulate, void* ws, size_t ws_bytes, int N,
-                       int Hs, int Ws, int Cin, int Cout, int K, int UP, hipStream_t st) {
+bool tiled_wgrad_supported(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
+    if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return false;
+    return plan_wgrad(N, Hs, Ws, Cin, Cout, K, UP).ok;
+}
+
+// Returns 1 when the shape is not covered, 0 on success, <0 on error.  db != null adds the bias gradient.
+int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
+                       int N, int Hs, int Ws, int Cin, int Cout, int K, int UP, hipStream_t st, int zmode,
+                       const float* zy, const uint8_t* zidx, int zact, float zalpha) {
     if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return 1;
     WgradPlan p = plan_wgrad(N, Hs, Ws, Cin, Cout, K, UP);
     if (!p.ok) return 1;
     const size_t kc = (size_t)K * K * Cin * Cout;
-    if (ws == nullptr || ws_bytes < (size_t)p.nblk * kc * sizeof(float))
-        return fail(SV_E_WORKSPACE, "conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes,
-                    (size_t)p.nblk * kc * sizeof(float));
+    const int ncb = db != nullptr ? Cout : 0;
+    const size_t need = (size_t)p.nblk * (kc + ncb) * sizeof(float);
+    if (ws == nullptr || ws_bytes < need)
+        return fail(SV_E_WORKSPACE, "conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
     WgradArgs a{};
     a.x = x; a.dz = dz; a.slab = (float*)ws;
     a.N = N; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.Cout = Cout; a.Ho = Hs * UP; a.Wo = Ws * UP; a.up = UP;
     a.S = p.S; a.cib = p.cib; a.cob = p.cob; a.PG = p.PG; a.xplane = p.xplane; a.xwp = p.xwp; a.zplane = p.zplane;
+    a.zmode = zmode; a.zy = zy; a.zidx = zidx; a.zk = act_grad_coef(zact, zalpha); a.with_bias = db != nullptr;
+    a.lgWs = ilog2_exact(Ws); a.lgHs = ilog2_exact(Hs); a.lgHWo = ilog2_exact(a.Ho * a.Wo);
     if (K == 3) {
         if (p.co_t == 8)
             hipLaunchKernelGGL((wgrad_s1_lds<3, 8>), p.grid, dim3(256), p.lds_bytes, st, a);
@@ -525,9 +759,9 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, int accumulat
     }
     int rc = check_launch("wgrad_s1_lds");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(ew_grid((int64_t)kc)), dim3(256), 0, st, (const float*)ws, dw, (int64_t)kc,
-                       p.nblk, accumulate);
-    return check_launch("wgrad_reduce");
+    hipLaunchKernelGGL(wgrad_reduce2, dim3((unsigned)ceil_div((int64_t)(kc + ncb), 64)), dim3(1024), 0, st,
+                       (const float*)ws, dw, db, (int64_t)kc, ncb, p.nblk, accumulate);
+    return check_launch("wgrad_reduce2");
 }
 
 }  // namespace sv

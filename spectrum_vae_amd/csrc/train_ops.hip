@@ -47,12 +47,20 @@ __global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-__global__ void loss_fold_k(const float* __restrict__ partials, int nblocks, float inv_count, float* __restrict__ out,
-                            int accumulate) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += (double)partials[b];
-        const float v = (float)(s * (double)inv_count);
+// one block of 256 threads: fixed-order tree over the (<= 1024) block partials
+__global__ __launch_bounds__(256) void loss_fold_k(const float* __restrict__ partials, int nblocks, float inv_count,
+                                                    float* __restrict__ out, int accumulate) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partials[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)(red[0] * (double)inv_count);
         out[0] = accumulate ? out[0] + v : v;
     }
 }
@@ -261,7 +269,7 @@ int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int
                        loss_scale, n, partials);
     int rc = check_launch("sv_loss_mse");
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(64), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
     return check_launch("sv_loss_mse/fold");
 }
 
@@ -285,7 +293,7 @@ int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int acc
                        partials);
     int rc = check_launch("sv_loss_mae");
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(64), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
     return check_launch("sv_loss_mae/fold");
 }
 
@@ -305,7 +313,7 @@ int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out,
                            loss_scale, n, partials);
     int rc = check_launch("sv_loss_bce");
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(64), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
     return check_launch("sv_loss_bce/fold");
 }
 
@@ -364,7 +372,7 @@ int sv_reparam_kl_fwd(const float* mean, const float* logvar, const float* eps_i
                        partials, n, seed, offset);
     int rc = check_launch("sv_reparam_kl_fwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(64), 0, to_stream(stream), partials, nb, 1.f / (float)B, kl_out, 0);
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, 1.f / (float)B, kl_out, 0);
     return check_launch("sv_reparam_kl_fwd/fold");
 }
 

@@ -250,6 +250,8 @@ class _ConvBase(Layer):
         self.kernel_initializer = kernel_initializer
         self.declared_input_shape = input_shape
         self.up = (1, 1)  # nearest-upsampling folded into this conv's gather (set by Sequential's planner)
+        self.pool = None  # a following 2x2 MaxPooling2D computed in this conv's epilogue (set by the planner)
+        self.fused_bwd = False  # whole backward (act', bias/kernel/input gradient) in the fused kernels
         self._geoms: Dict[int, ops.ConvGeom] = {}
 
     def _build(self, in_shape):
@@ -293,11 +295,29 @@ class _ConvBase(Layer):
         ho, wo, cout = self.output_shape_
         return ho * wo * cout * kh * kw * self.input_shape_[2]
 
+    def plan_fusion(self, pool=None):
+        """Decide (host-side, from the geometry alone) which fused kernels this layer uses."""
+        if self.transposed:
+            return False
+        g = self.geom(1)
+        if pool is not None and ops.conv2d_fused_supported(g, True):
+            self.pool = pool
+        self.fused_bwd = ops.conv2d_fused_supported(g, self.pool is not None)
+        return self.pool is not None
+
     def forward(self, ctx, x):
         n = x.shape[0]
         g = self.geom(n)
-        y = ctx.buf(self, "y", (n,) + self.output_shape_)
         b = self.bias.data if self.bias is not None else None
+        if self.pool is not None:
+            ho, wo, cout = self.output_shape_
+            y = ctx.buf(self, "y", (n, ho // 2, wo // 2, cout))
+            idx = ctx.buf(self, "idx", (n, ho // 2, wo // 2, cout), torch.uint8)
+            ops.conv2d_pool_fwd(g, x, self.kernel.data, b, y, idx, self.act, self.alpha)
+            if ctx.training:
+                ctx.saved[id(self)] = {"x": x, "y": y, "idx": idx}
+            return y
+        y = ctx.buf(self, "y", (n,) + self.output_shape_)
         if self.transposed:
             ops.conv2d_transpose_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha)
         else:
@@ -312,6 +332,19 @@ class _ConvBase(Layer):
         n = x.shape[0]
         g = self.geom(n)
         ho, wo, cout = self.output_shape_
+        if self.fused_bwd and ctx.param_grads:
+            dx = ctx.buf(self, "dx", tuple(x.shape)) if need_dx else None
+            ws = ctx.pool.workspace(ops.conv2d_wgrad_workspace(g))
+            ops.conv2d_bwd(g, x, self.kernel.data, dy, y, s.get("idx"), dx, self.kernel.grad,
+                           self.bias.grad if self.bias is not None else None, self.act, self.alpha, ws)
+            return dx
+        if self.pool is not None:
+            # unfused backward of a fused conv+pool forward: expand the pooled gradient first
+            full = ctx.buf(self, "dy_full", (n, ho, wo, cout))
+            yfull = ctx.buf(self, "y_full", (n, ho, wo, cout))
+            ops.maxpool2d_bwd(dy, s["idx"], full, n, ho, wo, cout, 2, 2, 0, 0, ho // 2, wo // 2)
+            ops.maxpool2d_bwd(y, s["idx"], yfull, n, ho, wo, cout, 2, 2, 0, 0, ho // 2, wo // 2)
+            dy, y = full, yfull  # act'(0) * 0 == 0 at the non-argmax positions for every activation used
         rows = n * ho * wo
         dz = dy  # the activation backward runs in place on the incoming gradient buffer
         want_db = self.bias is not None and ctx.param_grads
@@ -356,6 +389,7 @@ class MaxPooling2D(Layer):
         if strides is not None and _pair(strides) != self.pool:
             raise NotImplementedError("MaxPooling2D: only stride == pool size (the reference's use) is built")
         self.padding = padding.lower()
+        self.folded = False  # True when the preceding Conv2D computes this pooling in its epilogue
 
     def _build(self, in_shape):
         h, w, c = in_shape
@@ -370,6 +404,8 @@ class MaxPooling2D(Layer):
         return (ho, wo, c)
 
     def forward(self, ctx, x):
+        if self.folded:
+            return x
         n = x.shape[0]
         h, w, c = self.input_shape_
         ho, wo, _ = self.output_shape_
@@ -383,6 +419,8 @@ class MaxPooling2D(Layer):
     def backward(self, ctx, dy, need_dx=True):
         if not need_dx:
             return None
+        if self.folded:
+            return dy
         n = dy.shape[0]
         h, w, c = self.input_shape_
         ho, wo, _ = self.output_shape_
@@ -643,10 +681,12 @@ class ReduceSumH(Layer):
 class Sequential(Layer):
     """tf.keras.Sequential: a list of layers run in order, with ``summary()``."""
 
-    def __init__(self, layers: Optional[Sequence[Layer]] = None, name=None, fold_upsampling: bool = True):
+    def __init__(self, layers: Optional[Sequence[Layer]] = None, name=None, fold_upsampling: bool = True,
+                 fuse: bool = True):
         super().__init__(name)
         self.layers: List[Layer] = []
         self.fold_upsampling = fold_upsampling
+        self.fuse = fuse  # conv+pool forward fusion and fused conv backward where the kernels cover the shape
         for l in layers or []:
             self.add(l)
 
@@ -677,6 +717,15 @@ class Sequential(Layer):
                 self.layers[i + 1].up = l.size
                 continue  # the conv sees the *stored* (small) tensor's shape
             shape = l.build(shape)
+        if self.fuse:
+            for i, l in enumerate(self.layers):
+                if type(l) is not Conv2D:
+                    continue
+                nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
+                pool = nxt if (isinstance(nxt, MaxPooling2D) and nxt.pool == (2, 2) and nxt.pt == 0 and nxt.pl == 0
+                               and l.output_shape_[0] % 2 == 0 and l.output_shape_[1] % 2 == 0) else None
+                if l.plan_fusion(pool):
+                    pool.folded = True
         return shape
 
     def forward(self, ctx, x):

@@ -87,6 +87,21 @@ def conv2d_wgrad(g: ConvGeom, x, dz, dw, accumulate: bool, ws: torch.Tensor):
                               ws.numel(), F32, _stream()), "sv_conv2d_wgrad")
 
 
+def conv2d_fused_supported(g: ConvGeom, pooled: bool) -> bool:
+    return bool(lib.sv_conv2d_fused_supported(C.byref(g), int(pooled)))
+
+
+def conv2d_pool_fwd(g: ConvGeom, x, w, bias, y_pooled, idx, act: str, alpha: float):
+    check(lib.sv_conv2d_pool_fwd(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y_pooled), _ptr(idx, torch.uint8),
+                                 ACT[act], alpha, F32, _stream()), "sv_conv2d_pool_fwd")
+
+
+def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float, ws: torch.Tensor):
+    check(lib.sv_conv2d_bwd(C.byref(g), _ptr(x), _ptr(w), _ptr(dy), _ptr(y), _ptr(idx, torch.uint8), _ptr(dx), _ptr(dw),
+                            _ptr(db), ACT[act], alpha, _ptr(ws, torch.uint8), ws.numel(), F32, _stream()),
+          "sv_conv2d_bwd")
+
+
 def conv2d_transpose_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float):
     check(lib.sv_conv2d_transpose_fwd(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha, F32,
                                       _stream()), "sv_conv2d_transpose_fwd")

@@ -131,12 +131,19 @@ def test_caepadded_per_layer_activations():
     ctx = model._calls[-1]
     taps = {}
     ref(torch.from_numpy(x), training=True, taps=taps)
-    ref_convs = [taps[i].detach().numpy() for i, l in enumerate(ref.layers) if l["type"] == "conv2d"]
-    hip_convs = [ctx.saved[id(l)]["y"].cpu().numpy() for l in model.encoder.layers + model.decoder.layers
-                 if isinstance(l, Conv2D)]
-    assert len(ref_convs) == len(hip_convs) == 6
-    for i, (a, b) in enumerate(zip(hip_convs, ref_convs)):
-        assert rel(a, b) <= 1e-4, f"conv {i}"
+    # a conv whose 2x2 max-pool is fused into its epilogue saves the POOLED activation: compare with the
+    # oracle's pooling output there, with the conv output elsewhere
+    ref_outs = []
+    for i, l in enumerate(ref.layers):
+        if l["type"] == "conv2d":
+            pooled_next = i + 1 < len(ref.layers) and ref.layers[i + 1]["type"] == "maxpool"
+            ref_outs.append((taps[i].detach().numpy(), taps[i + 1].detach().numpy() if pooled_next else None))
+    hip_convs = [l for l in model.encoder.layers + model.decoder.layers if isinstance(l, Conv2D)]
+    assert len(ref_outs) == len(hip_convs) == 6
+    assert [l.pool is not None for l in hip_convs] == [True, True, True, False, False, False]
+    for i, (l, (full, pooled)) in enumerate(zip(hip_convs, ref_outs)):
+        got = ctx.saved[id(l)]["y"].cpu().numpy()
+        assert rel(got, pooled if l.pool is not None else full) <= 1e-4, f"conv {i}"
     model._calls.clear()
 
 

@@ -120,6 +120,64 @@ def test_conv2d_folded_upsampling(up):
     close(dw, dw_o, what="wgrad")
 
 
+@pytest.mark.parametrize("cfg", [
+    # (K, H, W, Cin, Cout, up, pooled, act, N)
+    (3, 32, 32, 3, 8, 1, True, "elu", 5), (3, 16, 16, 8, 16, 1, True, "elu", 9), (3, 8, 8, 16, 32, 1, True, "relu", 7),
+    (3, 4, 4, 32, 16, 2, False, "elu", 11), (3, 8, 8, 16, 8, 2, False, "elu", 6), (3, 16, 16, 8, 3, 2, False, "tanh", 3),
+    (5, 16, 16, 16, 16, 1, True, "relu", 4), (5, 8, 8, 32, 16, 2, False, "elu", 5), (3, 32, 32, 16, 16, 1, False, None, 2),
+    (3, 4, 4, 128, 128, 1, True, "elu", 3), (5, 2, 2, 64, 128, 2, False, "relu", 2), (3, 6, 12, 5, 7, 1, True, "sigmoid", 3),
+])
+def test_conv2d_fused_pool_fwd_and_fused_bwd(cfg):
+    """conv+act+maxpool in one pass and the whole layer backward in the fused kernels, against the oracle chain
+    conv -> act -> maxpool (forward) and maxpool_bwd -> act' -> conv grads (backward)."""
+    from spectrum_vae_amd import ops
+    K, h, w, cin, cout, up, pooled, act, n = cfg
+    rng = np.random.default_rng(zlib.crc32(repr(cfg).encode()))
+    x = rng.standard_normal((n, h, w, cin))
+    k = rng.standard_normal((K, K, cin, cout)) * (0.5 / np.sqrt(K * K * cin))
+    b = rng.standard_normal(cout) * 0.1
+    H, W = h * up, w * up
+    g = ops.conv_geom(n, H, W, cin, K, K, 1, 1, "same", cout, (up, up))
+    assert ops.conv2d_fused_supported(g, pooled)
+    xu = np_ops.upsample2d(x, (up, up)) if up > 1 else x
+    z = np_ops.conv2d(xu, k, b, (1, 1), "same")
+    a = np_ops.act_fwd(z, act)
+    xd, kd, bd = dev(x), dev(k), dev(b)
+    if pooled:
+        y_o, arg_o = np_ops.maxpool2d(a, (2, 2), "valid")
+        y = torch.empty(y_o.shape, device="cuda")
+        idx = torch.empty(y_o.shape, dtype=torch.uint8, device="cuda")
+        ops.conv2d_pool_fwd(g, xd, kd, bd, y, idx, act, 1.0)
+        close(y, y_o, what="pooled fwd")
+        # argmax may legitimately differ only where two window entries tie to float32 precision
+        same = idx.cpu().numpy().astype(np.int64) == arg_o
+        assert same.mean() > 0.999
+        arg = idx.cpu().numpy().astype(np.int64)
+    else:
+        y_o, arg = a, None
+        y = torch.empty(y_o.shape, device="cuda")
+        ops.conv2d_fwd(g, xd, kd, bd, y, act, 1.0)
+        close(y, y_o, what="fwd")
+        idx = None
+    dy = rng.standard_normal(y_o.shape)
+    g_act = dy * np_ops.act_bwd_from_output(y_o, act)
+    dz = np_ops.maxpool2d_bwd(g_act, arg, a.shape, (2, 2), "valid") if pooled else g_act
+    dxu, dw_o, db_o = np_ops.conv2d_grads(xu, k, dz, (1, 1), "same")
+    dx_o = np_ops.upsample2d_bwd(dxu, (up, up)) if up > 1 else dxu
+    ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device="cuda")
+    dx = torch.empty(x.shape, device="cuda")
+    dw = torch.ones((K, K, cin, cout), device="cuda")
+    db = torch.ones(cout, device="cuda")
+    ops.conv2d_bwd(g, xd, kd, dev(dy), dev(y_o), idx, dx, dw, db, act, 1.0, ws)
+    close(dx, dx_o, what="fused dx")
+    close(dw, 1.0 + dw_o, what="fused dw (accumulating)")
+    close(db, 1.0 + db_o, what="fused db (accumulating)")
+    # without dx and without bias
+    dw2 = torch.zeros((K, K, cin, cout), device="cuda")
+    ops.conv2d_bwd(g, xd, kd, dev(dy), dev(y_o), idx, None, dw2, None, act, 1.0, ws)
+    close(dw2, dw_o, what="fused dw only")
+
+
 @pytest.mark.parametrize("act", ["relu", "elu", "lrelu", "tanh", "sigmoid"])
 @pytest.mark.parametrize("shape", [(1000, 8), (37, 3), (5, 300), (4096, 64)])
 def test_act_fwd_bwd_bias(act, shape):
