@@ -70,7 +70,9 @@ int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* 
  *  sv_conv2d_bwd: whole backward of one conv layer.  dz = dy * act'(y) is formed on the fly from the saved
  *      activation OUTPUT y; with idx != NULL, dy / y / idx are at the pooled resolution and dz is that product
  *      placed at each window's argmax, zero elsewhere.  dw += kernel gradient, db += sum(dz) (db may be NULL),
- *      dx = input gradient (skipped when dx == NULL).  workspace: sv_conv2d_wgrad_workspace_bytes(g). */
+ *      dx = input gradient.  Either half is skipped when its output pointer is NULL (dw == NULL: input gradient
+ *      only; dx == NULL: weight gradients only), so the two halves can be issued on different streams.
+ *      workspace (needed when dw != NULL): sv_conv2d_wgrad_workspace_bytes(g). */
 int sv_conv2d_fused_supported(const sv_conv_geom* g, int pooled);
 int sv_conv2d_pool_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y_pooled,
                        uint8_t* idx, int act, float alpha, int dtype, sv_stream_t stream);

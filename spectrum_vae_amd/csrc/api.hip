@@ -133,14 +133,18 @@ int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const voi
     SV_F32_ONLY(dtype, "sv_conv2d_bwd");
     int rc = validate_geom(g, "sv_conv2d_bwd");
     if (rc) return rc;
-    SV_REQUIRE(x && w && dy && y && dw, "sv_conv2d_bwd: null tensor");
+    SV_REQUIRE(w && dy && y, "sv_conv2d_bwd: null tensor");
+    SV_REQUIRE(dw != nullptr || dx != nullptr, "sv_conv2d_bwd: nothing to compute (dw and dx are both NULL)");
+    SV_REQUIRE(dw == nullptr || x != nullptr, "sv_conv2d_bwd: the kernel gradient needs x");
     const int pooled = idx != nullptr;
     SV_REQUIRE(sv_conv2d_fused_supported(g, pooled), "sv_conv2d_bwd: shape is outside the fused family");
     const int zmode = pooled ? 2 : 1;
-    rc = launch_tiled_wgrad((const float*)x, (const float*)dy, (float*)dw, (float*)db, 1, workspace, workspace_bytes,
-                            g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, to_stream(stream),
-                            zmode, (const float*)y, idx, act, alpha);
-    if (rc) return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: shape not covered") : rc;
+    if (dw != nullptr) {
+        rc = launch_tiled_wgrad((const float*)x, (const float*)dy, (float*)dw, (float*)db, 1, workspace,
+                                workspace_bytes, g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h,
+                                to_stream(stream), zmode, (const float*)y, idx, act, alpha);
+        if (rc) return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: shape not covered") : rc;
+    }
     if (dx == nullptr) return SV_OK;
     rc = launch_tiled_s1((const float*)dy, (const float*)w, nullptr, (float*)dx, nullptr, g->N, g->H, g->W, g->Cout,
                          g->Cin, g->KH, 1, 1, g->up_h == 2 ? 2 : 0, SV_ACT_NONE, 0.f, to_stream(stream), zmode,

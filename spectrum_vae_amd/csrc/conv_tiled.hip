@@ -45,6 +45,7 @@ struct TiledArgs {
     int zmode;
     ActGradCoef zk;
     int lgW, lgH;  // log2 of Ws / Hs when they are powers of two, else -1
+    int ks;        // input channels of one output tile are split over ks adjacent lanes (1, 2 or 4) and summed by shuffles
 };
 
 // n / d and n % d for a divisor that is usually a power of two (image extents, channel counts): lg >= 0 selects
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
     const int coc = min(a.coc, a.Cout - co_base);  // channels this block really owns
     const int n_cot = (coc + CO_T - 1) / CO_T;
     const int cop = n_cot * CO_T;
-    const int per_cot = a.S * T;                   // work items per channel tile in one pass
+    const int ks = a.ks;
+    const int per_cot = a.S * T * ks;              // work items per channel tile in one pass
     const int total = n_cot * per_cot;
     const bool one_chunk = a.cic >= a.Cin;
 
@@ -167,10 +169,12 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
         for (int item0 = 0; item0 < total; item0 += nt) {
             const int item = item0 + threadIdx.x;
             const bool live = item < total;
-            int cot = 0, s = 0, ty = 0, tx = 0;
+            int cot = 0, s = 0, ty = 0, tx = 0, kl = 0;
             if (live) {
                 cot = item / per_cot;
-                const int r = item - cot * per_cot;
+                int r = item - cot * per_cot;
+                kl = r % ks;  // which slice of the input channels this lane sums
+                r /= ks;
                 s = r / T;
                 const int t = r - s * T;
                 ty = t / tiles_x;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
                     const int r0 = (UP == 1 ? 2 * ty : ty) + a.halo + floordiv_c(-PADL, UP);
                     const int c0 = (UP == 1 ? 2 * tx : tx) + a.halo + floordiv_c(-PADL, UP);
                     const float* wbase = w_lds + cot * CO_T;
-                    for (int c = 0; c < cic; ++c) {
+                    for (int c = kl; c < cic; c += ks) {
                         float patch[NPR][NPR + 1];
                         const float* pl = img + c * a.plane + r0 * a.wp + c0;
 #pragma unroll
@@ -237,8 +241,17 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
                     }
                 }
             }
+            // ---- fold the ks channel slices (adjacent lanes of one wave; dead lanes hold zeros)
+            for (int o = 1; o < ks; o <<= 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < CO_T; ++q) acc[i][j][q] += __shfl_xor(acc[i][j][q], o, 64);
+            }
             // ---- epilogue
-            if (work) {
+            if (work && kl == 0) {
                 const int n = n0 + s;
                 const int cg = co_base + cot * CO_T;  // first global output channel of this thread
                 if (EPI == EPI_STORE) {
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
 // ------------------------------------------------------------------------------------------------ host side
 struct TiledPlan {
     bool ok;
-    int S, cic, coc, plane, wp, halo, co_t, nt;
+    int S, cic, coc, plane, wp, halo, co_t, nt, ks;
     size_t lds_bytes;
     dim3 grid;
 };
@@ -330,17 +343,20 @@ TiledPlan plan_tiled(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     while (cic > 1 && bytes(1, cic, coc) > kLdsBudget) cic = (cic + 1) / 2;
     if (bytes(1, cic, coc) > kLdsBudget) return p;
     const int n_cot = coc / p.co_t;
-    // One pass should hold ~256 work items; small layers take several samples per pass, but never so few passes
-    // that the grid cannot cover the chip (>= ~3 blocks per CU): then the block shrinks to 128 or 64 threads.
-    const int items1 = T * n_cot;  // items of one sample
-    int S = items1 >= 256 ? 1 : 256 / items1;
     const int ny = (Cout + coc - 1) / coc;
-    while (S > 1 && (int64_t)((N + S - 1) / S) * ny < 768) S >>= 1;
+    // Parallelism first: the launch should put >= 2 waves on every SIMD (2048 waves on the chip).  When the
+    // output tiles alone are too few (small images), each tile's input channels are split over 2 or 4 lanes.
+    int ks = 1;
+    while (ks < 4 && cic / (2 * ks) >= 4 && (int64_t)N * T * n_cot * ny * ks < 2048 * 64) ks <<= 1;
+    // A pass holds ~256 work items; small layers take several samples per pass.
+    const int items1 = T * n_cot * ks;  // items of one sample
+    int S = items1 >= 256 ? 1 : 256 / items1;
     while (S > 1 && bytes(S, cic, coc) > kLdsBudget) --S;
     if (S > N) S = N;
     int nt = 256;
     while (nt > 64 && S * items1 <= nt / 2) nt >>= 1;
     p.nt = nt;
+    p.ks = ks;
     p.S = S;
     p.cic = cic;
     p.coc = coc;
@@ -394,7 +410,7 @@ int launch_tiled_s1(const float* x, const float* w, const float* bias, float* y,
     a.wflip = wflip; a.act = act; a.alpha = alpha;
     a.S = p.S; a.cic = p.cic; a.coc = p.coc; a.plane = p.plane; a.wp = p.wp; a.halo = p.halo;
     a.zmode = zmode; a.zy = zy; a.zidx = zidx; a.zk = act_grad_coef(zact, zalpha);
-    a.lgW = ilog2_exact(Ws); a.lgH = ilog2_exact(Hs);
+    a.lgW = ilog2_exact(Ws); a.lgH = ilog2_exact(Hs); a.ks = p.ks;
     if (K == 3) return UP == 1 ? launch_cot<3, 1>(a, epi, p, st) : launch_cot<3, 2>(a, epi, p, st);
     return UP == 1 ? launch_cot<5, 1>(a, epi, p, st) : launch_cot<5, 2>(a, epi, p, st);
 }

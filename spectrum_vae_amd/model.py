@@ -77,6 +77,10 @@ class Model(Layer):
         self._reducer = None  # data-parallel gradient reducer (parallel.GradReducer)
         self._graphs: Dict[tuple, object] = {}
         self.use_graphs = True
+        # Run the weight-gradient kernels, the gradient zero-fill and the optimizer's schedule update on a second
+        # HIP stream beside the forward / input-gradient chain (fit / train_on_device_batch only).
+        self.use_side_stream = True
+        self._side: Optional[torch.cuda.Stream] = None
         self.stop_training = False
 
     # ------------------------------------------------------------------ structure
@@ -221,10 +225,12 @@ class Model(Layer):
     def call(self, x, training: bool = False):
         return self.__call__(x, training=training)
 
-    def forward_raw(self, x: torch.Tensor, training: bool) -> torch.Tensor:
-        """Forward on a prepared device tensor; the result aliases the model's buffer pool."""
+    def forward_raw(self, x: torch.Tensor, training: bool, side=None) -> torch.Tensor:
+        """Forward on a prepared device tensor; the result aliases the model's buffer pool.  ``side``: stream
+        the backward pass of this call may use for its weight-gradient kernels (the caller joins it)."""
         if training:
             ctx = CallCtx(self._pool, len(self._calls), True)
+            ctx.side = side
             self._calls.append(ctx)
         else:
             ctx = CallCtx(self._pool, "infer", False)
@@ -279,21 +285,53 @@ class Model(Layer):
             "acc": p.get(("fit", "acc"), (1,)),
         }
 
-    def _fwd_bwd(self, b: dict, same_xy: bool, weight: float):
-        """zero grads -> forward -> loss (+dL/dpred) -> backward, all enqueued on the current stream."""
-        self.zero_grad_raw()
-        pred = self.forward_raw(b["x"], True)
+    def _side_stream(self):
+        if not self.use_side_stream or not self._params.is_cuda:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self._params.device)
+        return self._side
+
+    def _fwd_bwd(self, b: dict, same_xy: bool, weight: float, prepare_opt: bool = False):
+        """zero grads -> forward -> loss (+dL/dpred) -> backward, enqueued on the current stream, with the
+        work that is off the critical path (zero-fill, schedule update, weight gradients) forked onto the
+        side stream and joined before returning."""
+        side = self._side_stream()
+        if side is None:
+            self.zero_grad_raw()
+            if prepare_opt:
+                self.optimizer.prepare(self._params.device)
+        else:
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            zeroed = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                self.zero_grad_raw()
+                zeroed.record(side)
+                if prepare_opt:
+                    self.optimizer.prepare(self._params.device)
+        pred = self.forward_raw(b["x"], True, side)
         yt = b["x"] if same_xy else b["y"]
         self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0)
         ops.axpy(b["acc"], b["loss"], weight)
+        if side is not None:
+            main.wait_event(zeroed)
         self.backward_raw(b["dpred"], -1, need_dx=False)
+        if side is not None:
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
         self._calls.clear()
 
     def _train_step_body(self, b: dict, same_xy: bool, weight: float):
+        if self._reducer is None:
+            self._fwd_bwd(b, same_xy, weight, prepare_opt=True)
+            self.optimizer.apply_model(self, 1.0, prepared=True)
+            return
         self._fwd_bwd(b, same_xy, weight)
-        scale = 1.0
-        if self._reducer is not None:
-            scale = self._reducer.all_reduce(self._grads)
+        scale = self._reducer.all_reduce(self._grads)
         self.optimizer.apply_model(self, scale)
 
     def zero_grad_raw(self):

@@ -115,6 +115,7 @@ class BufferPool:
     def __init__(self):
         self.bufs: Dict[tuple, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
+        self._ws_side: Optional[torch.Tensor] = None
         self.device: Optional[torch.device] = None
 
     def get(self, key, shape, dtype=torch.float32) -> torch.Tensor:
@@ -132,6 +133,13 @@ class BufferPool:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def workspace_side(self, nbytes: int) -> torch.Tensor:
+        """Scratch of the kernels issued on the side stream (weight-gradient branch of the backward pass)."""
+        nbytes = max(int(nbytes), 256)
+        if self._ws_side is None or self._ws_side.numel() < nbytes:
+            self._ws_side = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws_side
+
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
@@ -147,6 +155,9 @@ class CallCtx:
         # False: backward only propagates to the inputs (a generator's gradient THROUGH a discriminator);
         # weight/bias gradients are skipped, BatchNorm's go to scratch.
         self.param_grads = True
+        # Second HIP stream for the weight-gradient kernels: they only feed the optimizer, so they run beside the
+        # input-gradient chain instead of in it.  The owner joins the stream before the optimizer step.
+        self.side: Optional[torch.cuda.Stream] = None
 
     def buf(self, layer, role, shape, dtype=torch.float32):
         return self.pool.get((id(layer), role, self.slot), shape, dtype)
@@ -334,9 +345,21 @@ class _ConvBase(Layer):
         ho, wo, cout = self.output_shape_
         if self.fused_bwd and ctx.param_grads:
             dx = ctx.buf(self, "dx", tuple(x.shape)) if need_dx else None
-            ws = ctx.pool.workspace(ops.conv2d_wgrad_workspace(g))
-            ops.conv2d_bwd(g, x, self.kernel.data, dy, y, s.get("idx"), dx, self.kernel.grad,
-                           self.bias.grad if self.bias is not None else None, self.act, self.alpha, ws)
+            db = self.bias.grad if self.bias is not None else None
+            if ctx.side is None or not need_dx:
+                ws = ctx.pool.workspace(ops.conv2d_wgrad_workspace(g))
+                ops.conv2d_bwd(g, x, self.kernel.data, dy, y, s.get("idx"), dx, self.kernel.grad, db, self.act,
+                               self.alpha, ws)
+                return dx
+            # weight gradients on the side stream (after dy is complete), input gradient on the main stream
+            ready = torch.cuda.Event()
+            ready.record()
+            ws = ctx.pool.workspace_side(ops.conv2d_wgrad_workspace(g))
+            with torch.cuda.stream(ctx.side):
+                ctx.side.wait_event(ready)
+                ops.conv2d_bwd(g, x, self.kernel.data, dy, y, s.get("idx"), None, self.kernel.grad, db, self.act,
+                               self.alpha, ws)
+            ops.conv2d_bwd(g, None, self.kernel.data, dy, y, s.get("idx"), dx, None, None, self.act, self.alpha, None)
             return dx
         if self.pool is not None:
             # unfused backward of a fused conv+pool forward: expand the pooled gradient first

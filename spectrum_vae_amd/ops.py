@@ -96,10 +96,10 @@ def conv2d_pool_fwd(g: ConvGeom, x, w, bias, y_pooled, idx, act: str, alpha: flo
                                  ACT[act], alpha, F32, _stream()), "sv_conv2d_pool_fwd")
 
 
-def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float, ws: torch.Tensor):
+def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float, ws: Optional[torch.Tensor]):
     check(lib.sv_conv2d_bwd(C.byref(g), _ptr(x), _ptr(w), _ptr(dy), _ptr(y), _ptr(idx, torch.uint8), _ptr(dx), _ptr(dw),
-                            _ptr(db), ACT[act], alpha, _ptr(ws, torch.uint8), ws.numel(), F32, _stream()),
-          "sv_conv2d_bwd")
+                            _ptr(db), ACT[act], alpha, _ptr(ws, torch.uint8) if ws is not None else None,
+                            ws.numel() if ws is not None else 0, F32, _stream()), "sv_conv2d_bwd")
 
 
 def conv2d_transpose_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float):

@@ -75,9 +75,14 @@ class Adam:
                          sc.decay_rate if sc else 1.0, sc.staircase if sc else False)
         return st
 
+    def prepare(self, device):
+        """Advance the update counter and refresh the step size on the current stream; the matching
+        ``apply_model(..., prepared=True)`` then only runs the parameter update."""
+        self._prepare(device)
+
     # ---- the fused path: one launch over the model's whole flat parameter buffer
-    def apply_model(self, model, grad_scale: float = 1.0):
-        st = self._prepare(model._params.device)
+    def apply_model(self, model, grad_scale: float = 1.0, prepared: bool = False):
+        st = self._ensure_state(model._params.device) if prepared else self._prepare(model._params.device)
         m, v = self._slots_for(model)
         ops.adam_apply(model._params, model._grads, m, v, st, self.beta_1, self.beta_2, self.epsilon, grad_scale)
 
