@@ -77,10 +77,13 @@ class Model(Layer):
         self._reducer = None  # data-parallel gradient reducer (parallel.GradReducer)
         self._graphs: Dict[tuple, object] = {}
         self.use_graphs = True
-        # Run the weight-gradient kernels, the gradient zero-fill and the optimizer's schedule update on a second
-        # HIP stream beside the forward / input-gradient chain (fit / train_on_device_batch only).
-        self.use_side_stream = True
-        self._side: Optional[torch.cuda.Stream] = None
+        # Optional: run the weight-gradient kernels, the gradient zero-fill and the optimizer's schedule update on
+        # extra HIP streams beside the forward / input-gradient chain (fit / train_on_device_batch only).  Off by
+        # default: at the shapes measured so far every conv launch already occupies the LDS of all CUs, so the
+        # branches do not overlap and the extra dependencies only add latency.
+        self.use_side_stream = False
+        self.n_side_streams = 3
+        self._side: Optional[List[torch.cuda.Stream]] = None
         self.stop_training = False
 
     # ------------------------------------------------------------------ structure
@@ -289,7 +292,7 @@ class Model(Layer):
         if not self.use_side_stream or not self._params.is_cuda:
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self._params.device)
+            self._side = [torch.cuda.Stream(device=self._params.device) for _ in range(self.n_side_streams)]
         return self._side
 
     def _fwd_bwd(self, b: dict, same_xy: bool, weight: float, prepare_opt: bool = False):
@@ -306,12 +309,16 @@ class Model(Layer):
             fork = torch.cuda.Event()
             fork.record(main)
             zeroed = torch.cuda.Event()
-            with torch.cuda.stream(side):
-                side.wait_event(fork)
-                self.zero_grad_raw()
-                zeroed.record(side)
-                if prepare_opt:
-                    self.optimizer.prepare(self._params.device)
+            for i, sd in enumerate(side):
+                with torch.cuda.stream(sd):
+                    sd.wait_event(fork)
+                    if i == 0:
+                        self.zero_grad_raw()
+                        zeroed.record(sd)
+                        if prepare_opt:
+                            self.optimizer.prepare(self._params.device)
+                    else:
+                        sd.wait_event(zeroed)
         pred = self.forward_raw(b["x"], True, side)
         yt = b["x"] if same_xy else b["y"]
         self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0)
@@ -320,9 +327,10 @@ class Model(Layer):
             main.wait_event(zeroed)
         self.backward_raw(b["dpred"], -1, need_dx=False)
         if side is not None:
-            done = torch.cuda.Event()
-            done.record(side)
-            main.wait_event(done)
+            for sd in side:
+                done = torch.cuda.Event()
+                done.record(sd)
+                main.wait_event(done)
         self._calls.clear()
 
     def _train_step_body(self, b: dict, same_xy: bool, weight: float):

@@ -115,7 +115,8 @@ class BufferPool:
     def __init__(self):
         self.bufs: Dict[tuple, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
-        self._ws_side: Optional[torch.Tensor] = None
+        self._ws_side: Dict[int, torch.Tensor] = {}
+        self._retired: List[torch.Tensor] = []
         self.device: Optional[torch.device] = None
 
     def get(self, key, shape, dtype=torch.float32) -> torch.Tensor:
@@ -133,12 +134,15 @@ class BufferPool:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def workspace_side(self, nbytes: int) -> torch.Tensor:
-        """Scratch of the kernels issued on the side stream (weight-gradient branch of the backward pass)."""
+    def workspace_side(self, lane: int, nbytes: int) -> torch.Tensor:
+        """Scratch of the kernels issued on side stream ``lane`` (weight-gradient branch of the backward pass)."""
         nbytes = max(int(nbytes), 256)
-        if self._ws_side is None or self._ws_side.numel() < nbytes:
-            self._ws_side = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws_side
+        cur = self._ws_side.get(lane)
+        if cur is None or cur.numel() < nbytes:
+            if cur is not None:  # may still be in use by queued side-stream kernels: keep it alive
+                self._retired.append(cur)
+            cur = self._ws_side[lane] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return cur
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
@@ -155,9 +159,11 @@ class CallCtx:
         # False: backward only propagates to the inputs (a generator's gradient THROUGH a discriminator);
         # weight/bias gradients are skipped, BatchNorm's go to scratch.
         self.param_grads = True
-        # Second HIP stream for the weight-gradient kernels: they only feed the optimizer, so they run beside the
-        # input-gradient chain instead of in it.  The owner joins the stream before the optimizer step.
-        self.side: Optional[torch.cuda.Stream] = None
+        # Extra HIP streams for the weight-gradient kernels: they only feed the optimizer, so they run beside the
+        # input-gradient chain (and beside each other, round-robin) instead of in it.  The owner joins the
+        # streams before the optimizer step.
+        self.side: Optional[List[torch.cuda.Stream]] = None
+        self.side_rr = 0
 
     def buf(self, layer, role, shape, dtype=torch.float32):
         return self.pool.get((id(layer), role, self.slot), shape, dtype)
@@ -346,7 +352,7 @@ class _ConvBase(Layer):
         if self.fused_bwd and ctx.param_grads:
             dx = ctx.buf(self, "dx", tuple(x.shape)) if need_dx else None
             db = self.bias.grad if self.bias is not None else None
-            if ctx.side is None or not need_dx:
+            if not ctx.side or not need_dx:
                 ws = ctx.pool.workspace(ops.conv2d_wgrad_workspace(g))
                 ops.conv2d_bwd(g, x, self.kernel.data, dy, y, s.get("idx"), dx, self.kernel.grad, db, self.act,
                                self.alpha, ws)
@@ -354,9 +360,12 @@ class _ConvBase(Layer):
             # weight gradients on the side stream (after dy is complete), input gradient on the main stream
             ready = torch.cuda.Event()
             ready.record()
-            ws = ctx.pool.workspace_side(ops.conv2d_wgrad_workspace(g))
-            with torch.cuda.stream(ctx.side):
-                ctx.side.wait_event(ready)
+            lane = ctx.side_rr % len(ctx.side)
+            ctx.side_rr += 1
+            side = ctx.side[lane]
+            ws = ctx.pool.workspace_side(lane, ops.conv2d_wgrad_workspace(g))
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
                 ops.conv2d_bwd(g, x, self.kernel.data, dy, y, s.get("idx"), None, self.kernel.grad, db, self.act,
                                self.alpha, ws)
             ops.conv2d_bwd(g, None, self.kernel.data, dy, y, s.get("idx"), dx, None, None, self.act, self.alpha, None)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/profile_round.sh <tag>
+# 1) kernel-trace statistics of the default bench command, 2) + 3) HBM traffic counters in passes of their own.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+tag=$1
+out=gpurun_out/profile_$tag
+mkdir -p $out/trace $out/fetch $out/write
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_under_trace.json 2> $out/trace_err.log || { echo trace failed; exit 1; }
+cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > $out/fetch_out.json 2> $out/fetch_err.log || { echo fetch pass failed; exit 1; }
+cp $(find $out/fetch -name "*counter_collection.csv" | head -1) $out/fetch.csv
+timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > $out/write_out.json 2> $out/write_err.log || { echo write pass failed; exit 1; }
+cp $(find $out/write -name "*counter_collection.csv" | head -1) $out/write.csv
+python3 - <<PY
+import csv, collections, json
+def agg(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if 'sv::' in r['Kernel_Name']:
+            d[(r['Kernel_Name'], r['Grid_Size'] if 'Grid_Size' in r else r.get('Grid_Size_X', ''))].append(float(r['Counter_Value']))
+    return {f"{k[0]} | grid {k[1]}": sum(v) / len(v) for k, v in d.items()}
+res = {"FETCH_SIZE_raw_avg_per_launch": agg("$out/fetch.csv"), "WRITE_SIZE_raw_avg_per_launch": agg("$out/write.csv")}
+json.dump(res, open("$out/traffic_raw.json", "w"), indent=1)
+for k, v in res.items():
+    print(k)
+    for n, x in sorted(v.items(), key=lambda t: -t[1])[:14]:
+        print(f"  {x:12.1f}  {n[:110]}")
+PY
+rm -rf $out/trace $out/fetch $out/write
+head -14 $out/kernel_stats.csv | cut -c1-160
