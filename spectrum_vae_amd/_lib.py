@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspectrum_hip.so")
+# SPECTRUM_HIP_LIB selects another build of the same library (the diagnostic trace build)
+LIB_PATH = os.environ.get("SPECTRUM_HIP_LIB") or os.path.join(_HERE, "libspectrum_hip.so")
 
 ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "elu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5}
 F32, BF16 = 0, 1

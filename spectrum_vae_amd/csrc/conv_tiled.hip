@@ -20,6 +20,23 @@ namespace sv {
 
 enum { EPI_STORE = 0, EPI_MAXPOOL = 1, EPI_SUM4 = 2 };
 
+// Phase timestamps for kernel tuning (diagnostic builds only: make TRACE=1).  Thread 0 of every workgroup stores
+// the 100 MHz wall clock at up to 8 phase marks into g_sv_trace[block][8] (slot 7: hardware id).
+#ifdef SV_TRACE
+__device__ unsigned long long* g_sv_trace = nullptr;
+__device__ __forceinline__ void trace_mark(int slot) {
+    if (threadIdx.x == 0 && g_sv_trace != nullptr) {
+        const size_t b = (size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        g_sv_trace[b * 8 + slot] = wall_clock64();
+        if (slot == 0) g_sv_trace[b * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                                                 ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
+    }
+}
+#define SV_MARK(slot) trace_mark(slot)
+#else
+#define SV_MARK(slot)
+#endif
+
 struct TiledArgs {
     const float* x;     // [N][Hs][Ws][Cin]   stored input (for WFLIP: dz)
     const float* w;     // HWIO [K][K][Cw_in][Cw_out] as stored by the layer
@@ -44,13 +61,13 @@ struct TiledArgs {
     const uint8_t* zidx;
     int zmode;
     ActGradCoef zk;
-    int lgW, lgH;  // log2 of Ws / Hs when they are powers of two, else -1
     int ks;        // input channels of one output tile are split over ks adjacent lanes (1, 2 or 4) and summed by shuffles
+    int epi_lds;   // 1: outputs leave through an LDS tile [sample][pixel][out_cs] as coalesced stores
+    int out_cs;    // floats per pixel of that tile
 };
 
-// n / d and n % d for a divisor that is usually a power of two (image extents, channel counts): lg >= 0 selects
-// the shift form, lg < 0 the general division.
-__device__ __forceinline__ int fdiv(int n, int d, int lg) { return lg >= 0 ? (n >> lg) : n / d; }
+// n / d for a divisor that is usually a power of two (image extents, channel counts).
+__device__ __forceinline__ int dv(int n, int d) { return (d & (d - 1)) == 0 ? (n >> (31 - __clz(d))) : n / d; }
 inline int ilog2_exact(int v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctz(v) : -1; }
 
 __host__ __device__ constexpr int floordiv_c(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -59,87 +76,216 @@ __host__ __device__ constexpr int floordiv_c(int a, int b) { return (a >= 0) ? a
 template <int UP, int PADL>
 __host__ __device__ constexpr int patch_row(int q) { return floordiv_c(q - PADL, UP) - floordiv_c(-PADL, UP); }
 
-// ---- staging helpers (nt = threads in the block) -------------------------------------------------------------
-// Input chunk [ci0, ci0+cic) of samples [n0, n0+ns) -> planar LDS image inside the zero halo.
-__device__ __forceinline__ void stage_input(const TiledArgs& a, float* in_lds, int n0, int ns, int ci0, int cic,
-                                            int nt) {
-    const int Hs = a.Hs, Ws = a.Ws;
-    const int tid = threadIdx.x;
-    const int C4 = cic >> 2;
-    const bool vec = (cic & 3) == 0 && (a.Cin & 3) == 0 && C4 > 0 && (C4 & (C4 - 1)) == 0 && C4 <= nt;
-    if (a.zmode != 2) {
-        if (vec) {  // one float4 = 4 channels of one pixel
-            const int cl = tid & (C4 - 1), pl = tid / C4, PP = nt / C4;
-            const int HW = Hs * Ws;
-            for (int p = pl; p < ns * HW; p += PP) {
-                const int r = fdiv(p, Ws, a.lgW), col = p - r * Ws;
-                const int ss = fdiv(r, Hs, a.lgH), row = r - ss * Hs;
-                const size_t gi = ((size_t)n0 * HW + p) * a.Cin + ci0 + cl * 4;
-                float4 v = *reinterpret_cast<const float4*>(a.x + gi);
-                if (a.zmode == 1) {
-                    const float4 yv = *reinterpret_cast<const float4*>(a.zy + gi);
-                    v.x *= act_grad_q(yv.x, a.zk);
-                    v.y *= act_grad_q(yv.y, a.zk);
-                    v.z *= act_grad_q(yv.z, a.zk);
-                    v.w *= act_grad_q(yv.w, a.zk);
-                }
-                float* q = in_lds + (ss * a.cic + cl * 4) * a.plane + (row + a.halo) * a.wp + col + a.halo;
-                q[0] = v.x; q[a.plane] = v.y; q[2 * a.plane] = v.z; q[3 * a.plane] = v.w;
-            }
-        } else {
-            const int elems = Hs * Ws * cic;
-            for (int i = tid; i < ns * elems; i += nt) {
-                const int ss = i / elems;
-                const int e = i - ss * elems;
-                const int p = e / cic, c = e - p * cic;
-                const int row = p / Ws, col = p - row * Ws;
-                const size_t gi = (((size_t)(n0 + ss) * Hs + row) * Ws + col) * a.Cin + ci0 + c;
-                float v = a.x[gi];
-                if (a.zmode == 1) v *= act_grad_q(a.zy[gi], a.zk);
-                in_lds[(ss * a.cic + c) * a.plane + (row + a.halo) * a.wp + col + a.halo] = v;
+// ---- staging: NHWC tensor in global memory -> planar images in LDS ----------------------------------------------
+// A global round trip costs far more than the few instructions that consume it, so staging is split into a LOAD
+// phase that issues up to U independent 16-byte loads per thread into registers and a STORE phase that decodes
+// positions and writes LDS; callers put other work (LDS zero fill, the previous pass's arithmetic) between the two.
+struct PlanarSrc {
+    const float* x;       // [n][Hs][Ws][C]
+    const float* zy;      // mode 1/2: activation output the gradient is taken through
+    const uint8_t* zidx;  // mode 2: argmax slot (0..3) of each 2x2 window
+    // 0: x as is;  1: x * act'(zy);  2: x, zy, zidx live at half resolution and the value lands on the argmax slot of
+    // its 2x2 window of the LDS image (zeros on the other three);  3: x replicated to a 2x2 block (nearest upsampling)
+    int mode;
+    ActGradCoef zk;
+    int Hs, Ws, C;        // extents of the STORED tensor (mode 2: the pooled extents) and its channel count
+};
+struct PlanarDst {
+    int cpl;    // channel planes per sample in LDS
+    int plane;  // floats per plane
+    int wp;     // floats per row
+    int off;    // row/col offset of pixel (0,0) inside a plane (the zero halo)
+};
+struct StageJob {
+    int kind;   // 0: float4 = 4 channels of one pixel; 1: float4 = 4 consecutive floats of the contiguous pass; 2: scalars
+    int units;  // float4s (kind 0/1) or floats (kind 2) in this pass
+    int c0, cc, C4;
+    size_t base;  // element offset of sample n0
+};
+__device__ __forceinline__ StageJob make_stage_job(const PlanarSrc& s, int n0, int ns, int c0, int cc) {
+    StageJob j;
+    const int HW = s.Hs * s.Ws;
+    j.c0 = c0; j.cc = cc; j.C4 = cc >> 2;
+    j.base = (size_t)n0 * HW * s.C;
+    if ((cc & 3) == 0 && (s.C & 3) == 0 && (c0 & 3) == 0) {
+        j.kind = 0; j.units = ns * HW * j.C4;
+    } else if (c0 == 0 && cc == s.C && ((HW * s.C) & 3) == 0) {
+        j.kind = 1; j.units = (ns * HW * s.C) >> 2;
+    } else {
+        j.kind = 2; j.units = ns * HW * cc;
+    }
+    return j;
+}
+
+// n / d with the power-of-two decision taken at compile time (P2: d == 1 << lg), so staging loops are branch-free
+template <bool P2>
+__device__ __forceinline__ int dvt(int n, int d, int lg) { return P2 ? (n >> lg) : n / d; }
+__device__ __forceinline__ int lg2(int d) { return 31 - __clz(d); }
+__device__ __forceinline__ bool is_p2(int d) { return (d & (d - 1)) == 0; }
+
+// one staged value -> its place(s) in the LDS image of channel plane q0 (already offset to the sample and channel)
+template <int MODE>
+__device__ __forceinline__ void stage_put(const PlanarSrc& s, const PlanarDst& d, float* q0, int row, int col, float x,
+                                          float y, uint32_t k) {
+    if (MODE == 0) {
+        q0[(row + d.off) * d.wp + col + d.off] = x;
+    } else if (MODE == 1) {
+        q0[(row + d.off) * d.wp + col + d.off] = x * act_grad_q(y, s.zk);
+    } else if (MODE == 3) {
+        float* q = q0 + (2 * row + d.off) * d.wp + 2 * col + d.off;
+        q[0] = x; q[1] = x; q[d.wp] = x; q[d.wp + 1] = x;
+    } else {
+        const float v = x * act_grad_q(y, s.zk);
+        float* q = q0 + (2 * row + d.off) * d.wp + 2 * col + d.off;
+        q[0] = k == 0 ? v : 0.f; q[1] = k == 1 ? v : 0.f; q[d.wp] = k == 2 ? v : 0.f; q[d.wp + 1] = k == 3 ? v : 0.f;
+    }
+}
+
+// One pass: every thread walks its units with a stride of nt.  The loop bodies are branch-free and unrolled by 4 so
+// that the global loads of four units are issued before the first LDS write (a global round trip costs far more
+// than the instructions that consume it).
+template <int MODE, bool P2>
+__device__ __forceinline__ void stage_pass_t(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
+    const int HW = s.Hs * s.Ws;
+    const int lgHW = lg2(HW), lgW = lg2(s.Ws), lgC = lg2(s.C);
+    constexpr bool need_y = MODE == 1 || MODE == 2;
+    if (j.kind == 0) {
+        const int lgC4 = lg2(j.C4);
+#pragma unroll 4
+        for (int u = threadIdx.x; u < j.units; u += nt) {
+            const int p = dvt<P2>(u, j.C4, lgC4), cl = u - p * j.C4;
+            const size_t gi = j.base + (size_t)p * s.C + j.c0 + 4 * cl;
+            const float4 v = *reinterpret_cast<const float4*>(s.x + gi);
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t k = 0;
+            if (need_y) y = *reinterpret_cast<const float4*>(s.zy + gi);
+            if (MODE == 2) k = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
+            const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
+            const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
+            float* q = lds + (size_t)(ss * d.cpl + 4 * cl) * d.plane;
+            stage_put<MODE>(s, d, q, row, col, v.x, y.x, k & 0xff);
+            stage_put<MODE>(s, d, q + d.plane, row, col, v.y, y.y, (k >> 8) & 0xff);
+            stage_put<MODE>(s, d, q + 2 * d.plane, row, col, v.z, y.z, (k >> 16) & 0xff);
+            stage_put<MODE>(s, d, q + 3 * d.plane, row, col, v.w, y.w, k >> 24);
+        }
+    } else if (j.kind == 1) {
+#pragma unroll 4
+        for (int u = threadIdx.x; u < j.units; u += nt) {
+            const size_t gi = j.base + 4 * (size_t)u;
+            const float4 v = *reinterpret_cast<const float4*>(s.x + gi);
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t k = 0;
+            if (need_y) y = *reinterpret_cast<const float4*>(s.zy + gi);
+            if (MODE == 2) k = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            const float yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = 4 * u + t;
+                const int p = dvt<P2>(e, s.C, lgC), c = e - p * s.C;
+                const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
+                const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
+                stage_put<MODE>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, row, col, xv[t], yv[t], (k >> (8 * t)) & 0xff);
             }
         }
-    } else {  // pooled gradient: x, zy, zidx at (Hs/2, Ws/2); scatter to the argmax slot of each 2x2 window
-        const int Hq = Hs >> 1, Wq = Ws >> 1;
-        const int elems = Hq * Wq * cic;
-        for (int i = tid; i < ns * elems; i += nt) {
-            const int ss = i / elems;
-            const int e = i - ss * elems;
-            const int p = e / cic, c = e - p * cic;
-            const int row = p / Wq, col = p - row * Wq;
-            const size_t gi = (((size_t)(n0 + ss) * Hq + row) * Wq + col) * a.Cin + ci0 + c;
-            const float v = a.x[gi] * act_grad_q(a.zy[gi], a.zk);
-            const int k = a.zidx[gi];
-            float* q = in_lds + (ss * a.cic + c) * a.plane + (2 * row + a.halo) * a.wp + 2 * col + a.halo;
-            *reinterpret_cast<float2*>(q) = make_float2(k == 0 ? v : 0.f, k == 1 ? v : 0.f);
-            *reinterpret_cast<float2*>(q + a.wp) = make_float2(k == 2 ? v : 0.f, k == 3 ? v : 0.f);
+    } else {
+        const int lgcc = lg2(j.cc);
+#pragma unroll 4
+        for (int u = threadIdx.x; u < j.units; u += nt) {
+            const int p = dvt<P2>(u, j.cc, lgcc), c = u - p * j.cc;
+            const size_t gi = j.base + (size_t)p * s.C + j.c0 + c;
+            const float v = s.x[gi];
+            const float y = need_y ? s.zy[gi] : 0.f;
+            const uint32_t k = MODE == 2 ? s.zidx[gi] : 0u;
+            const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
+            const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
+            stage_put<MODE>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, row, col, v, y, k);
         }
     }
 }
 
-// Filter chunk -> w_lds[tap][c][cop] (cop = channel tiles * CO_T, zero padded).
-template <int K>
-__device__ __forceinline__ void stage_weights(const TiledArgs& a, float* w_lds, int ci0, int cic, int co_base, int coc,
-                                              int cop, int nt) {
-    const int cnt = K * K * cic * cop;
-    for (int i = threadIdx.x; i < cnt; i += nt) {
-        const int co = i % cop;
-        const int r = i / cop;
-        const int c = r % cic, tap = r / cic;
-        float v = 0.f;
-        if (co < coc) {
-            const int kh = tap / K, kw = tap - kh * K;
-            if (a.wflip)  // stored [K][K][Cout_launch][Cin_launch], taps mirrored
-                v = a.w[((size_t)((K - 1 - kh) * K + (K - 1 - kw)) * a.Cout + co_base + co) * a.Cin + ci0 + c];
-            else
-                v = a.w[((size_t)tap * a.Cin + ci0 + c) * a.Cout + co_base + co];
-        }
-        w_lds[(tap * a.cic + c) * cop + co] = v;
+template <int MODE>
+__device__ __forceinline__ void stage_pass_m(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
+    const bool p2 = is_p2(s.Hs * s.Ws) && is_p2(s.Ws) && is_p2(s.C) && is_p2(j.kind == 0 ? j.C4 : j.cc);
+    if (p2) stage_pass_t<MODE, true>(s, d, j, lds, nt);
+    else stage_pass_t<MODE, false>(s, d, j, lds, nt);
+}
+
+__device__ __forceinline__ void stage_pass(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
+    switch (s.mode) {
+        case 0: stage_pass_m<0>(s, d, j, lds, nt); break;
+        case 1: stage_pass_m<1>(s, d, j, lds, nt); break;
+        case 2: stage_pass_m<2>(s, d, j, lds, nt); break;
+        default: stage_pass_m<3>(s, d, j, lds, nt); break;
     }
+}
+
+// ---- filter chunk -> w_lds[tap][c][cop] (cop = channel tiles * CO_T; padded channels stay zero from the LDS fill)
+struct WJob {
+    int kind;  // 0: float4 over 4 output channels (plain layout); 1: float4 over 4 input channels (flipped); 2: scalars
+    int units;
+    int ci0, cic, co_base, coc, cop;
+};
+__device__ __forceinline__ WJob make_wjob(const TiledArgs& a, int ci0, int cic, int co_base, int coc, int cop, int K2) {
+    WJob j;
+    j.ci0 = ci0; j.cic = cic; j.co_base = co_base; j.coc = coc; j.cop = cop;
+    if (!a.wflip && (a.Cout & 3) == 0 && (coc & 3) == 0 && (co_base & 3) == 0) {
+        j.kind = 0; j.units = K2 * cic * (coc >> 2);
+    } else if (a.wflip && (a.Cin & 3) == 0 && (cic & 3) == 0 && (ci0 & 3) == 0) {
+        j.kind = 1; j.units = K2 * coc * (cic >> 2);
+    } else {
+        j.kind = 2; j.units = K2 * cic * coc;
+    }
+    return j;
+}
+template <int K, bool P2>
+__device__ __forceinline__ void w_pass_t(const TiledArgs& a, const WJob& j, float* w_lds, int nt) {
+    const int lgcic = lg2(j.cic), lgcoc = lg2(j.coc);
+    if (j.kind == 0) {
+        const int c4n = j.coc >> 2, lg4 = lg2(c4n);
+#pragma unroll 4
+        for (int u = threadIdx.x; u < j.units; u += nt) {
+            const int r = dvt<P2>(u, c4n, lg4), co4 = u - r * c4n;
+            const int tap = dvt<P2>(r, j.cic, lgcic), c = r - tap * j.cic;
+            const float4 v = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.Cin + j.ci0 + c) * a.Cout + j.co_base + 4 * co4);
+            *reinterpret_cast<float4*>(w_lds + (tap * a.cic + c) * j.cop + 4 * co4) = v;
+        }
+    } else if (j.kind == 1) {
+        const int c4n = j.cic >> 2, lg4 = lg2(c4n);
+#pragma unroll 4
+        for (int u = threadIdx.x; u < j.units; u += nt) {
+            const int r = dvt<P2>(u, c4n, lg4), c4 = u - r * c4n;
+            const int tap = dvt<P2>(r, j.coc, lgcoc), co = r - tap * j.coc;
+            const float4 v = *reinterpret_cast<const float4*>(a.w + ((size_t)(K * K - 1 - tap) * a.Cout + j.co_base + co) * a.Cin +
+                                                              j.ci0 + 4 * c4);
+            float* q = w_lds + (tap * a.cic + 4 * c4) * j.cop + co;
+            q[0] = v.x; q[j.cop] = v.y; q[2 * j.cop] = v.z; q[3 * j.cop] = v.w;
+        }
+    } else if (a.wflip) {
+#pragma unroll 4
+        for (int u = threadIdx.x; u < j.units; u += nt) {
+            const int r = dvt<P2>(u, j.coc, lgcoc), co = u - r * j.coc;
+            const int tap = dvt<P2>(r, j.cic, lgcic), c = r - tap * j.cic;
+            w_lds[(tap * a.cic + c) * j.cop + co] = a.w[((size_t)(K * K - 1 - tap) * a.Cout + j.co_base + co) * a.Cin + j.ci0 + c];
+        }
+    } else {
+#pragma unroll 4
+        for (int u = threadIdx.x; u < j.units; u += nt) {
+            const int r = dvt<P2>(u, j.coc, lgcoc), co = u - r * j.coc;
+            const int tap = dvt<P2>(r, j.cic, lgcic), c = r - tap * j.cic;
+            w_lds[(tap * a.cic + c) * j.cop + co] = a.w[((size_t)tap * a.Cin + j.ci0 + c) * a.Cout + j.co_base + co];
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void w_pass(const TiledArgs& a, const WJob& j, float* w_lds, int nt) {
+    const int c4n = j.kind == 0 ? j.coc >> 2 : j.kind == 1 ? j.cic >> 2 : 1;
+    if (is_p2(j.cic) && is_p2(j.coc) && is_p2(c4n)) w_pass_t<K, true>(a, j, w_lds, nt);
+    else w_pass_t<K, false>(a, j, w_lds, nt);
 }
 
 template <int K, int UP, int CO_T, int EPI>
-__global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
     constexpr int PADL = (K - 1) / 2;
     constexpr int NPR = patch_row<UP, PADL>(K) + 1;  // patch rows == patch cols
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -158,11 +304,29 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
     const int total = n_cot * per_cot;
     const bool one_chunk = a.cic >= a.Cin;
 
-    // zero once: the halo, the row padding and unused planes are never overwritten afterwards
-    for (int i = threadIdx.x; i < a.S * a.cic * a.plane; i += nt) in_lds[i] = 0.f;
-    if (one_chunk) stage_weights<K>(a, w_lds, 0, a.Cin, co_base, coc, cop, nt);
+    PlanarSrc src;
+    src.x = a.x; src.zy = a.zy; src.zidx = a.zidx; src.mode = a.zmode; src.zk = a.zk; src.C = a.Cin;
+    src.Hs = a.zmode == 2 ? a.Hs >> 1 : a.Hs;
+    src.Ws = a.zmode == 2 ? a.Ws >> 1 : a.Ws;
+    const PlanarDst dst{a.cic, a.plane, a.wp, a.halo};
 
-    for (int n0 = blockIdx.x * a.S; n0 < a.N; n0 += gridDim.x * a.S) {
+    SV_MARK(0);
+    // ---- prologue: zero the LDS (halo, row padding and padded channels are never overwritten afterwards), then
+    // stage the filter chunk and the first pass's input
+    int n0 = blockIdx.x * a.S;
+    {
+        const int lds_f4 = (a.S * a.cic * a.plane + K * K * a.cic * cop + 3) >> 2;
+        for (int i = threadIdx.x; i < lds_f4; i += nt) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        SV_MARK(1);
+        const int ns = min(a.S, a.N - n0);
+        const int cic0 = min(a.cic, a.Cin);
+        w_pass<K>(a, make_wjob(a, 0, cic0, co_base, coc, cop, K * K), w_lds, nt);
+        stage_pass(src, dst, make_stage_job(src, n0, ns, 0, cic0), in_lds, nt);
+    }
+    bool prestaged = true;
+
+    for (; n0 < a.N; n0 += gridDim.x * a.S) {
         const int ns = min(a.S, a.N - n0);
         // A thread owns one work item per pass of nt; its accumulators live across the ci-chunk loop.  When a
         // sample pass has more than nt items the passes are looped and each re-walks (re-stages) the chunks.
@@ -191,10 +355,14 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
 
             for (int ci0 = 0; ci0 < a.Cin; ci0 += a.cic) {
                 const int cic = min(a.cic, a.Cin - ci0);
-                __syncthreads();  // previous chunk / item pass is done with LDS (and the zero fill has landed)
-                if (item0 == 0 || !one_chunk) stage_input(a, in_lds, n0, ns, ci0, cic, nt);
-                if (!one_chunk) stage_weights<K>(a, w_lds, ci0, cic, co_base, coc, cop, nt);
+                if (!prestaged) {
+                    __syncthreads();  // previous chunk / item pass is done with LDS
+                    if (item0 == 0 || !one_chunk) stage_pass(src, dst, make_stage_job(src, n0, ns, ci0, cic), in_lds, nt);
+                    if (!one_chunk) w_pass<K>(a, make_wjob(a, ci0, cic, co_base, coc, cop, K * K), w_lds, nt);
+                }
+                prestaged = false;
                 __syncthreads();
+                SV_MARK(2);
                 if (work) {
                     const float* img = in_lds + (size_t)s * a.cic * a.plane;
                     // patch origin in the padded stored image (even column when UP == 1: 8-byte aligned rows)
@@ -241,6 +409,7 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
                     }
                 }
             }
+            SV_MARK(3);
             // ---- fold the ks channel slices (adjacent lanes of one wave; dead lanes hold zeros)
             for (int o = 1; o < ks; o <<= 1) {
 #pragma unroll
@@ -250,10 +419,111 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
 #pragma unroll
                         for (int q = 0; q < CO_T; ++q) acc[i][j][q] += __shfl_xor(acc[i][j][q], o, 64);
             }
-            // ---- epilogue
-            if (work && kl == 0) {
-                const int n = n0 + s;
-                const int cg = co_base + cot * CO_T;  // first global output channel of this thread
+            // ---- epilogue values: bias + activation (+ 2x2 max / 2x2 sum)
+            const int cg = co_base + cot * CO_T;  // first global output channel of this thread
+            const int n = n0 + s;
+            if (EPI == EPI_STORE) {
+#pragma unroll
+                for (int q = 0; q < CO_T; ++q) {
+                    const float b = (a.bias != nullptr && cg + q < a.Cout) ? a.bias[cg + q] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j][q] = act_apply(acc[i][j][q] + b, a.act, a.alpha);
+                }
+            }
+            float red[CO_T];      // MAXPOOL / SUM4: one value per channel
+            uint32_t slot[CO_T];  // MAXPOOL: argmax slot
+            if (EPI == EPI_MAXPOOL) {
+                // max of the pre-activations first (every activation here is non-decreasing, so the maximum and -
+                // wherever the activation is strictly increasing - its position are those of the activated
+                // values), then ONE activation per window.  relu flattens negatives into ties at 0 whose "first
+                // maximum" is slot 0 in the unfused order; no gradient flows there (relu'(0) = 0), so only the
+                // recorded slot could differ, and it is made to agree below.
+#pragma unroll
+                for (int q = 0; q < CO_T; ++q) {
+                    const float b = (a.bias != nullptr && cg + q < a.Cout) ? a.bias[cg + q] : 0.f;
+                    float best = acc[0][0][q];
+                    uint32_t bi = 0;
+                    if (acc[0][1][q] > best) { best = acc[0][1][q]; bi = 1; }
+                    if (acc[1][0][q] > best) { best = acc[1][0][q]; bi = 2; }
+                    if (acc[1][1][q] > best) { best = acc[1][1][q]; bi = 3; }
+                    const float v = act_apply(best + b, a.act, a.alpha);
+                    if (a.act == SV_ACT_RELU && v <= 0.f) bi = 0;
+                    red[q] = v;
+                    slot[q] = bi;
+                }
+            } else if (EPI == EPI_SUM4) {
+#pragma unroll
+                for (int q = 0; q < CO_T; ++q) red[q] = (acc[0][0][q] + acc[0][1][q]) + (acc[1][0][q] + acc[1][1][q]);
+            }
+
+            if (a.epi_lds) {
+                // ---- transpose through LDS: every thread drops its values at [sample][pixel][channel] of the block's
+                // output tile (the staging buffers are dead: one item pass, one chunk), then the whole tile - contiguous
+                // in global memory when the block owns all channels - leaves as full-width coalesced stores.
+                const int cs = a.out_cs;                       // floats per pixel in the LDS tile (padded)
+                const int P = EPI == EPI_STORE ? a.Ho * a.Wo : T;  // output pixels per sample
+                __syncthreads();
+                if (work && kl == 0) {
+                    if (EPI == EPI_STORE) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                float* o = smem + ((size_t)s * P + (2 * ty + i) * a.Wo + 2 * tx + j) * cs + cot * CO_T;
+#pragma unroll
+                                for (int q = 0; q < CO_T; q += 4)
+                                    *reinterpret_cast<float4*>(o + q) =
+                                        make_float4(acc[i][j][q], acc[i][j][q + 1], acc[i][j][q + 2], acc[i][j][q + 3]);
+                            }
+                    } else {
+                        float* o = smem + ((size_t)s * P + ty * tiles_x + tx) * cs + cot * CO_T;
+#pragma unroll
+                        for (int q = 0; q < CO_T; q += 4)
+                            *reinterpret_cast<float4*>(o + q) = make_float4(red[q], red[q + 1], red[q + 2], red[q + 3]);
+                        if (EPI == EPI_MAXPOOL && a.idx != nullptr) {
+                            uint32_t* ob = reinterpret_cast<uint32_t*>(smem + (size_t)a.S * P * cs) +
+                                           (((size_t)s * P + ty * tiles_x + tx) * cop + cot * CO_T) / 4;
+#pragma unroll
+                            for (int q = 0; q < CO_T; q += 4)
+                                ob[q >> 2] = slot[q] | (slot[q + 1] << 8) | (slot[q + 2] << 16) | (slot[q + 3] << 24);
+                        }
+                    }
+                }
+                __syncthreads();
+                const int rows = ns * P;  // one row = the coc channels of one pixel
+                if ((coc & 3) == 0 && (a.Cout & 3) == 0) {
+                    const int c4n = coc >> 2;
+                    for (int u = threadIdx.x; u < rows * c4n; u += nt) {
+                        const int r = dv(u, c4n), c4 = u - r * c4n;
+                        const float4 v = *reinterpret_cast<const float4*>(smem + (size_t)r * cs + 4 * c4);
+                        *reinterpret_cast<float4*>(a.y + ((size_t)n0 * P + r) * a.Cout + co_base + 4 * c4) = v;
+                    }
+                    if (EPI == EPI_MAXPOOL && a.idx != nullptr) {
+                        const uint32_t* ob = reinterpret_cast<const uint32_t*>(smem + (size_t)a.S * P * cs);
+                        for (int u = threadIdx.x; u < rows * c4n; u += nt) {
+                            const int r = dv(u, c4n), c4 = u - r * c4n;
+                            *reinterpret_cast<uint32_t*>(a.idx + ((size_t)n0 * P + r) * a.Cout + co_base + 4 * c4) =
+                                ob[((size_t)r * cop) / 4 + c4];
+                        }
+                    }
+                } else {
+                    for (int u = threadIdx.x; u < rows * coc; u += nt) {
+                        const int r = dv(u, coc), c = u - r * coc;
+                        a.y[((size_t)n0 * P + r) * a.Cout + co_base + c] = smem[(size_t)r * cs + c];
+                    }
+                    if (EPI == EPI_MAXPOOL && a.idx != nullptr) {
+                        const uint8_t* ob = reinterpret_cast<const uint8_t*>(smem + (size_t)a.S * P * cs);
+                        for (int u = threadIdx.x; u < rows * coc; u += nt) {
+                            const int r = dv(u, coc), c = u - r * coc;
+                            a.idx[((size_t)n0 * P + r) * a.Cout + co_base + c] = ob[(size_t)r * cop + c];
+                        }
+                    }
+                }
+                prestaged = false;
+            } else if (work && kl == 0) {
+                // ---- direct stores (multi-pass blocks, or an output tile larger than the staging footprint)
                 if (EPI == EPI_STORE) {
                     const bool vec = (a.Cout & 3) == 0;  // cg is a multiple of 4: 16-byte aligned rows of channels
 #pragma unroll
@@ -261,53 +531,33 @@ __global__ __launch_bounds__(256) void conv_s1_lds(TiledArgs a) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             float* yp = a.y + (((size_t)n * a.Ho + 2 * ty + i) * a.Wo + 2 * tx + j) * a.Cout + cg;
-                            float v[CO_T];
-#pragma unroll
-                            for (int q = 0; q < CO_T; ++q) {
-                                const float b = (a.bias != nullptr && cg + q < a.Cout) ? a.bias[cg + q] : 0.f;
-                                v[q] = act_apply(acc[i][j][q] + b, a.act, a.alpha);
-                            }
                             if (vec) {
 #pragma unroll
                                 for (int q = 0; q < CO_T; q += 4)
                                     if (cg + q < a.Cout)
-                                        *reinterpret_cast<float4*>(yp + q) = make_float4(v[q], v[q + 1], v[q + 2], v[q + 3]);
+                                        *reinterpret_cast<float4*>(yp + q) =
+                                            make_float4(acc[i][j][q], acc[i][j][q + 1], acc[i][j][q + 2], acc[i][j][q + 3]);
                             } else {
 #pragma unroll
                                 for (int q = 0; q < CO_T; ++q)
-                                    if (cg + q < a.Cout) yp[q] = v[q];
+                                    if (cg + q < a.Cout) yp[q] = acc[i][j][q];
                             }
                         }
-                } else if (EPI == EPI_MAXPOOL) {
-                    // max of the pre-activations first (every activation here is non-decreasing, so the maximum and -
-                    // wherever the activation is strictly increasing - its position are those of the activated
-                    // values), then ONE activation per window.  relu flattens negatives into ties at 0 whose "first
-                    // maximum" is slot 0 in the unfused order; no gradient flows there (relu'(0) = 0), so only the
-                    // recorded slot could differ, and it is made to agree below.
+                } else {
                     const size_t o = (((size_t)n * tiles_y + ty) * tiles_x + tx) * a.Cout + cg;
 #pragma unroll
                     for (int q = 0; q < CO_T; ++q)
                         if (cg + q < a.Cout) {
-                            const float b = a.bias != nullptr ? a.bias[cg + q] : 0.f;
-                            float best = acc[0][0][q];
-                            int bi = 0;
-                            if (acc[0][1][q] > best) { best = acc[0][1][q]; bi = 1; }
-                            if (acc[1][0][q] > best) { best = acc[1][0][q]; bi = 2; }
-                            if (acc[1][1][q] > best) { best = acc[1][1][q]; bi = 3; }
-                            const float v = act_apply(best + b, a.act, a.alpha);
-                            if (a.act == SV_ACT_RELU && v <= 0.f) bi = 0;
-                            a.y[o + q] = v;
-                            if (a.idx != nullptr) a.idx[o + q] = (uint8_t)bi;
+                            a.y[o + q] = red[q];
+                            if (EPI == EPI_MAXPOOL && a.idx != nullptr) a.idx[o + q] = (uint8_t)slot[q];
                         }
-                } else {  // EPI_SUM4
-                    const size_t o = (((size_t)n * tiles_y + ty) * tiles_x + tx) * a.Cout + cg;
-#pragma unroll
-                    for (int q = 0; q < CO_T; ++q)
-                        if (cg + q < a.Cout) a.y[o + q] = (acc[0][0][q] + acc[0][1][q]) + (acc[1][0][q] + acc[1][1][q]);
                 }
             }
+            SV_MARK(4);
         }
     }
+    __syncthreads();
+    SV_MARK(5);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -410,12 +660,32 @@ int launch_tiled_s1(const float* x, const float* w, const float* bias, float* y,
     a.wflip = wflip; a.act = act; a.alpha = alpha;
     a.S = p.S; a.cic = p.cic; a.coc = p.coc; a.plane = p.plane; a.wp = p.wp; a.halo = p.halo;
     a.zmode = zmode; a.zy = zy; a.zidx = zidx; a.zk = act_grad_coef(zact, zalpha);
-    a.lgW = ilog2_exact(Ws); a.lgH = ilog2_exact(Hs); a.ks = p.ks;
+    a.ks = p.ks;
+    // Outputs leave through an LDS tile when the block makes exactly one pass (the tile reuses the staging buffers)
+    {
+        const int T = (a.Ho / 2) * (a.Wo / 2);
+        const int n_cot = p.coc / p.co_t;
+        const size_t P = epi == EPI_STORE ? (size_t)a.Ho * a.Wo : (size_t)T;
+        const int cs = p.coc + 4;
+        const size_t out_bytes = (size_t)p.S * P * cs * sizeof(float) + (epi == EPI_MAXPOOL ? (size_t)p.S * P * p.coc : 0);
+        const bool single = (int64_t)p.S * T * n_cot * p.ks <= p.nt && p.cic >= Cin &&
+                            (int64_t)p.grid.x * p.S >= N;
+        a.epi_lds = single && out_bytes <= kLdsBudget;
+        a.out_cs = cs;
+        if (a.epi_lds && out_bytes > p.lds_bytes) p.lds_bytes = out_bytes;
+        p.lds_bytes = (p.lds_bytes + 15) & ~(size_t)15;
+    }
     if (K == 3) return UP == 1 ? launch_cot<3, 1>(a, epi, p, st) : launch_cot<3, 2>(a, epi, p, st);
     return UP == 1 ? launch_cot<5, 1>(a, epi, p, st) : launch_cot<5, 2>(a, epi, p, st);
 }
 
 }  // namespace sv
+
+#ifdef SV_TRACE
+extern "C" int sv_debug_set_trace(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sv::g_sv_trace), &buf, sizeof(buf));
+}
+#endif
 
 // =================================================================================================== kernel gradient
 // dw[kh][kw][ci][co] = sum over samples and output pixels of x[n, oh+kh-PADL, ow+kw-PADL, ci] * dz[n, oh, ow, co]
@@ -431,7 +701,7 @@ namespace sv {
 struct WgradArgs {
     const float* x;   // [N][Hs][Ws][Cin]
     const float* dz;  // [N][Ho][Wo][Cout]
-    float* slab;      // [gridDim.x][K*K*Cin*Cout]
+    float* slab;      // [gridDim.x][ny*nz][chunk][combo][RS]: partial sums in fold order
     int N, Hs, Ws, Cin, Cout, Ho, Wo, up;
     int S, cib, cob;  // samples per pass; input channels per block (grid.y); output channels per block (grid.z)
     int PG;           // pixel groups (power of two <= 64)
@@ -441,12 +711,17 @@ struct WgradArgs {
     const uint8_t* zidx;
     int zmode;
     ActGradCoef zk;
-    int lgWs, lgHs, lgHWo;  // log2 of Ws, Hs, Ho*Wo when powers of two, else -1
-    int with_bias;    // also emit sum(dz) per output channel at slab offset K*K*Cin*Cout
+    int with_bias;    // also emit sum(dz) per output channel
+    int combos_max;   // cib * (cob / CO_T): combo stride of the slab layout
 };
 
+// Slab layout shared by wgrad_s1_lds (writer) and wgrad_reduce3 (reader):
+//   part = blockIdx.z * gridDim.y + blockIdx.y;  slot = tap * CO_T + q  (kernel sums)  or  K*K*CO_T + q  (bias sums)
+//   offset = ((part * NCHUNK + slot / RS) * combos_max + combo) * RS + slot % RS,   combo = ci_local * n_cot + co_tile
+constexpr int kWgradRS = 20;
+
 template <int K, int CO_T>
-__global__ __launch_bounds__(256) void wgrad_s1_lds(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
     constexpr int PADL = (K - 1) / 2;
     constexpr int XC = K + 3;  // x columns needed by a strip of 4 output pixels
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -476,94 +751,29 @@ __global__ __launch_bounds__(256) void wgrad_s1_lds(WgradArgs a) {
     for (int q = 0; q < CO_T; ++q) accb[q] = 0.f;
     const bool do_bias = a.with_bias && live && cil == 0 && blockIdx.y == 0;
 
+    PlanarSrc xs;
+    xs.x = a.x; xs.zy = nullptr; xs.zidx = nullptr; xs.mode = a.up == 2 ? 3 : 0; xs.zk = a.zk;
+    xs.Hs = a.Hs; xs.Ws = a.Ws; xs.C = a.Cin;
+    const PlanarDst xd{a.cib, a.xplane, a.xwp, PADL};
+    PlanarSrc zs;
+    zs.x = a.dz; zs.zy = a.zy; zs.zidx = a.zidx; zs.mode = a.zmode; zs.zk = a.zk; zs.C = a.Cout;
+    zs.Hs = a.zmode == 2 ? a.Ho >> 1 : a.Ho;
+    zs.Ws = a.zmode == 2 ? a.Wo >> 1 : a.Wo;
+    const PlanarDst zd{n_cot * CO_T, a.zplane, a.Wo, 0};
+
+    SV_MARK(0);
     // zero once: halo, row padding and padded channels never get overwritten
-    const int lds_floats = a.S * (a.cib * a.xplane + n_cot * CO_T * a.zplane);
-    for (int i = threadIdx.x; i < lds_floats; i += 256) smem[i] = 0.f;
+    const int lds_f4 = (a.S * (a.cib * a.xplane + n_cot * CO_T * a.zplane) + 3) >> 2;
+    for (int i = threadIdx.x; i < lds_f4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    SV_MARK(1);
 
     for (int n0 = blockIdx.x * a.S; n0 < a.N; n0 += gridDim.x * a.S) {
         const int ns = min(a.S, a.N - n0);
+        __syncthreads();  // zero fill landed / previous pass is done reading
+        stage_pass(xs, xd, make_stage_job(xs, n0, ns, ci_base, cib), x_lds, 256);
+        stage_pass(zs, zd, make_stage_job(zs, n0, ns, co_base, cob), z_lds, 256);
         __syncthreads();
-        {  // stage x (replicated to the logical resolution when up > 1)
-            const int tid = threadIdx.x;
-            const int Hl = a.Hs * a.up, Wl = a.Ws * a.up;
-            const int C4 = cib >> 2;
-            if ((cib & 3) == 0 && (a.Cin & 3) == 0 && C4 > 0 && (C4 & (C4 - 1)) == 0) {
-                const int cl = tid & (C4 - 1), pl = tid / C4, PP = 256 / C4;
-                const int HW = a.Hs * a.Ws;
-                for (int p = pl; p < ns * HW; p += PP) {
-                    const int r = fdiv(p, a.Ws, a.lgWs), col = p - r * a.Ws;
-                    const int ss = fdiv(r, a.Hs, a.lgHs), row = r - ss * a.Hs;
-                    const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)n0 * HW + p) * a.Cin + ci_base + cl * 4);
-                    float* q = x_lds + (ss * a.cib + cl * 4) * a.xplane + (row * a.up + PADL) * a.xwp + col * a.up + PADL;
-                    for (int u = 0; u < a.up; ++u)
-                        for (int t = 0; t < a.up; ++t) {
-                            float* qq = q + u * a.xwp + t;
-                            qq[0] = v.x; qq[a.xplane] = v.y; qq[2 * a.xplane] = v.z; qq[3 * a.xplane] = v.w;
-                        }
-                }
-            } else {
-                const int elems = Hl * Wl * cib;
-                for (int i = tid; i < ns * elems; i += 256) {
-                    const int ss = i / elems;
-                    const int e = i - ss * elems;
-                    const int p = e / cib, c = e - p * cib;
-                    const int row = p / Wl, col = p - row * Wl;
-                    const float v = a.x[(((size_t)(n0 + ss) * a.Hs + row / a.up) * a.Ws + col / a.up) * a.Cin + ci_base + c];
-                    x_lds[(ss * a.cib + c) * a.xplane + (row + PADL) * a.xwp + col + PADL] = v;
-                }
-            }
-            // dz -> planar [co][Ho*Wo]
-            const int Z4 = cob >> 2;
-            const bool zvec = (cob & 3) == 0 && (a.Cout & 3) == 0 && Z4 > 0 && (Z4 & (Z4 - 1)) == 0;
-            const int zs = n_cot * CO_T;  // planes per sample
-            if (a.zmode != 2) {
-                const int HW = a.Ho * a.Wo;
-                if (zvec) {
-                    const int cl = tid & (Z4 - 1), pl = tid / Z4, PP = 256 / Z4;
-                    for (int p = pl; p < ns * HW; p += PP) {
-                        const int ss = fdiv(p, HW, a.lgHWo), pp = p - ss * HW;
-                        const size_t gi = ((size_t)n0 * HW + p) * a.Cout + co_base + cl * 4;
-                        float4 v = *reinterpret_cast<const float4*>(a.dz + gi);
-                        if (a.zmode == 1) {
-                            const float4 yv = *reinterpret_cast<const float4*>(a.zy + gi);
-                            v.x *= act_grad_q(yv.x, a.zk);
-                            v.y *= act_grad_q(yv.y, a.zk);
-                            v.z *= act_grad_q(yv.z, a.zk);
-                            v.w *= act_grad_q(yv.w, a.zk);
-                        }
-                        float* q = z_lds + (ss * zs + cl * 4) * a.zplane + pp;
-                        q[0] = v.x; q[a.zplane] = v.y; q[2 * a.zplane] = v.z; q[3 * a.zplane] = v.w;
-                    }
-                } else {
-                    const int zel = HW * cob;
-                    for (int i = tid; i < ns * zel; i += 256) {
-                        const int ss = i / zel;
-                        const int e = i - ss * zel;
-                        const int p = e / cob, c = e - p * cob;
-                        const size_t gi = ((size_t)(n0 + ss) * HW + p) * a.Cout + co_base + c;
-                        float v = a.dz[gi];
-                        if (a.zmode == 1) v *= act_grad_q(a.zy[gi], a.zk);
-                        z_lds[(ss * zs + c) * a.zplane + p] = v;
-                    }
-                }
-            } else {
-                const int Hq = a.Ho >> 1, Wq = a.Wo >> 1;
-                const int zel = Hq * Wq * cob;
-                for (int i = tid; i < ns * zel; i += 256) {
-                    const int ss = i / zel;
-                    const int e = i - ss * zel;
-                    const int p = e / cob, c = e - p * cob;
-                    const int row = p / Wq, col = p - row * Wq;
-                    const size_t gi = ((size_t)(n0 + ss) * Hq * Wq + p) * a.Cout + co_base + c;
-                    const float v = a.dz[gi] * act_grad_q(a.zy[gi], a.zk);
-                    const int k = a.zidx[gi];
-                    float* q = z_lds + (ss * zs + c) * a.zplane + (2 * row) * a.Wo + 2 * col;
-                    *reinterpret_cast<float2*>(q) = make_float2(k == 0 ? v : 0.f, k == 1 ? v : 0.f);
-                    *reinterpret_cast<float2*>(q + a.Wo) = make_float2(k == 2 ? v : 0.f, k == 3 ? v : 0.f);
-                }
-            }
-        }
-        __syncthreads();
+        SV_MARK(2);
         if (live) {
             for (int w = pg; w < ns * strips; w += PG) {
                 const int ss = w / strips;
@@ -605,16 +815,17 @@ __global__ __launch_bounds__(256) void wgrad_s1_lds(WgradArgs a) {
             }
         }
     }
+    SV_MARK(3);
     // ---- fold the PG partial sums of every (ci, co tile) through LDS (the staging buffers are dead now) and
-    // write this workgroup's slab.  Slots = K*K*CO_T kernel-gradient sums (+ CO_T bias sums), folded in chunks of
-    // RS slots so the scratch stays within the staging footprint: red[thread][RS + 1].
+    // write this workgroup's slab in fold order (contiguous, coalesced).  Slots = K*K*CO_T kernel-gradient sums
+    // + CO_T bias sums, folded in chunks of RS slots so the scratch stays small: red[thread][RS + 1].
     constexpr int NSLOT = K * K * CO_T + CO_T;
-    constexpr int RS = 20;
+    constexpr int RS = kWgradRS;
     constexpr int NCHUNK = (NSLOT + RS - 1) / RS;
-    const size_t kc = (size_t)K * K * a.Cin * a.Cout;
-    const size_t slab_stride = kc + (a.with_bias ? a.Cout : 0);
-    float* out = a.slab + (size_t)blockIdx.x * slab_stride;
-    float* red = smem;  // 256 * (RS + 1) floats = 21 KiB <= any staging footprint the planner accepts
+    const int nparts = gridDim.y * gridDim.z;
+    const int part = blockIdx.z * gridDim.y + blockIdx.y;
+    float* out = a.slab + ((size_t)blockIdx.x * nparts + part) * NCHUNK * a.combos_max * RS;
+    float* red = smem;  // 256 * (RS + 1) floats = 21 KiB <= the LDS size the planner requests
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ++ch) {
         __syncthreads();
@@ -630,27 +841,19 @@ __global__ __launch_bounds__(256) void wgrad_s1_lds(WgradArgs a) {
         const int nout = combos * RS;
         for (int o = threadIdx.x; o < nout; o += 256) {
             const int cb = o / RS, j = o - cb * RS;
-            const int slot = ch * RS + j;
-            if (slot >= NSLOT) continue;
             float sum = 0.f;
-            for (int g = 0; g < PG; ++g) sum += red[(cb * PG + g) * (RS + 1) + j];
-            const int ci_l = cb / n_cot, ct = cb - ci_l * n_cot;
-            if (slot < K * K * CO_T) {
-                const int tap = slot / CO_T, q = slot - tap * CO_T;
-                const int co = co_base + ct * CO_T + q;
-                if (co < a.Cout) out[((size_t)tap * a.Cin + ci_base + ci_l) * a.Cout + co] = sum;
-            } else if (a.with_bias && ci_l == 0 && blockIdx.y == 0) {
-                const int co = co_base + ct * CO_T + (slot - K * K * CO_T);
-                if (co < a.Cout) out[kc + co] = sum;
-            }
+            if (ch * RS + j < NSLOT)
+                for (int g = 0; g < PG; ++g) sum += red[(cb * PG + g) * (RS + 1) + j];
+            out[(size_t)ch * a.combos_max * RS + o] = sum;
         }
     }
+    SV_MARK(5);
 }
 
 struct WgradPlan {
     bool ok;
-    int S, cib, cob, PG, co_t, xplane, xwp, zplane, nblk;
-    size_t lds_bytes;
+    int S, cib, cob, PG, co_t, xplane, xwp, zplane, nblk, nchunk, combos_max;
+    size_t lds_bytes, slab_floats;  // slab_floats: per grid.x block
     dim3 grid;
 };
 
@@ -692,7 +895,8 @@ WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     if (S > N) S = N;
     p.S = S; p.cib = cib; p.cob = cob; p.PG = PG;
     p.lds_bytes = bytes(S, cib, cob);
-    if (p.lds_bytes < (size_t)256 * 21 * sizeof(float)) p.lds_bytes = (size_t)256 * 21 * sizeof(float);  // fold scratch
+    if (p.lds_bytes < (size_t)256 * (kWgradRS + 1) * sizeof(float)) p.lds_bytes = (size_t)256 * (kWgradRS + 1) * sizeof(float);
+    p.lds_bytes = (p.lds_bytes + 15) & ~(size_t)15;
     const int passes = (N + S - 1) / S;
     const int ny = (Cin + cib - 1) / cib, nz = (Cout + cob - 1) / cob;
     int gx = 512 / (ny * nz);
@@ -700,6 +904,10 @@ WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     if (gx > passes) gx = passes;
     p.nblk = gx;
     p.grid = dim3((unsigned)gx, (unsigned)ny, (unsigned)nz);
+    const int nslot = K * K * p.co_t + p.co_t;
+    p.nchunk = (nslot + kWgradRS - 1) / kWgradRS;
+    p.combos_max = combos;
+    p.slab_floats = (size_t)ny * nz * p.nchunk * combos * kWgradRS;
     p.ok = true;
     return p;
 }
@@ -708,38 +916,69 @@ size_t tiled_wgrad_workspace(int N, int Hs, int Ws, int Cin, int Cout, int K, in
     if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return 0;
     WgradPlan p = plan_wgrad(N, Hs, Ws, Cin, Cout, K, UP);
     if (!p.ok) return 0;
-    return (size_t)p.nblk * ((size_t)K * K * Cin * Cout + Cout) * sizeof(float);
+    return (size_t)p.nblk * p.slab_floats * sizeof(float);
 }
 
-// out[i] (+)= sum_sp part[sp][i] for i < kc (dw) and, when db != null, db[i - kc] for kc <= i < kc + ncb.
-__global__ __launch_bounds__(1024) void wgrad_reduce2(const float* __restrict__ part, float* __restrict__ dw,
-                                                       float* __restrict__ db, int64_t kc, int ncb, int n_split,
-                                                       int accumulate) {
+// Sums the slabs in a fixed order and scatters each sum to its place in dw / db.  One thread column per slab
+// element (coalesced reads); 16 groups of a block split the slabs and fold through LDS.
+struct ReduceArgs {
+    const float* part;
+    float* dw;
+    float* db;
+    int64_t slab_floats;
+    int n_split, accumulate;
+    int K2, co_t, nchunk, combos_max, ny, cib, cob, Cin, Cout;
+};
+__global__ __launch_bounds__(1024) void wgrad_reduce3(ReduceArgs a) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int64_t stride = kc + ncb;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (i < stride) {
+    if (e < a.slab_floats) {
         int sp = grp;
-        for (; sp + 7 * 16 < n_split; sp += 8 * 16) {
+        for (; sp + 7 * 16 < a.n_split; sp += 8 * 16) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(sp + u * 16) * stride + i];
+            for (int u = 0; u < 8; ++u) v[u] = a.part[(int64_t)(sp + u * 16) * a.slab_floats + e];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; sp < n_split; sp += 16) s += part[(int64_t)sp * stride + i];
+        for (; sp < a.n_split; sp += 16) s += a.part[(int64_t)sp * a.slab_floats + e];
     }
     red[grp][lane] = s;
     __syncthreads();
-    if (grp == 0 && i < stride) {
-        float* o = i < kc ? dw + i : db + (i - kc);
-        float t = accumulate ? *o : 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][lane];
-        *o = t;
+    if (grp != 0 || e >= a.slab_floats) return;
+    // decode the slab position
+    const int RS = kWgradRS;
+    int r = (int)e;
+    const int j = r % RS; r /= RS;
+    const int combo = r % a.combos_max; r /= a.combos_max;
+    const int ch = r % a.nchunk;
+    const int part = r / a.nchunk;
+    const int by = part % a.ny, bz = part / a.ny;
+    const int ci_base = by * a.cib, co_base = bz * a.cob;
+    const int cib = min(a.cib, a.Cin - ci_base), cob = min(a.cob, a.Cout - co_base);
+    const int n_cot = (cob + a.co_t - 1) / a.co_t;
+    if (combo >= cib * n_cot) return;
+    const int cil = combo / n_cot, ct = combo - cil * n_cot;
+    const int slot = ch * RS + j;
+    float* o;
+    if (slot < a.K2 * a.co_t) {
+        const int tap = slot / a.co_t, q = slot - tap * a.co_t;
+        const int co = co_base + ct * a.co_t + q;
+        if (co >= a.Cout) return;
+        o = a.dw + ((size_t)tap * a.Cin + ci_base + cil) * a.Cout + co;
+    } else if (slot < a.K2 * a.co_t + a.co_t) {
+        const int co = co_base + ct * a.co_t + (slot - a.K2 * a.co_t);
+        if (a.db == nullptr || cil != 0 || by != 0 || co >= a.Cout) return;
+        o = a.db + co;
+    } else {
+        return;
     }
+    float t = a.accumulate ? *o : 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    *o = t;
 }
 
 bool tiled_wgrad_supported(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
@@ -754,9 +993,8 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
     if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return 1;
     WgradPlan p = plan_wgrad(N, Hs, Ws, Cin, Cout, K, UP);
     if (!p.ok) return 1;
-    const size_t kc = (size_t)K * K * Cin * Cout;
-    const int ncb = db != nullptr ? Cout : 0;
-    const size_t need = (size_t)p.nblk * (kc + ncb) * sizeof(float);
+    if (zmode == 2 && (((Hs * UP) | (Ws * UP)) & 1)) return 1;
+    const size_t need = (size_t)p.nblk * p.slab_floats * sizeof(float);
     if (ws == nullptr || ws_bytes < need)
         return fail(SV_E_WORKSPACE, "conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
     WgradArgs a{};
@@ -764,7 +1002,7 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
     a.N = N; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.Cout = Cout; a.Ho = Hs * UP; a.Wo = Ws * UP; a.up = UP;
     a.S = p.S; a.cib = p.cib; a.cob = p.cob; a.PG = p.PG; a.xplane = p.xplane; a.xwp = p.xwp; a.zplane = p.zplane;
     a.zmode = zmode; a.zy = zy; a.zidx = zidx; a.zk = act_grad_coef(zact, zalpha); a.with_bias = db != nullptr;
-    a.lgWs = ilog2_exact(Ws); a.lgHs = ilog2_exact(Hs); a.lgHWo = ilog2_exact(a.Ho * a.Wo);
+    a.combos_max = p.combos_max;
     if (K == 3) {
         if (p.co_t == 8)
             hipLaunchKernelGGL((wgrad_s1_lds<3, 8>), p.grid, dim3(256), p.lds_bytes, st, a);
@@ -775,9 +1013,12 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
     }
     int rc = check_launch("wgrad_s1_lds");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce2, dim3((unsigned)ceil_div((int64_t)(kc + ncb), 64)), dim3(1024), 0, st,
-                       (const float*)ws, dw, db, (int64_t)kc, ncb, p.nblk, accumulate);
-    return check_launch("wgrad_reduce2");
+    ReduceArgs r{};
+    r.part = (const float*)ws; r.dw = dw; r.db = db; r.slab_floats = (int64_t)p.slab_floats; r.n_split = p.nblk;
+    r.accumulate = accumulate; r.K2 = K * K; r.co_t = p.co_t; r.nchunk = p.nchunk; r.combos_max = p.combos_max;
+    r.ny = (int)p.grid.y; r.cib = p.cib; r.cob = p.cob; r.Cin = Cin; r.Cout = Cout;
+    hipLaunchKernelGGL(wgrad_reduce3, dim3((unsigned)ceil_div((int64_t)p.slab_floats, 64)), dim3(1024), 0, st, r);
+    return check_launch("wgrad_reduce3");
 }
 
 }  // namespace sv
