@@ -80,6 +80,25 @@ int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const voi
                   const uint8_t* idx, void* dx, void* dw, void* db, int act, float alpha, void* workspace,
                   size_t workspace_bytes, int dtype, sv_stream_t stream);
 
+/* ---- Whole-network forward of a conv chain: the encoder + decoder stacks of CAEPadded (autoencoder.py:408-536,
+ *      `decoded = self.decoder(self.encoder(x))` :530-536) when every layer is a 3x3 stride-1 SAME Conv2D, optionally
+ *      preceded by UpSampling2D((2,2)) (up = 2) and/or followed by MaxPooling2D((2,2)) (pool = 1), without
+ *      BatchNormalization / Dense.  One launch carries each sample through all layers inside one workgroup; every
+ *      layer's output (pooled extent when pool = 1, NHWC) and pooling argmax are also written to y / idx, the tensors
+ *      the per-layer backward entry points read.  params: the flat parameter buffer the w_off / b_off (in floats,
+ *      b_off < 0: no bias) refer to.  H, W: extents of x.  sv_convnet_supported: 1 when the chain fits the kernel. */
+typedef struct sv_net_layer {
+    int32_t Cin, Cout, K, up, pool, act;
+    float alpha;
+    int32_t reserved;
+    int64_t w_off, b_off;
+    void* y;
+    uint8_t* idx;
+} sv_net_layer;
+int sv_convnet_supported(const sv_net_layer* layers, int n_layers, int N, int H, int W);
+int sv_convnet_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
+                   int dtype, sv_stream_t stream);
+
 /* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
 /* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */
 int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,

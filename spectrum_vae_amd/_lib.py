@@ -27,6 +27,14 @@ class ConvGeom(C.Structure):
         return tuple(getattr(self, f) for f, _ in self._fields_)
 
 
+class NetLayer(C.Structure):
+    """Mirror of ``sv_net_layer``."""
+
+    _fields_ = [("Cin", C.c_int32), ("Cout", C.c_int32), ("K", C.c_int32), ("up", C.c_int32), ("pool", C.c_int32),
+                ("act", C.c_int32), ("alpha", C.c_float), ("reserved", C.c_int32), ("w_off", C.c_int64),
+                ("b_off", C.c_int64), ("y", C.c_void_p), ("idx", C.c_void_p)]
+
+
 _p, _i, _f, _i64, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64, C.c_size_t
 _g = C.POINTER(ConvGeom)
 
@@ -41,6 +49,8 @@ SIGNATURES = {
     "sv_conv2d_fused_supported": (_i, [_g, _i]),
     "sv_conv2d_pool_fwd": (_i, [_g, _p, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_bwd": (_i, [_g, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _sz, _i, _p]),
+    "sv_convnet_supported": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i]),
+    "sv_convnet_fwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _i, _p]),
     "sv_conv2d_transpose_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_transpose_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
     "sv_conv2d_transpose_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),

@@ -27,6 +27,9 @@ class _EncoderDecoder(Model):
     def _build(self, in_shape):
         return self.decoder.build(self.encoder.build(in_shape))
 
+    def _sequentials(self):
+        return [self.encoder, self.decoder]
+
     def forward(self, ctx, x):
         return self.decoder.forward(ctx, self.encoder.forward(ctx, x))
 

@@ -14,11 +14,9 @@
 //   - forward conv + activation + 2x2 max-pool with argmax,                     EPI_MAXPOOL
 //   - the input gradient (a conv of dz with the taps flipped and channels swapped: WFLIP),
 //   - the input gradient summed over each 2x2 block (backward of a folded upsampling).  EPI_SUM4
-#include "common.h"
+#include "tile_common.h"
 
 namespace sv {
-
-enum { EPI_STORE = 0, EPI_MAXPOOL = 1, EPI_SUM4 = 2 };
 
 // Phase timestamps for kernel tuning (diagnostic builds only: make TRACE=1).  Thread 0 of every workgroup stores
 // the 100 MHz wall clock at up to 8 phase marks into g_sv_trace[block][8] (slot 7: hardware id).
@@ -65,160 +63,6 @@ struct TiledArgs {
     int epi_lds;   // 1: outputs leave through an LDS tile [sample][pixel][out_cs] as coalesced stores
     int out_cs;    // floats per pixel of that tile
 };
-
-// n / d for a divisor that is usually a power of two (image extents, channel counts).
-__device__ __forceinline__ int dv(int n, int d) { return (d & (d - 1)) == 0 ? (n >> (31 - __clz(d))) : n / d; }
-inline int ilog2_exact(int v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctz(v) : -1; }
-
-__host__ __device__ constexpr int floordiv_c(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
-
-// stored-patch row used by logical patch row q (q = pixel offset + tap) for pad PADL and upsampling UP
-template <int UP, int PADL>
-__host__ __device__ constexpr int patch_row(int q) { return floordiv_c(q - PADL, UP) - floordiv_c(-PADL, UP); }
-
-// ---- staging: NHWC tensor in global memory -> planar images in LDS ----------------------------------------------
-// A global round trip costs far more than the few instructions that consume it, so staging is split into a LOAD
-// phase that issues up to U independent 16-byte loads per thread into registers and a STORE phase that decodes
-// positions and writes LDS; callers put other work (LDS zero fill, the previous pass's arithmetic) between the two.
-struct PlanarSrc {
-    const float* x;       // [n][Hs][Ws][C]
-    const float* zy;      // mode 1/2: activation output the gradient is taken through
-    const uint8_t* zidx;  // mode 2: argmax slot (0..3) of each 2x2 window
-    // 0: x as is;  1: x * act'(zy);  2: x, zy, zidx live at half resolution and the value lands on the argmax slot of
-    // its 2x2 window of the LDS image (zeros on the other three);  3: x replicated to a 2x2 block (nearest upsampling)
-    int mode;
-    ActGradCoef zk;
-    int Hs, Ws, C;        // extents of the STORED tensor (mode 2: the pooled extents) and its channel count
-};
-struct PlanarDst {
-    int cpl;    // channel planes per sample in LDS
-    int plane;  // floats per plane
-    int wp;     // floats per row
-    int off;    // row/col offset of pixel (0,0) inside a plane (the zero halo)
-};
-struct StageJob {
-    int kind;   // 0: float4 = 4 channels of one pixel; 1: float4 = 4 consecutive floats of the contiguous pass; 2: scalars
-    int units;  // float4s (kind 0/1) or floats (kind 2) in this pass
-    int c0, cc, C4;
-    size_t base;  // element offset of sample n0
-};
-__device__ __forceinline__ StageJob make_stage_job(const PlanarSrc& s, int n0, int ns, int c0, int cc) {
-    StageJob j;
-    const int HW = s.Hs * s.Ws;
-    j.c0 = c0; j.cc = cc; j.C4 = cc >> 2;
-    j.base = (size_t)n0 * HW * s.C;
-    if ((cc & 3) == 0 && (s.C & 3) == 0 && (c0 & 3) == 0) {
-        j.kind = 0; j.units = ns * HW * j.C4;
-    } else if (c0 == 0 && cc == s.C && ((HW * s.C) & 3) == 0) {
-        j.kind = 1; j.units = (ns * HW * s.C) >> 2;
-    } else {
-        j.kind = 2; j.units = ns * HW * cc;
-    }
-    return j;
-}
-
-// n / d with the power-of-two decision taken at compile time (P2: d == 1 << lg), so staging loops are branch-free
-template <bool P2>
-__device__ __forceinline__ int dvt(int n, int d, int lg) { return P2 ? (n >> lg) : n / d; }
-__device__ __forceinline__ int lg2(int d) { return 31 - __clz(d); }
-__device__ __forceinline__ bool is_p2(int d) { return (d & (d - 1)) == 0; }
-
-// one staged value -> its place(s) in the LDS image of channel plane q0 (already offset to the sample and channel)
-template <int MODE>
-__device__ __forceinline__ void stage_put(const PlanarSrc& s, const PlanarDst& d, float* q0, int row, int col, float x,
-                                          float y, uint32_t k) {
-    if (MODE == 0) {
-        q0[(row + d.off) * d.wp + col + d.off] = x;
-    } else if (MODE == 1) {
-        q0[(row + d.off) * d.wp + col + d.off] = x * act_grad_q(y, s.zk);
-    } else if (MODE == 3) {
-        float* q = q0 + (2 * row + d.off) * d.wp + 2 * col + d.off;
-        q[0] = x; q[1] = x; q[d.wp] = x; q[d.wp + 1] = x;
-    } else {
-        const float v = x * act_grad_q(y, s.zk);
-        float* q = q0 + (2 * row + d.off) * d.wp + 2 * col + d.off;
-        q[0] = k == 0 ? v : 0.f; q[1] = k == 1 ? v : 0.f; q[d.wp] = k == 2 ? v : 0.f; q[d.wp + 1] = k == 3 ? v : 0.f;
-    }
-}
-
-// One pass: every thread walks its units with a stride of nt.  The loop bodies are branch-free and unrolled by 4 so
-// that the global loads of four units are issued before the first LDS write (a global round trip costs far more
-// than the instructions that consume it).
-template <int MODE, bool P2>
-__device__ __forceinline__ void stage_pass_t(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
-    const int HW = s.Hs * s.Ws;
-    const int lgHW = lg2(HW), lgW = lg2(s.Ws), lgC = lg2(s.C);
-    constexpr bool need_y = MODE == 1 || MODE == 2;
-    if (j.kind == 0) {
-        const int lgC4 = lg2(j.C4);
-#pragma unroll 4
-        for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int p = dvt<P2>(u, j.C4, lgC4), cl = u - p * j.C4;
-            const size_t gi = j.base + (size_t)p * s.C + j.c0 + 4 * cl;
-            const float4 v = *reinterpret_cast<const float4*>(s.x + gi);
-            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t k = 0;
-            if (need_y) y = *reinterpret_cast<const float4*>(s.zy + gi);
-            if (MODE == 2) k = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
-            const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
-            const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
-            float* q = lds + (size_t)(ss * d.cpl + 4 * cl) * d.plane;
-            stage_put<MODE>(s, d, q, row, col, v.x, y.x, k & 0xff);
-            stage_put<MODE>(s, d, q + d.plane, row, col, v.y, y.y, (k >> 8) & 0xff);
-            stage_put<MODE>(s, d, q + 2 * d.plane, row, col, v.z, y.z, (k >> 16) & 0xff);
-            stage_put<MODE>(s, d, q + 3 * d.plane, row, col, v.w, y.w, k >> 24);
-        }
-    } else if (j.kind == 1) {
-#pragma unroll 4
-        for (int u = threadIdx.x; u < j.units; u += nt) {
-            const size_t gi = j.base + 4 * (size_t)u;
-            const float4 v = *reinterpret_cast<const float4*>(s.x + gi);
-            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t k = 0;
-            if (need_y) y = *reinterpret_cast<const float4*>(s.zy + gi);
-            if (MODE == 2) k = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
-            const float xv[4] = {v.x, v.y, v.z, v.w};
-            const float yv[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int e = 4 * u + t;
-                const int p = dvt<P2>(e, s.C, lgC), c = e - p * s.C;
-                const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
-                const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
-                stage_put<MODE>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, row, col, xv[t], yv[t], (k >> (8 * t)) & 0xff);
-            }
-        }
-    } else {
-        const int lgcc = lg2(j.cc);
-#pragma unroll 4
-        for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int p = dvt<P2>(u, j.cc, lgcc), c = u - p * j.cc;
-            const size_t gi = j.base + (size_t)p * s.C + j.c0 + c;
-            const float v = s.x[gi];
-            const float y = need_y ? s.zy[gi] : 0.f;
-            const uint32_t k = MODE == 2 ? s.zidx[gi] : 0u;
-            const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
-            const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
-            stage_put<MODE>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, row, col, v, y, k);
-        }
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ void stage_pass_m(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
-    const bool p2 = is_p2(s.Hs * s.Ws) && is_p2(s.Ws) && is_p2(s.C) && is_p2(j.kind == 0 ? j.C4 : j.cc);
-    if (p2) stage_pass_t<MODE, true>(s, d, j, lds, nt);
-    else stage_pass_t<MODE, false>(s, d, j, lds, nt);
-}
-
-__device__ __forceinline__ void stage_pass(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
-    switch (s.mode) {
-        case 0: stage_pass_m<0>(s, d, j, lds, nt); break;
-        case 1: stage_pass_m<1>(s, d, j, lds, nt); break;
-        case 2: stage_pass_m<2>(s, d, j, lds, nt); break;
-        default: stage_pass_m<3>(s, d, j, lds, nt); break;
-    }
-}
 
 // ---- filter chunk -> w_lds[tap][c][cop] (cop = channel tiles * CO_T; padded channels stay zero from the LDS fill)
 struct WJob {
@@ -287,7 +131,6 @@ __device__ __forceinline__ void w_pass(const TiledArgs& a, const WJob& j, float*
 template <int K, int UP, int CO_T, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
     constexpr int PADL = (K - 1) / 2;
-    constexpr int NPR = patch_row<UP, PADL>(K) + 1;  // patch rows == patch cols
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* in_lds = smem;                                   // [S][cic][plane]
     float* w_lds = smem + (size_t)a.S * a.cic * a.plane;    // [K*K][cic][cop]
@@ -368,45 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
                     // patch origin in the padded stored image (even column when UP == 1: 8-byte aligned rows)
                     const int r0 = (UP == 1 ? 2 * ty : ty) + a.halo + floordiv_c(-PADL, UP);
                     const int c0 = (UP == 1 ? 2 * tx : tx) + a.halo + floordiv_c(-PADL, UP);
-                    const float* wbase = w_lds + cot * CO_T;
-                    for (int c = kl; c < cic; c += ks) {
-                        float patch[NPR][NPR + 1];
-                        const float* pl = img + c * a.plane + r0 * a.wp + c0;
-#pragma unroll
-                        for (int pr = 0; pr < NPR; ++pr) {
-                            if (UP == 1) {  // NPR = K + 1 is even
-#pragma unroll
-                                for (int pc = 0; pc < NPR; pc += 2) {
-                                    const float2 v2 = *reinterpret_cast<const float2*>(pl + pr * a.wp + pc);
-                                    patch[pr][pc] = v2.x;
-                                    patch[pr][pc + 1] = v2.y;
-                                }
-                            } else {
-#pragma unroll
-                                for (int pc = 0; pc < NPR; ++pc) patch[pr][pc] = pl[pr * a.wp + pc];
-                            }
-                        }
-#pragma unroll
-                        for (int kh = 0; kh < K; ++kh)
-#pragma unroll
-                            for (int kw = 0; kw < K; ++kw) {
-                                float wv[CO_T];
-                                const float* wp = wbase + ((kh * K + kw) * a.cic + c) * cop;
-#pragma unroll
-                                for (int q = 0; q < CO_T; q += 4) {
-                                    const float4 w4 = *reinterpret_cast<const float4*>(wp + q);
-                                    wv[q] = w4.x; wv[q + 1] = w4.y; wv[q + 2] = w4.z; wv[q + 3] = w4.w;
-                                }
-#pragma unroll
-                                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                                    for (int j = 0; j < 2; ++j) {
-                                        const float v = patch[patch_row<UP, PADL>(i + kh)][patch_row<UP, PADL>(j + kw)];
-#pragma unroll
-                                        for (int q = 0; q < CO_T; ++q) acc[i][j][q] = fmaf(v, wv[q], acc[i][j][q]);
-                                    }
-                            }
-                    }
+                    conv_tile_fma<K, UP, CO_T>(acc, img, w_lds + cot * CO_T, a.plane, a.wp, r0, c0, kl, cic, ks, a.cic, cop);
                 }
             }
             SV_MARK(3);

@@ -1,0 +1,448 @@
+// Whole-network kernels for chains of stride-1 SAME convs (optionally with a folded 2x nearest upsampling on the
+// input and a folded 2x2 max-pool on the output): the CAEPadded family without BatchNorm / Dense.
+//
+// Samples are independent through every layer, so one workgroup carries S samples through ALL layers without
+// leaving the CU: activations live in two LDS arenas as planar images with a zero halo (the layout the register-tile
+// FMA loop reads), layer l reads arena l % 2 and writes arena (l + 1) % 2.  Per layer the workgroup
+//   [A] zeroes the output arena and drops the (prefetched) filters + bias of the layer into the filter arena,
+//   [B] puts the next layer's filter loads in flight (registers),
+//   [C] computes: a thread owns 2x2 output pixels x CO_T channels, bias + activation (+ 2x2 max-pool with argmax)
+//       in registers, results written to the output arena in the next layer's input layout,
+//   [E] copies the output arena to global memory as NHWC with full-width stores (the backward pass reads it).
+// One launch replaces one launch per layer, and no layer waits for a global-memory round trip of its input.
+#include "tile_common.h"
+
+namespace sv {
+
+constexpr int kMaxNetLayers = 12;
+constexpr int kNetWPre = 6;  // float4 registers per thread holding the next layer's filters
+
+struct NetLayer {
+    int Cin, Cout;
+    int Hs, Ws;      // stored input extent
+    int up, pool;    // input read through 2x nearest upsampling / output 2x2 max-pooled
+    int act;
+    float alpha;
+    int w_off, b_off;                  // float offsets into the flat parameter buffer (b_off < 0: no bias)
+    int in_off, out_off;               // LDS float offsets of the input / output arena
+    int in_plane, in_wp, in_halo;      // planar layout of the input
+    int out_plane, out_wp, out_halo;   // planar layout of the output (= the next layer's input layout)
+    int co_t, n_cot, ks;
+    float* y;        // global output [N][Hout][Wout][Cout] (pooled extent when pool)
+    uint8_t* idx;    // global argmax slots (pool only, may be null)
+};
+
+struct NetFwdArgs {
+    const float* x;
+    const float* params;
+    int N, S, n_layers;
+    int w_off;    // LDS float offset of the filter arena ([tap][Cin][cop] + cop bias values)
+    int idx_off;  // LDS float offset of the argmax byte arena
+    NetLayer L[kMaxNetLayers];
+};
+
+// ---- filters: global -> registers (prefetch) -> LDS [tap][ci][cop] followed by cop bias values ----------------------
+template <int K>
+__device__ __forceinline__ void net_w_load(const NetFwdArgs& a, const NetLayer& L, float4 (&wpre)[kNetWPre], float& bpre,
+                                           int nt) {
+    const int cop = L.n_cot * L.co_t;
+    const float* w = a.params + L.w_off;
+    const int rows = K * K * L.Cin;
+    if ((L.Cout & 3) == 0 && (L.w_off & 3) == 0) {
+        const int c4n = cop >> 2, units = rows * c4n;
+#pragma unroll
+        for (int i = 0; i < kNetWPre; ++i) {
+            const int u = threadIdx.x + i * nt;
+            wpre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < units) {
+                const int r = dv(u, c4n), c4 = u - r * c4n;
+                if (4 * c4 < L.Cout) wpre[i] = *reinterpret_cast<const float4*>(w + (size_t)r * L.Cout + 4 * c4);
+            }
+        }
+    } else {
+        const int units = rows * cop;
+#pragma unroll
+        for (int i = 0; i < kNetWPre; ++i) {
+            const int u = threadIdx.x + i * nt;
+            wpre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < units) {
+                const int r = dv(u, cop), co = u - r * cop;
+                if (co < L.Cout) wpre[i].x = w[(size_t)r * L.Cout + co];
+            }
+        }
+    }
+    bpre = (L.b_off >= 0 && (int)threadIdx.x < L.Cout) ? a.params[L.b_off + threadIdx.x] : 0.f;
+}
+
+template <int K>
+__device__ __forceinline__ void net_w_store(const NetFwdArgs& a, const NetLayer& L, const float4 (&wpre)[kNetWPre],
+                                            float bpre, float* w_lds, int nt) {
+    const int cop = L.n_cot * L.co_t;
+    const float* w = a.params + L.w_off;
+    const int rows = K * K * L.Cin;
+    if ((L.Cout & 3) == 0 && (L.w_off & 3) == 0) {
+        const int c4n = cop >> 2, units = rows * c4n;
+#pragma unroll
+        for (int i = 0; i < kNetWPre; ++i) {
+            const int u = threadIdx.x + i * nt;
+            if (u < units) reinterpret_cast<float4*>(w_lds)[u] = wpre[i];
+        }
+        for (int u = threadIdx.x + kNetWPre * nt; u < units; u += nt) {  // filters larger than the prefetch registers
+            const int r = dv(u, c4n), c4 = u - r * c4n;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * c4 < L.Cout) v = *reinterpret_cast<const float4*>(w + (size_t)r * L.Cout + 4 * c4);
+            reinterpret_cast<float4*>(w_lds)[u] = v;
+        }
+    } else {
+        const int units = rows * cop;
+#pragma unroll
+        for (int i = 0; i < kNetWPre; ++i) {
+            const int u = threadIdx.x + i * nt;
+            if (u < units) w_lds[u] = wpre[i].x;
+        }
+        for (int u = threadIdx.x + kNetWPre * nt; u < units; u += nt) {
+            const int r = dv(u, cop), co = u - r * cop;
+            w_lds[u] = co < L.Cout ? w[(size_t)r * L.Cout + co] : 0.f;
+        }
+    }
+    if ((int)threadIdx.x < cop) w_lds[rows * cop + threadIdx.x] = bpre;
+}
+
+// ---- one layer, LDS -> LDS ---------------------------------------------------------------------------------------------
+template <int K, int UP, int CO_T, int POOL>
+__device__ __forceinline__ void net_layer_fwd(const NetFwdArgs& a, const NetLayer& L, float* smem, int ns, int nt) {
+    constexpr int PADL = (K - 1) / 2;
+    const int Ho = L.Hs * UP, Wo = L.Ws * UP;
+    const int tiles_x = Wo >> 1, tiles_y = Ho >> 1;
+    const int T = tiles_x * tiles_y;
+    const int cop = L.n_cot * CO_T;
+    const int ks = L.ks;
+    const int per_cot = a.S * T * ks;
+    const int total = L.n_cot * per_cot;
+    const float* in = smem + L.in_off;
+    float* out = smem + L.out_off;
+    const float* w_lds = smem + a.w_off;
+    const float* b_lds = w_lds + K * K * L.Cin * cop;
+    uint8_t* idx_lds = reinterpret_cast<uint8_t*>(smem + a.idx_off);
+    const int oh = L.out_halo;
+
+    for (int item0 = 0; item0 < total; item0 += nt) {
+        const int item = item0 + threadIdx.x;
+        const bool live = item < total;
+        int cot = 0, s = 0, ty = 0, tx = 0, kl = 0;
+        if (live) {
+            cot = item / per_cot;
+            int r = item - cot * per_cot;
+            kl = r % ks;
+            r /= ks;
+            s = r / T;
+            const int t = r - s * T;
+            ty = t / tiles_x;
+            tx = t - ty * tiles_x;
+        }
+        const bool work = live && s < ns;
+        float acc[2][2][CO_T];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < CO_T; ++c) acc[i][j][c] = 0.f;
+        if (work) {
+            const int r0 = (UP == 1 ? 2 * ty : ty) + L.in_halo + floordiv_c(-PADL, UP);
+            const int c0 = (UP == 1 ? 2 * tx : tx) + L.in_halo + floordiv_c(-PADL, UP);
+            conv_tile_fma<K, UP, CO_T>(acc, in + (size_t)s * L.Cin * L.in_plane, w_lds + cot * CO_T, L.in_plane, L.in_wp, r0,
+                                       c0, kl, L.Cin, ks, L.Cin, cop);
+        }
+        for (int o = 1; o < ks; o <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < CO_T; ++q) acc[i][j][q] += __shfl_xor(acc[i][j][q], o, 64);
+        }
+        if (work && kl == 0) {
+            const int cg = cot * CO_T;
+            if (POOL == 0) {
+#pragma unroll
+                for (int q = 0; q < CO_T; ++q)
+                    if (cg + q < L.Cout) {
+                        const float b = b_lds[cg + q];
+                        float* o = out + (size_t)(s * L.Cout + cg + q) * L.out_plane + (2 * ty + oh) * L.out_wp + 2 * tx + oh;
+                        o[0] = act_apply(acc[0][0][q] + b, L.act, L.alpha);
+                        o[1] = act_apply(acc[0][1][q] + b, L.act, L.alpha);
+                        o[L.out_wp] = act_apply(acc[1][0][q] + b, L.act, L.alpha);
+                        o[L.out_wp + 1] = act_apply(acc[1][1][q] + b, L.act, L.alpha);
+                    }
+            } else {
+                // max of the pre-activations, then one activation per window (all activations here are non-decreasing);
+                // relu's flattened ties record slot 0, the slot the unfused order would pick
+#pragma unroll
+                for (int q = 0; q < CO_T; ++q)
+                    if (cg + q < L.Cout) {
+                        float best = acc[0][0][q];
+                        uint32_t bi = 0;
+                        if (acc[0][1][q] > best) { best = acc[0][1][q]; bi = 1; }
+                        if (acc[1][0][q] > best) { best = acc[1][0][q]; bi = 2; }
+                        if (acc[1][1][q] > best) { best = acc[1][1][q]; bi = 3; }
+                        const float v = act_apply(best + b_lds[cg + q], L.act, L.alpha);
+                        if (L.act == SV_ACT_RELU && v <= 0.f) bi = 0;
+                        out[(size_t)(s * L.Cout + cg + q) * L.out_plane + (ty + oh) * L.out_wp + tx + oh] = v;
+                        idx_lds[((size_t)s * T + ty * tiles_x + tx) * L.Cout + cg + q] = (uint8_t)bi;
+                    }
+            }
+        }
+    }
+}
+
+// output arena (planar) -> global NHWC, argmax bytes -> global
+__device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer& L, const float* smem, int n0, int ns,
+                                             int nt) {
+    const int Ho = L.Hs * L.up, Wo = L.Ws * L.up;
+    const int Hout = L.pool ? Ho >> 1 : Ho, Wout = L.pool ? Wo >> 1 : Wo;
+    const int P = Hout * Wout;
+    const float* out = smem + L.out_off;
+    const int oh = L.out_halo;
+    if ((L.Cout & 3) == 0) {
+        const int c4n = L.Cout >> 2;
+        const int units = ns * P * c4n;
+        for (int u = threadIdx.x; u < units; u += nt) {
+            const int r = dv(u, c4n), c4 = u - r * c4n;
+            const int s = dv(r, P), p = r - s * P;
+            const int row = dv(p, Wout), col = p - row * Wout;
+            const float* q = out + (size_t)(s * L.Cout + 4 * c4) * L.out_plane + (row + oh) * L.out_wp + col + oh;
+            const float4 v = make_float4(q[0], q[L.out_plane], q[2 * L.out_plane], q[3 * L.out_plane]);
+            *reinterpret_cast<float4*>(L.y + ((size_t)n0 * P + r) * L.Cout + 4 * c4) = v;
+        }
+        if (L.pool && L.idx != nullptr) {
+            const uint32_t* ib = reinterpret_cast<const uint32_t*>(smem + a.idx_off);
+            for (int u = threadIdx.x; u < units; u += nt)
+                *reinterpret_cast<uint32_t*>(L.idx + ((size_t)n0 * P) * L.Cout + 4 * (size_t)u) = ib[u];
+        }
+    } else {
+        const int units = ns * P * L.Cout;
+        for (int u = threadIdx.x; u < units; u += nt) {
+            const int r = dv(u, L.Cout), c = u - r * L.Cout;
+            const int s = dv(r, P), p = r - s * P;
+            const int row = dv(p, Wout), col = p - row * Wout;
+            L.y[(size_t)n0 * P * L.Cout + u] = out[(size_t)(s * L.Cout + c) * L.out_plane + (row + oh) * L.out_wp + col + oh];
+        }
+        if (L.pool && L.idx != nullptr) {
+            const uint8_t* ib = reinterpret_cast<const uint8_t*>(smem + a.idx_off);
+            for (int u = threadIdx.x; u < units; u += nt) L.idx[(size_t)n0 * P * L.Cout + u] = ib[u];
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nt = blockDim.x;
+    float* w_lds = smem + a.w_off;
+    float4 wpre[kNetWPre];
+    float bpre;
+    for (int n0 = blockIdx.x * a.S; n0 < a.N; n0 += gridDim.x * a.S) {
+        const int ns = min(a.S, a.N - n0);
+        {
+            const NetLayer& L = a.L[0];
+            net_w_load<K>(a, L, wpre, bpre, nt);
+            __syncthreads();  // the previous pass is done with every arena
+            float4* z = reinterpret_cast<float4*>(smem + L.in_off);
+            const int nz = (a.S * L.Cin * L.in_plane) >> 2;
+            for (int i = threadIdx.x; i < nz; i += nt) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+            PlanarSrc src;
+            src.x = a.x; src.zy = nullptr; src.zidx = nullptr; src.mode = 0; src.zk = ActGradCoef{};
+            src.Hs = L.Hs; src.Ws = L.Ws; src.C = L.Cin;
+            const PlanarDst dst{L.Cin, L.in_plane, L.in_wp, L.in_halo};
+            stage_pass(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
+        }
+        for (int l = 0; l < a.n_layers; ++l) {
+            const NetLayer& L = a.L[l];
+            // [A]
+            float4* z = reinterpret_cast<float4*>(smem + L.out_off);
+            const int nz = (a.S * L.Cout * L.out_plane) >> 2;
+            for (int i = threadIdx.x; i < nz; i += nt) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            net_w_store<K>(a, L, wpre, bpre, w_lds, nt);
+            __syncthreads();
+            // [B]
+            if (l + 1 < a.n_layers) net_w_load<K>(a, a.L[l + 1], wpre, bpre, nt);
+            // [C]
+            if (L.up == 1) {
+                if (L.co_t == 8) {
+                    if (L.pool) net_layer_fwd<K, 1, 8, 1>(a, L, smem, ns, nt);
+                    else net_layer_fwd<K, 1, 8, 0>(a, L, smem, ns, nt);
+                } else {
+                    if (L.pool) net_layer_fwd<K, 1, 4, 1>(a, L, smem, ns, nt);
+                    else net_layer_fwd<K, 1, 4, 0>(a, L, smem, ns, nt);
+                }
+            } else {
+                if (L.co_t == 8) {
+                    if (L.pool) net_layer_fwd<K, 2, 8, 1>(a, L, smem, ns, nt);
+                    else net_layer_fwd<K, 2, 8, 0>(a, L, smem, ns, nt);
+                } else {
+                    if (L.pool) net_layer_fwd<K, 2, 4, 1>(a, L, smem, ns, nt);
+                    else net_layer_fwd<K, 2, 4, 0>(a, L, smem, ns, nt);
+                }
+            }
+            __syncthreads();
+            // [E]
+            net_copy_out(a, L, smem, n0, ns, nt);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ host side
+struct NetPlan {
+    bool ok;
+    int S, nt, grid;
+    size_t lds_bytes;
+    NetFwdArgs args;
+};
+
+constexpr size_t kNetLdsPerBlock = 78 * 1024;  // two workgroups share a CU's 160 KiB
+
+static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int N, int H, int W, int S, int nt,
+                    size_t* lds_floats) {
+    // activation i is the input of layer i (i = n_layers: the network output); it lives in arena i % 2
+    size_t arena[2] = {0, 0};
+    size_t w_floats = 0, idx_bytes = 0;
+    int h = H, w = W;
+    for (int l = 0; l <= n_layers; ++l) {
+        int C, plane, wp, halo;
+        if (l < n_layers) {
+            C = layers[l].Cin; halo = 1;
+            wp = (w + 2 * halo + 3) & ~3;
+            plane = (h + 2 * halo) * wp + 4;
+        } else {
+            C = layers[n_layers - 1].Cout; halo = 0;
+            wp = w;
+            plane = (h * w + 3) & ~3;
+        }
+        const size_t need = (size_t)S * C * plane;
+        if (need > arena[l & 1]) arena[l & 1] = need;
+        if (l > 0) {
+            NetLayer& P = a.L[l - 1];
+            P.out_plane = plane; P.out_wp = wp; P.out_halo = halo;
+        }
+        if (l == n_layers) break;
+        const sv_net_layer& s = layers[l];
+        NetLayer& L = a.L[l];
+        L.Cin = s.Cin; L.Cout = s.Cout; L.Hs = h; L.Ws = w; L.up = s.up; L.pool = s.pool; L.act = s.act; L.alpha = s.alpha;
+        L.w_off = (int)s.w_off; L.b_off = (int)s.b_off; L.in_plane = plane; L.in_wp = wp; L.in_halo = halo;
+        L.y = (float*)s.y; L.idx = s.idx;
+        L.co_t = s.Cout > 4 ? 8 : 4;
+        L.n_cot = (s.Cout + L.co_t - 1) / L.co_t;
+        const int Ho = h * s.up, Wo = w * s.up;
+        const int T = (Ho / 2) * (Wo / 2);
+        int ks = 1;
+        while (ks < 8 && s.Cin / (2 * ks) >= 2 && (int64_t)L.n_cot * S * T * ks < nt) ks <<= 1;
+        L.ks = ks;
+        const size_t wf = (size_t)9 * s.Cin * L.n_cot * L.co_t + L.n_cot * L.co_t;
+        if (wf > w_floats) w_floats = wf;
+        if (s.pool) {
+            const size_t ib = (size_t)S * T * s.Cout;
+            if (ib > idx_bytes) idx_bytes = ib;
+        }
+        h = s.pool ? Ho / 2 : Ho;
+        w = s.pool ? Wo / 2 : Wo;
+    }
+    auto r4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
+    const size_t o0 = 0, o1 = r4(arena[0]), ow = o1 + r4(arena[1]), oi = ow + r4(w_floats);
+    for (int l = 0; l < n_layers; ++l) {
+        a.L[l].in_off = (int)((l & 1) ? o1 : o0);
+        a.L[l].out_off = (int)((l & 1) ? o0 : o1);
+    }
+    a.w_off = (int)ow;
+    a.idx_off = (int)oi;
+    *lds_floats = oi + r4((idx_bytes + 3) / 4);
+    return 0;
+}
+
+int net_validate(const sv_net_layer* layers, int n_layers, int N, int H, int W, const char* who) {
+    if (layers == nullptr || n_layers < 1 || n_layers > kMaxNetLayers)
+        return fail(SV_E_INVALID, "%s: 1..%d layers expected", who, kMaxNetLayers);
+    if (N < 1 || H < 1 || W < 1) return fail(SV_E_INVALID, "%s: empty input", who);
+    int h = H, w = W, c = layers[0].Cin;
+    for (int l = 0; l < n_layers; ++l) {
+        const sv_net_layer& s = layers[l];
+        if (s.K != 3) return fail(SV_E_UNSUPPORTED, "%s: layer %d: only 3x3 kernels", who, l);
+        if (s.Cin != c || s.Cin < 1 || s.Cout < 1) return fail(SV_E_INVALID, "%s: layer %d: channel mismatch", who, l);
+        if (!(s.up == 1 || s.up == 2) || !(s.pool == 0 || s.pool == 1))
+            return fail(SV_E_INVALID, "%s: layer %d: up must be 1|2, pool 0|1", who, l);
+        const int Ho = h * s.up, Wo = w * s.up;
+        if ((Ho & 1) || (Wo & 1)) return fail(SV_E_UNSUPPORTED, "%s: layer %d: odd conv extent %dx%d", who, l, Ho, Wo);
+        if (s.w_off < 0 || s.w_off > INT32_MAX || s.b_off > INT32_MAX)
+            return fail(SV_E_INVALID, "%s: layer %d: parameter offsets out of range", who, l);
+        h = s.pool ? Ho / 2 : Ho;
+        w = s.pool ? Wo / 2 : Wo;
+        c = s.Cout;
+    }
+    return SV_OK;
+}
+
+NetPlan plan_net_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int W) {
+    NetPlan p{};
+    p.ok = false;
+    p.nt = 256;
+    for (int S = 4; S >= 1; --S) {
+        if (S == 3) continue;
+        size_t fl = 0;
+        NetFwdArgs a{};
+        net_fill(a, layers, n_layers, N, H, W, S, p.nt, &fl);
+        if (fl * sizeof(float) <= kNetLdsPerBlock) {
+            p.S = S > N ? N : S;
+            if (p.S != S) net_fill(a, layers, n_layers, N, H, W, p.S, p.nt, &fl);
+            p.args = a;
+            p.lds_bytes = (fl * sizeof(float) + 15) & ~(size_t)15;
+            p.ok = true;
+            break;
+        }
+    }
+    if (!p.ok) return p;
+    const int passes = (N + p.S - 1) / p.S;
+    p.grid = passes < 512 ? passes : 512;
+    p.args.N = N; p.args.S = p.S; p.args.n_layers = n_layers;
+    return p;
+}
+
+static int net_enable_lds(size_t bytes) {
+    static size_t enabled = 0;  // benign race: the attribute is idempotent
+    if (bytes <= enabled) return SV_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&net_fwd_s1<3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNetLdsPerBlock);
+    if (e != hipSuccess) return fail(SV_E_LAUNCH, "net_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+    enabled = kNetLdsPerBlock;
+    return SV_OK;
+}
+
+}  // namespace sv
+
+using namespace sv;
+
+extern "C" {
+
+int sv_convnet_supported(const sv_net_layer* layers, int n_layers, int N, int H, int W) {
+    if (net_validate(layers, n_layers, N, H, W, "sv_convnet_supported")) return 0;
+    return plan_net_fwd(layers, n_layers, N, H, W).ok ? 1 : 0;
+}
+
+int sv_convnet_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
+                   int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_convnet_fwd");
+    int rc = net_validate(layers, n_layers, N, H, W, "sv_convnet_fwd");
+    if (rc) return rc;
+    SV_REQUIRE(x && params, "sv_convnet_fwd: null tensor");
+    for (int l = 0; l < n_layers; ++l) SV_REQUIRE(layers[l].y != nullptr, "sv_convnet_fwd: layer %d has no output buffer", l);
+    NetPlan p = plan_net_fwd(layers, n_layers, N, H, W);
+    if (!p.ok) return fail(SV_E_UNSUPPORTED, "sv_convnet_fwd: the activations of one sample do not fit the LDS arenas");
+    rc = net_enable_lds(p.lds_bytes);
+    if (rc) return rc;
+    p.args.x = (const float*)x;
+    p.args.params = (const float*)params;
+    hipLaunchKernelGGL((net_fwd_s1<3>), dim3((unsigned)p.grid), dim3((unsigned)p.nt), p.lds_bytes, to_stream(stream), p.args);
+    return check_launch("net_fwd_s1");
+}
+
+}  // extern "C"

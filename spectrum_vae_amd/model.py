@@ -77,6 +77,10 @@ class Model(Layer):
         self._reducer = None  # data-parallel gradient reducer (parallel.GradReducer)
         self._graphs: Dict[tuple, object] = {}
         self.use_graphs = True
+        # Run the whole forward as ONE launch when the model is a plain chain of fusable 3x3 convs (see
+        # ``_conv_chain``); the per-layer buffers are filled exactly as the per-layer path fills them.
+        self.use_net_fused = True
+        self._chain_cache: Dict[int, object] = {}
         # Optional: run the weight-gradient kernels, the gradient zero-fill and the optimizer's schedule update on
         # extra HIP streams beside the forward / input-gradient chain (fit / train_on_device_batch only).  Off by
         # default: at the shapes measured so far every conv launch already occupies the LDS of all CUs, so the
@@ -228,6 +232,68 @@ class Model(Layer):
     def call(self, x, training: bool = False):
         return self.__call__(x, training=training)
 
+    # ------------------------------------------------------------------ whole-network forward
+    def _sequentials(self) -> Optional[List[Sequential]]:
+        """The Sequential stacks whose composition IS this model's forward, or None when the forward is not a chain."""
+        st = getattr(self, "_stack", None)
+        return [st] if isinstance(st, Sequential) else None
+
+    def _conv_chain(self):
+        """Conv layers in execution order when every layer of the forward is a fused 3x3 stride-1 SAME Conv2D (with its
+        folded UpSampling2D / MaxPooling2D neighbours), else None."""
+        from .nn import Conv2D, Dropout, InputLayer, MaxPooling2D, UpSampling2D
+        seqs = self._sequentials()
+        if not seqs:
+            return None
+        chain = []
+        for sq in seqs:
+            for l in sq.layers:
+                if isinstance(l, InputLayer) or (isinstance(l, (MaxPooling2D, UpSampling2D)) and l.folded):
+                    continue
+                if isinstance(l, Dropout) and l.rate == 0:
+                    continue
+                if (type(l) is Conv2D and l.fused_bwd and l.kernel_size == (3, 3) and l.up[0] == l.up[1]
+                        and l.kernel.owner is self):
+                    chain.append(l)
+                    continue
+                return None
+        return chain or None
+
+    def _net_forward(self, ctx, x: torch.Tensor):
+        """One-launch forward; returns None when the model (or this batch size) is outside the fused family."""
+        n = x.shape[0]
+        key = (n, ctx.slot if not isinstance(ctx.slot, int) else "train%d" % ctx.slot)
+        plan = self._chain_cache.get(key)
+        if plan is None:
+            chain = self._conv_chain()
+            plan = False
+            if chain:
+                specs, bufs, prev = [], [], x
+                for l in chain:
+                    ho, wo, cout = l.output_shape_
+                    shp = (n, ho // 2, wo // 2, cout) if l.pool is not None else (n, ho, wo, cout)
+                    y = ctx.buf(l, "y", shp)
+                    idx = ctx.buf(l, "idx", shp, torch.uint8) if l.pool is not None else None
+                    specs.append(dict(Cin=l.input_shape_[2], Cout=cout, K=3, up=l.up[0], pool=int(l.pool is not None),
+                                      act=l.act, alpha=l.alpha, w_off=l.kernel.offset,
+                                      b_off=l.bias.offset if l.bias is not None else -1, y=y, idx=idx))
+                    bufs.append((l, y, idx))
+                arr = ops.net_layers(specs)
+                h, w = chain[0].input_shape_[0], chain[0].input_shape_[1]
+                if ops.convnet_supported(arr, n, h, w):
+                    plan = (arr, bufs, h, w)
+            self._chain_cache[key] = plan
+        if plan is False:
+            return None
+        arr, bufs, h, w = plan
+        ops.convnet_fwd(arr, n, h, w, x, self._params)
+        prev = x
+        for l, y, idx in bufs:
+            if ctx.training:
+                ctx.saved[id(l)] = {"x": prev, "y": y, "idx": idx} if idx is not None else {"x": prev, "y": y}
+            prev = y
+        return prev
+
     def forward_raw(self, x: torch.Tensor, training: bool, side=None) -> torch.Tensor:
         """Forward on a prepared device tensor; the result aliases the model's buffer pool.  ``side``: stream
         the backward pass of this call may use for its weight-gradient kernels (the caller joins it)."""
@@ -237,6 +303,10 @@ class Model(Layer):
             self._calls.append(ctx)
         else:
             ctx = CallCtx(self._pool, "infer", False)
+        if self.use_net_fused:
+            y = self._net_forward(ctx, x)
+            if y is not None:
+                return y
         return self.forward(ctx, x)
 
     def backward_raw(self, dy: torch.Tensor, call: int = -1, need_dx: bool = False):

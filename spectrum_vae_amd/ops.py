@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT, F32, ConvGeom, check, lib
+from ._lib import ACT, F32, ConvGeom, NetLayer, check, lib
 
 
 def _stream() -> int:
@@ -94,6 +94,27 @@ def conv2d_fused_supported(g: ConvGeom, pooled: bool) -> bool:
 def conv2d_pool_fwd(g: ConvGeom, x, w, bias, y_pooled, idx, act: str, alpha: float):
     check(lib.sv_conv2d_pool_fwd(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y_pooled), _ptr(idx, torch.uint8),
                                  ACT[act], alpha, F32, _stream()), "sv_conv2d_pool_fwd")
+
+
+def net_layers(specs) -> "C.Array":
+    """ctypes array of ``sv_net_layer`` from dicts with Cin, Cout, K, up, pool, act, alpha, w_off, b_off, y, idx
+    (y / idx: tensors or None)."""
+    arr = (NetLayer * len(specs))()
+    for a, d in zip(arr, specs):
+        a.Cin, a.Cout, a.K, a.up, a.pool = d["Cin"], d["Cout"], d["K"], d["up"], d["pool"]
+        a.act, a.alpha, a.reserved = ACT[d["act"]], float(d["alpha"] or 0.0), 0
+        a.w_off, a.b_off = d["w_off"], d["b_off"]
+        a.y = _ptr(d.get("y"))
+        a.idx = _ptr(d.get("idx"), torch.uint8)
+    return arr
+
+
+def convnet_supported(arr, n: int, h: int, w: int) -> bool:
+    return bool(lib.sv_convnet_supported(arr, len(arr), n, h, w))
+
+
+def convnet_fwd(arr, n: int, h: int, w: int, x, params):
+    check(lib.sv_convnet_fwd(arr, len(arr), n, h, w, _ptr(x), _ptr(params), F32, _stream()), "sv_convnet_fwd")
 
 
 def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float, ws: Optional[torch.Tensor]):

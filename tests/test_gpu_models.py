@@ -425,3 +425,36 @@ def test_keras_surface_apply_gradients_and_losses():
         assert np.allclose(v.numpy(), a - 1e-2 * 1.0 / (1.0 + 1e-7 / np.sqrt(1 - 0.999)), atol=1e-6)
     per_pixel = losses.mse(pred, x)
     assert tuple(per_pixel.shape) == (8, 32, 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 64, 1100])
+def test_whole_network_forward_matches_per_layer_path_and_oracle(n):
+    """The one-launch forward fills every per-layer buffer (activations, argmax) exactly like the per-layer path."""
+    from spectrum_vae_amd import autoencoder
+    from spectrum_vae_amd.losses import to_device_f32
+    x = data(n, seed=7 + n)
+    outs = {}
+    for fused in (True, False):
+        model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+        model.use_net_fused = fused
+        model.build((None, 32, 32, 3))
+        model._materialize()
+        chain = model._conv_chain()
+        assert chain is not None and len(chain) == 6
+        model.forward_raw(to_device_f32(x), True)
+        ctx = model._calls[-1]
+        outs[fused] = [(ctx.saved[id(l)]["y"].cpu().numpy().copy(),
+                        ctx.saved[id(l)]["idx"].cpu().numpy().copy() if "idx" in ctx.saved[id(l)] else None) for l in chain]
+        if fused:
+            assert model._chain_cache and all(v is not False for v in model._chain_cache.values())
+            pred_infer = model.predict(x[: min(n, 40)], batch_size=16)
+            enc, dec = omodels.caepadded(**RUN_MODEL_DEFAULTS)
+            ref = RefSequential(enc + dec, (32, 32, 3))
+            load_into_ref(ref, model)
+            want = ref(torch.from_numpy(x[: min(n, 40)]), training=False).detach().numpy()
+            assert rel(pred_infer, want) < 1e-4
+    for (yf, idf), (yu, idu) in zip(outs[True], outs[False]):
+        assert rel(yf, yu) < 1e-5
+        if idf is not None:
+            assert (idf != idu).mean() < 1e-4  # a differing slot needs a tie within rounding
