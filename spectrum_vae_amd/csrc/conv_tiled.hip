@@ -82,50 +82,47 @@ __device__ __forceinline__ WJob make_wjob(const TiledArgs& a, int ci0, int cic, 
     }
     return j;
 }
-template <int K, bool P2>
-__device__ __forceinline__ void w_pass_t(const TiledArgs& a, const WJob& j, float* w_lds, int nt) {
-    const int lgcic = lg2(j.cic), lgcoc = lg2(j.coc);
+template <int K, int CO_T>
+__device__ __forceinline__ void w_pass(const TiledArgs& a, const WJob& j, float* w_lds, int nt) {
+    const FDiv fcic = fd_make(j.cic), fcoc = fd_make(j.coc);
     if (j.kind == 0) {
-        const int c4n = j.coc >> 2, lg4 = lg2(c4n);
+        const int c4n = j.coc >> 2;
+        const FDiv f4 = fd_make(c4n);
 #pragma unroll 4
         for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int r = dvt<P2>(u, c4n, lg4), co4 = u - r * c4n;
-            const int tap = dvt<P2>(r, j.cic, lgcic), c = r - tap * j.cic;
+            const int r = fd(u, f4), co4 = u - r * c4n;
+            const int tap = fd(r, fcic), c = r - tap * j.cic;
             const float4 v = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.Cin + j.ci0 + c) * a.Cout + j.co_base + 4 * co4);
-            *reinterpret_cast<float4*>(w_lds + (tap * a.cic + c) * j.cop + 4 * co4) = v;
+            *reinterpret_cast<float4*>(w_lds + w_lds_index<K, CO_T>(4 * co4, c, tap, a.cic)) = v;
         }
     } else if (j.kind == 1) {
-        const int c4n = j.cic >> 2, lg4 = lg2(c4n);
+        const int c4n = j.cic >> 2;
+        const FDiv f4 = fd_make(c4n);
 #pragma unroll 4
         for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int r = dvt<P2>(u, c4n, lg4), c4 = u - r * c4n;
-            const int tap = dvt<P2>(r, j.coc, lgcoc), co = r - tap * j.coc;
+            const int r = fd(u, f4), c4 = u - r * c4n;
+            const int tap = fd(r, fcoc), co = r - tap * j.coc;
             const float4 v = *reinterpret_cast<const float4*>(a.w + ((size_t)(K * K - 1 - tap) * a.Cout + j.co_base + co) * a.Cin +
                                                               j.ci0 + 4 * c4);
-            float* q = w_lds + (tap * a.cic + 4 * c4) * j.cop + co;
-            q[0] = v.x; q[j.cop] = v.y; q[2 * j.cop] = v.z; q[3 * j.cop] = v.w;
+            float* q = w_lds + w_lds_index<K, CO_T>(co, 4 * c4, tap, a.cic);
+            q[0] = v.x; q[K * K * CO_T] = v.y; q[2 * K * K * CO_T] = v.z; q[3 * K * K * CO_T] = v.w;
         }
     } else if (a.wflip) {
 #pragma unroll 4
         for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int r = dvt<P2>(u, j.coc, lgcoc), co = u - r * j.coc;
-            const int tap = dvt<P2>(r, j.cic, lgcic), c = r - tap * j.cic;
-            w_lds[(tap * a.cic + c) * j.cop + co] = a.w[((size_t)(K * K - 1 - tap) * a.Cout + j.co_base + co) * a.Cin + j.ci0 + c];
+            const int r = fd(u, fcoc), co = u - r * j.coc;
+            const int tap = fd(r, fcic), c = r - tap * j.cic;
+            w_lds[w_lds_index<K, CO_T>(co, c, tap, a.cic)] =
+                a.w[((size_t)(K * K - 1 - tap) * a.Cout + j.co_base + co) * a.Cin + j.ci0 + c];
         }
     } else {
 #pragma unroll 4
         for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int r = dvt<P2>(u, j.coc, lgcoc), co = u - r * j.coc;
-            const int tap = dvt<P2>(r, j.cic, lgcic), c = r - tap * j.cic;
-            w_lds[(tap * a.cic + c) * j.cop + co] = a.w[((size_t)tap * a.Cin + j.ci0 + c) * a.Cout + j.co_base + co];
+            const int r = fd(u, fcoc), co = u - r * j.coc;
+            const int tap = fd(r, fcic), c = r - tap * j.cic;
+            w_lds[w_lds_index<K, CO_T>(co, c, tap, a.cic)] = a.w[((size_t)tap * a.Cin + j.ci0 + c) * a.Cout + j.co_base + co];
         }
     }
-}
-template <int K>
-__device__ __forceinline__ void w_pass(const TiledArgs& a, const WJob& j, float* w_lds, int nt) {
-    const int c4n = j.kind == 0 ? j.coc >> 2 : j.kind == 1 ? j.cic >> 2 : 1;
-    if (is_p2(j.cic) && is_p2(j.coc) && is_p2(c4n)) w_pass_t<K, true>(a, j, w_lds, nt);
-    else w_pass_t<K, false>(a, j, w_lds, nt);
 }
 
 template <int K, int UP, int CO_T, int EPI>
@@ -146,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
     const int per_cot = a.S * T * ks;              // work items per channel tile in one pass
     const int total = n_cot * per_cot;
     const bool one_chunk = a.cic >= a.Cin;
+    const FDiv f_percot = fd_make(per_cot), f_ks = fd_make(ks), f_T = fd_make(T), f_tx = fd_make(tiles_x);
 
     PlanarSrc src;
     src.x = a.x; src.zy = a.zy; src.zidx = a.zidx; src.mode = a.zmode; src.zk = a.zk; src.C = a.Cin;
@@ -164,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
         SV_MARK(1);
         const int ns = min(a.S, a.N - n0);
         const int cic0 = min(a.cic, a.Cin);
-        w_pass<K>(a, make_wjob(a, 0, cic0, co_base, coc, cop, K * K), w_lds, nt);
+        w_pass<K, CO_T>(a, make_wjob(a, 0, cic0, co_base, coc, cop, K * K), w_lds, nt);
         stage_pass(src, dst, make_stage_job(src, n0, ns, 0, cic0), in_lds, nt);
     }
     bool prestaged = true;
@@ -178,13 +176,13 @@ __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
             const bool live = item < total;
             int cot = 0, s = 0, ty = 0, tx = 0, kl = 0;
             if (live) {
-                cot = item / per_cot;
+                cot = fd(item, f_percot);
                 int r = item - cot * per_cot;
-                kl = r % ks;  // which slice of the input channels this lane sums
-                r /= ks;
-                s = r / T;
-                const int t = r - s * T;
-                ty = t / tiles_x;
+                const int r1 = fd(r, f_ks);
+                kl = r - r1 * ks;  // which slice of the input channels this lane sums
+                s = fd(r1, f_T);
+                const int t = r1 - s * T;
+                ty = fd(t, f_tx);
                 tx = t - ty * tiles_x;
             }
             const bool work = live && s < ns;
@@ -201,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
                 if (!prestaged) {
                     __syncthreads();  // previous chunk / item pass is done with LDS
                     if (item0 == 0 || !one_chunk) stage_pass(src, dst, make_stage_job(src, n0, ns, ci0, cic), in_lds, nt);
-                    if (!one_chunk) w_pass<K>(a, make_wjob(a, ci0, cic, co_base, coc, cop, K * K), w_lds, nt);
+                    if (!one_chunk) w_pass<K, CO_T>(a, make_wjob(a, ci0, cic, co_base, coc, cop, K * K), w_lds, nt);
                 }
                 prestaged = false;
                 __syncthreads();
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
                     // patch origin in the padded stored image (even column when UP == 1: 8-byte aligned rows)
                     const int r0 = (UP == 1 ? 2 * ty : ty) + a.halo + floordiv_c(-PADL, UP);
                     const int c0 = (UP == 1 ? 2 * tx : tx) + a.halo + floordiv_c(-PADL, UP);
-                    conv_tile_fma<K, UP, CO_T>(acc, img, w_lds + cot * CO_T, a.plane, a.wp, r0, c0, kl, cic, ks, a.cic, cop);
+                    conv_tile_fma<K, UP, CO_T>(acc, img, w_lds + cot * a.cic * K * K * CO_T, a.plane, a.wp, r0, c0, kl, cic, ks);
                 }
             }
             SV_MARK(3);
@@ -300,28 +298,30 @@ __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
                 const int rows = ns * P;  // one row = the coc channels of one pixel
                 if ((coc & 3) == 0 && (a.Cout & 3) == 0) {
                     const int c4n = coc >> 2;
+                    const FDiv f4 = fd_make(c4n);
                     for (int u = threadIdx.x; u < rows * c4n; u += nt) {
-                        const int r = dv(u, c4n), c4 = u - r * c4n;
+                        const int r = fd(u, f4), c4 = u - r * c4n;
                         const float4 v = *reinterpret_cast<const float4*>(smem + (size_t)r * cs + 4 * c4);
                         *reinterpret_cast<float4*>(a.y + ((size_t)n0 * P + r) * a.Cout + co_base + 4 * c4) = v;
                     }
                     if (EPI == EPI_MAXPOOL && a.idx != nullptr) {
                         const uint32_t* ob = reinterpret_cast<const uint32_t*>(smem + (size_t)a.S * P * cs);
                         for (int u = threadIdx.x; u < rows * c4n; u += nt) {
-                            const int r = dv(u, c4n), c4 = u - r * c4n;
+                            const int r = fd(u, f4), c4 = u - r * c4n;
                             *reinterpret_cast<uint32_t*>(a.idx + ((size_t)n0 * P + r) * a.Cout + co_base + 4 * c4) =
                                 ob[((size_t)r * cop) / 4 + c4];
                         }
                     }
                 } else {
+                    const FDiv fc = fd_make(coc);
                     for (int u = threadIdx.x; u < rows * coc; u += nt) {
-                        const int r = dv(u, coc), c = u - r * coc;
+                        const int r = fd(u, fc), c = u - r * coc;
                         a.y[((size_t)n0 * P + r) * a.Cout + co_base + c] = smem[(size_t)r * cs + c];
                     }
                     if (EPI == EPI_MAXPOOL && a.idx != nullptr) {
                         const uint8_t* ob = reinterpret_cast<const uint8_t*>(smem + (size_t)a.S * P * cs);
                         for (int u = threadIdx.x; u < rows * coc; u += nt) {
-                            const int r = dv(u, coc), c = u - r * coc;
+                            const int r = fd(u, fc), c = u - r * coc;
                             a.idx[((size_t)n0 * P + r) * a.Cout + co_base + c] = ob[(size_t)r * cop + c];
                         }
                     }
@@ -545,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
     const int cot = live ? combo - cil * n_cot : 0;
     const int strips_x = a.Wo >> 2;
     const int strips = a.Ho * strips_x;
+    const FDiv f_strips = fd_make(strips), f_sx = fd_make(strips_x);
 
     float acc[K * K][CO_T];
     float accb[CO_T];
@@ -581,9 +582,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
         SV_MARK(2);
         if (live) {
             for (int w = pg; w < ns * strips; w += PG) {
-                const int ss = w / strips;
+                const int ss = fd(w, f_strips);
                 const int st = w - ss * strips;
-                const int oh = st / strips_x;
+                const int oh = fd(st, f_sx);
                 const int ow0 = (st - oh * strips_x) << 2;
                 // x rows oh .. oh+K-1 and cols ow0 .. ow0+K+2 of the padded image
                 const float* xp = x_lds + (ss * a.cib + cil) * a.xplane + oh * a.xwp + ow0;

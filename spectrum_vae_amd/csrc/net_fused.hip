@@ -14,6 +14,17 @@
 
 namespace sv {
 
+#ifdef SV_TRACE
+// diagnostic builds: thread 0 of every workgroup stores the 100 MHz wall clock at phase marks, 32 slots per workgroup
+__device__ unsigned long long* g_net_trace = nullptr;
+__device__ __forceinline__ void net_mark(int slot) {
+    if (threadIdx.x == 0 && g_net_trace != nullptr && slot < 32) g_net_trace[(size_t)blockIdx.x * 32 + slot] = wall_clock64();
+}
+#define NET_MARK(slot) net_mark(slot)
+#else
+#define NET_MARK(slot)
+#endif
+
 constexpr int kMaxNetLayers = 12;
 constexpr int kNetWPre = 6;  // float4 registers per thread holding the next layer's filters
 
@@ -50,23 +61,25 @@ __device__ __forceinline__ void net_w_load(const NetFwdArgs& a, const NetLayer& 
     const int rows = K * K * L.Cin;
     if ((L.Cout & 3) == 0 && (L.w_off & 3) == 0) {
         const int c4n = cop >> 2, units = rows * c4n;
+        const FDiv f4 = fd_make(c4n);
 #pragma unroll
         for (int i = 0; i < kNetWPre; ++i) {
             const int u = threadIdx.x + i * nt;
             wpre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (u < units) {
-                const int r = dv(u, c4n), c4 = u - r * c4n;
+                const int r = fd(u, f4), c4 = u - r * c4n;
                 if (4 * c4 < L.Cout) wpre[i] = *reinterpret_cast<const float4*>(w + (size_t)r * L.Cout + 4 * c4);
             }
         }
     } else {
         const int units = rows * cop;
+        const FDiv fcop = fd_make(cop);
 #pragma unroll
         for (int i = 0; i < kNetWPre; ++i) {
             const int u = threadIdx.x + i * nt;
             wpre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (u < units) {
-                const int r = dv(u, cop), co = u - r * cop;
+                const int r = fd(u, fcop), co = u - r * cop;
                 if (co < L.Cout) wpre[i].x = w[(size_t)r * L.Cout + co];
             }
         }
@@ -74,35 +87,54 @@ __device__ __forceinline__ void net_w_load(const NetFwdArgs& a, const NetLayer& 
     bpre = (L.b_off >= 0 && (int)threadIdx.x < L.Cout) ? a.params[L.b_off + threadIdx.x] : 0.f;
 }
 
+// LDS filter layout [channel tile][ci][tap][co_t] for a runtime co_t
+template <int K>
+__device__ __forceinline__ int net_w_index(const NetLayer& L, int co, int c, int tap) {
+    return L.co_t == 8 ? w_lds_index<K, 8>(co, c, tap, L.Cin) : w_lds_index<K, 4>(co, c, tap, L.Cin);
+}
+
 template <int K>
 __device__ __forceinline__ void net_w_store(const NetFwdArgs& a, const NetLayer& L, const float4 (&wpre)[kNetWPre],
                                             float bpre, float* w_lds, int nt) {
     const int cop = L.n_cot * L.co_t;
+    const FDiv fCin = fd_make(L.Cin);
     const float* w = a.params + L.w_off;
     const int rows = K * K * L.Cin;
     if ((L.Cout & 3) == 0 && (L.w_off & 3) == 0) {
         const int c4n = cop >> 2, units = rows * c4n;
+        const FDiv f4 = fd_make(c4n);
 #pragma unroll
         for (int i = 0; i < kNetWPre; ++i) {
             const int u = threadIdx.x + i * nt;
-            if (u < units) reinterpret_cast<float4*>(w_lds)[u] = wpre[i];
+            if (u < units) {
+                const int r = fd(u, f4), c4 = u - r * c4n;
+                const int tap = fd(r, fCin), c = r - tap * L.Cin;
+                *reinterpret_cast<float4*>(w_lds + net_w_index<K>(L, 4 * c4, c, tap)) = wpre[i];
+            }
         }
         for (int u = threadIdx.x + kNetWPre * nt; u < units; u += nt) {  // filters larger than the prefetch registers
-            const int r = dv(u, c4n), c4 = u - r * c4n;
+            const int r = fd(u, f4), c4 = u - r * c4n;
+            const int tap = fd(r, fCin), c = r - tap * L.Cin;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (4 * c4 < L.Cout) v = *reinterpret_cast<const float4*>(w + (size_t)r * L.Cout + 4 * c4);
-            reinterpret_cast<float4*>(w_lds)[u] = v;
+            *reinterpret_cast<float4*>(w_lds + net_w_index<K>(L, 4 * c4, c, tap)) = v;
         }
     } else {
         const int units = rows * cop;
+        const FDiv fcop = fd_make(cop);
 #pragma unroll
         for (int i = 0; i < kNetWPre; ++i) {
             const int u = threadIdx.x + i * nt;
-            if (u < units) w_lds[u] = wpre[i].x;
+            if (u < units) {
+                const int r = fd(u, fcop), co = u - r * cop;
+                const int tap = fd(r, fCin), c = r - tap * L.Cin;
+                w_lds[net_w_index<K>(L, co, c, tap)] = wpre[i].x;
+            }
         }
         for (int u = threadIdx.x + kNetWPre * nt; u < units; u += nt) {
-            const int r = dv(u, cop), co = u - r * cop;
-            w_lds[u] = co < L.Cout ? w[(size_t)r * L.Cout + co] : 0.f;
+            const int r = fd(u, fcop), co = u - r * cop;
+            const int tap = fd(r, fCin), c = r - tap * L.Cin;
+            w_lds[net_w_index<K>(L, co, c, tap)] = co < L.Cout ? w[(size_t)r * L.Cout + co] : 0.f;
         }
     }
     if ((int)threadIdx.x < cop) w_lds[rows * cop + threadIdx.x] = bpre;
@@ -125,19 +157,20 @@ __device__ __forceinline__ void net_layer_fwd(const NetFwdArgs& a, const NetLaye
     const float* b_lds = w_lds + K * K * L.Cin * cop;
     uint8_t* idx_lds = reinterpret_cast<uint8_t*>(smem + a.idx_off);
     const int oh = L.out_halo;
+    const FDiv f_percot = fd_make(per_cot), f_ks = fd_make(ks), f_T = fd_make(T), f_tx = fd_make(tiles_x);
 
     for (int item0 = 0; item0 < total; item0 += nt) {
         const int item = item0 + threadIdx.x;
         const bool live = item < total;
         int cot = 0, s = 0, ty = 0, tx = 0, kl = 0;
         if (live) {
-            cot = item / per_cot;
-            int r = item - cot * per_cot;
-            kl = r % ks;
-            r /= ks;
-            s = r / T;
-            const int t = r - s * T;
-            ty = t / tiles_x;
+            cot = fd(item, f_percot);
+            const int r = item - cot * per_cot;
+            const int r1 = fd(r, f_ks);
+            kl = r - r1 * ks;
+            s = fd(r1, f_T);
+            const int t = r1 - s * T;
+            ty = fd(t, f_tx);
             tx = t - ty * tiles_x;
         }
         const bool work = live && s < ns;
@@ -151,8 +184,8 @@ __device__ __forceinline__ void net_layer_fwd(const NetFwdArgs& a, const NetLaye
         if (work) {
             const int r0 = (UP == 1 ? 2 * ty : ty) + L.in_halo + floordiv_c(-PADL, UP);
             const int c0 = (UP == 1 ? 2 * tx : tx) + L.in_halo + floordiv_c(-PADL, UP);
-            conv_tile_fma<K, UP, CO_T>(acc, in + (size_t)s * L.Cin * L.in_plane, w_lds + cot * CO_T, L.in_plane, L.in_wp, r0,
-                                       c0, kl, L.Cin, ks, L.Cin, cop);
+            conv_tile_fma<K, UP, CO_T>(acc, in + (size_t)s * L.Cin * L.in_plane, w_lds + cot * L.Cin * K * K * CO_T, L.in_plane,
+                                       L.in_wp, r0, c0, kl, L.Cin, ks);
         }
         for (int o = 1; o < ks; o <<= 1) {
 #pragma unroll
@@ -204,13 +237,15 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
     const int P = Hout * Wout;
     const float* out = smem + L.out_off;
     const int oh = L.out_halo;
+    const FDiv fP = fd_make(P), fW = fd_make(Wout);
     if ((L.Cout & 3) == 0) {
         const int c4n = L.Cout >> 2;
         const int units = ns * P * c4n;
+        const FDiv f4 = fd_make(c4n);
         for (int u = threadIdx.x; u < units; u += nt) {
-            const int r = dv(u, c4n), c4 = u - r * c4n;
-            const int s = dv(r, P), p = r - s * P;
-            const int row = dv(p, Wout), col = p - row * Wout;
+            const int r = fd(u, f4), c4 = u - r * c4n;
+            const int s = fd(r, fP), p = r - s * P;
+            const int row = fd(p, fW), col = p - row * Wout;
             const float* q = out + (size_t)(s * L.Cout + 4 * c4) * L.out_plane + (row + oh) * L.out_wp + col + oh;
             const float4 v = make_float4(q[0], q[L.out_plane], q[2 * L.out_plane], q[3 * L.out_plane]);
             *reinterpret_cast<float4*>(L.y + ((size_t)n0 * P + r) * L.Cout + 4 * c4) = v;
@@ -222,10 +257,11 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
         }
     } else {
         const int units = ns * P * L.Cout;
+        const FDiv fC = fd_make(L.Cout);
         for (int u = threadIdx.x; u < units; u += nt) {
-            const int r = dv(u, L.Cout), c = u - r * L.Cout;
-            const int s = dv(r, P), p = r - s * P;
-            const int row = dv(p, Wout), col = p - row * Wout;
+            const int r = fd(u, fC), c = u - r * L.Cout;
+            const int s = fd(r, fP), p = r - s * P;
+            const int row = fd(p, fW), col = p - row * Wout;
             L.y[(size_t)n0 * P * L.Cout + u] = out[(size_t)(s * L.Cout + c) * L.out_plane + (row + oh) * L.out_wp + col + oh];
         }
         if (L.pool && L.idx != nullptr) {
@@ -242,6 +278,7 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
     float* w_lds = smem + a.w_off;
     float4 wpre[kNetWPre];
     float bpre;
+    NET_MARK(0);
     for (int n0 = blockIdx.x * a.S; n0 < a.N; n0 += gridDim.x * a.S) {
         const int ns = min(a.S, a.N - n0);
         {
@@ -258,6 +295,7 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
             const PlanarDst dst{L.Cin, L.in_plane, L.in_wp, L.in_halo};
             stage_pass(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
         }
+        NET_MARK(1);
         for (int l = 0; l < a.n_layers; ++l) {
             const NetLayer& L = a.L[l];
             // [A]
@@ -266,6 +304,7 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
             for (int i = threadIdx.x; i < nz; i += nt) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             net_w_store<K>(a, L, wpre, bpre, w_lds, nt);
             __syncthreads();
+            NET_MARK(2 + 3 * l);
             // [B]
             if (l + 1 < a.n_layers) net_w_load<K>(a, a.L[l + 1], wpre, bpre, nt);
             // [C]
@@ -287,8 +326,10 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
                 }
             }
             __syncthreads();
+            NET_MARK(3 + 3 * l);
             // [E]
             net_copy_out(a, L, smem, n0, ns, nt);
+            NET_MARK(4 + 3 * l);
         }
     }
 }
@@ -422,6 +463,10 @@ static int net_enable_lds(size_t bytes) {
 using namespace sv;
 
 extern "C" {
+
+#ifdef SV_TRACE
+int sv_debug_set_net_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(sv::g_net_trace), &buf, sizeof(buf)); }
+#endif
 
 int sv_convnet_supported(const sv_net_layer* layers, int n_layers, int N, int H, int W) {
     if (net_validate(layers, n_layers, N, H, W, "sv_convnet_supported")) return 0;

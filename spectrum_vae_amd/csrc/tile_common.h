@@ -10,6 +10,14 @@ enum { EPI_STORE = 0, EPI_MAXPOOL = 1, EPI_SUM4 = 2 };
 
 // n / d for a divisor that is usually a power of two (image extents, channel counts).
 __device__ __forceinline__ int dv(int n, int d) { return (d & (d - 1)) == 0 ? (n >> (31 - __clz(d))) : n / d; }
+// Division of small non-negative ints by a loop-invariant divisor as one multiply: q = hi32(n * ceil(2^32 / d)), exact
+// while n * d < 2^32 (tensor indices here stay far below that).  fd_make costs one real division; hoist it.
+struct FDiv {
+    uint32_t m;
+    int d;
+};
+__host__ __device__ __forceinline__ FDiv fd_make(int d) { return FDiv{0xFFFFFFFFu / (uint32_t)d + 1u, d}; }
+__device__ __forceinline__ int fd(int n, const FDiv& f) { return f.d == 1 ? n : (int)__umulhi((uint32_t)n, f.m); }
 inline int ilog2_exact(int v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctz(v) : -1; }
 
 __host__ __device__ constexpr int floordiv_c(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -59,12 +67,6 @@ __device__ __forceinline__ StageJob make_stage_job(const PlanarSrc& s, int n0, i
     return j;
 }
 
-// n / d with the power-of-two decision taken at compile time (P2: d == 1 << lg), so staging loops are branch-free
-template <bool P2>
-__device__ __forceinline__ int dvt(int n, int d, int lg) { return P2 ? (n >> lg) : n / d; }
-__device__ __forceinline__ int lg2(int d) { return 31 - __clz(d); }
-__device__ __forceinline__ bool is_p2(int d) { return (d & (d - 1)) == 0; }
-
 // one staged value -> its place(s) in the LDS image of channel plane q0 (already offset to the sample and channel)
 template <int MODE>
 __device__ __forceinline__ void stage_put(const PlanarSrc& s, const PlanarDst& d, float* q0, int row, int col, float x,
@@ -86,24 +88,24 @@ __device__ __forceinline__ void stage_put(const PlanarSrc& s, const PlanarDst& d
 // One pass: every thread walks its units with a stride of nt.  The loop bodies are branch-free and unrolled by 4 so
 // that the global loads of four units are issued before the first LDS write (a global round trip costs far more
 // than the instructions that consume it).
-template <int MODE, bool P2>
-__device__ __forceinline__ void stage_pass_t(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
+template <int MODE>
+__device__ __forceinline__ void stage_pass_m(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
     const int HW = s.Hs * s.Ws;
-    const int lgHW = lg2(HW), lgW = lg2(s.Ws), lgC = lg2(s.C);
+    const FDiv fHW = fd_make(HW), fW = fd_make(s.Ws);
     constexpr bool need_y = MODE == 1 || MODE == 2;
     if (j.kind == 0) {
-        const int lgC4 = lg2(j.C4);
+        const FDiv fC4 = fd_make(j.C4);
 #pragma unroll 4
         for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int p = dvt<P2>(u, j.C4, lgC4), cl = u - p * j.C4;
+            const int p = fd(u, fC4), cl = u - p * j.C4;
             const size_t gi = j.base + (size_t)p * s.C + j.c0 + 4 * cl;
             const float4 v = *reinterpret_cast<const float4*>(s.x + gi);
             float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
             uint32_t k = 0;
             if (need_y) y = *reinterpret_cast<const float4*>(s.zy + gi);
             if (MODE == 2) k = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
-            const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
-            const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
+            const int ss = fd(p, fHW), pp = p - ss * HW;
+            const int row = fd(pp, fW), col = pp - row * s.Ws;
             float* q = lds + (size_t)(ss * d.cpl + 4 * cl) * d.plane;
             stage_put<MODE>(s, d, q, row, col, v.x, y.x, k & 0xff);
             stage_put<MODE>(s, d, q + d.plane, row, col, v.y, y.y, (k >> 8) & 0xff);
@@ -111,6 +113,7 @@ __device__ __forceinline__ void stage_pass_t(const PlanarSrc& s, const PlanarDst
             stage_put<MODE>(s, d, q + 3 * d.plane, row, col, v.w, y.w, k >> 24);
         }
     } else if (j.kind == 1) {
+        const FDiv fC = fd_make(s.C);
 #pragma unroll 4
         for (int u = threadIdx.x; u < j.units; u += nt) {
             const size_t gi = j.base + 4 * (size_t)u;
@@ -124,33 +127,26 @@ __device__ __forceinline__ void stage_pass_t(const PlanarSrc& s, const PlanarDst
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int e = 4 * u + t;
-                const int p = dvt<P2>(e, s.C, lgC), c = e - p * s.C;
-                const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
-                const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
+                const int p = fd(e, fC), c = e - p * s.C;
+                const int ss = fd(p, fHW), pp = p - ss * HW;
+                const int row = fd(pp, fW), col = pp - row * s.Ws;
                 stage_put<MODE>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, row, col, xv[t], yv[t], (k >> (8 * t)) & 0xff);
             }
         }
     } else {
-        const int lgcc = lg2(j.cc);
+        const FDiv fcc = fd_make(j.cc);
 #pragma unroll 4
         for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int p = dvt<P2>(u, j.cc, lgcc), c = u - p * j.cc;
+            const int p = fd(u, fcc), c = u - p * j.cc;
             const size_t gi = j.base + (size_t)p * s.C + j.c0 + c;
             const float v = s.x[gi];
             const float y = need_y ? s.zy[gi] : 0.f;
             const uint32_t k = MODE == 2 ? s.zidx[gi] : 0u;
-            const int ss = dvt<P2>(p, HW, lgHW), pp = p - ss * HW;
-            const int row = dvt<P2>(pp, s.Ws, lgW), col = pp - row * s.Ws;
+            const int ss = fd(p, fHW), pp = p - ss * HW;
+            const int row = fd(pp, fW), col = pp - row * s.Ws;
             stage_put<MODE>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, row, col, v, y, k);
         }
     }
-}
-
-template <int MODE>
-__device__ __forceinline__ void stage_pass_m(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
-    const bool p2 = is_p2(s.Hs * s.Ws) && is_p2(s.Ws) && is_p2(s.C) && is_p2(j.kind == 0 ? j.C4 : j.cc);
-    if (p2) stage_pass_t<MODE, true>(s, d, j, lds, nt);
-    else stage_pass_t<MODE, false>(s, d, j, lds, nt);
 }
 
 __device__ __forceinline__ void stage_pass(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
@@ -162,17 +158,24 @@ __device__ __forceinline__ void stage_pass(const PlanarSrc& s, const PlanarDst& 
     }
 }
 
+// LDS filter layout: [channel tile][channel (wcs per tile)][tap][CO_T]
+template <int K, int CO_T>
+__device__ __forceinline__ int w_lds_index(int co, int c, int tap, int wcs) {
+    return (((co / CO_T) * wcs + c) * K * K + tap) * CO_T + (co % CO_T);
+}
+
 // ---- the register-tile FMA loop ---------------------------------------------------------------------------------
 // A thread owns 2x2 output pixels x CO_T output channels.  Per input channel it loads the (K+1)x(K+1) patch (UP == 1)
 // or the smaller stored patch (UP == 2: nearest upsampling folded into the indexing) once and reuses it for all K*K
 // taps and CO_T channels; filter taps come from LDS at a wave-uniform address (broadcast reads).
 //   img    : planar image of this thread's sample, [channel][plane]
-//   wbase  : w_lds + (this thread's channel tile) * CO_T, laid out [tap][wcs channels][cop]
+//   wtile  : filters of this thread's channel tile, laid out [channel][tap][CO_T] (compile-time strides, so every
+//            filter read is one base register + an immediate offset)
 //   r0, c0 : patch origin inside a plane
 //   channels c_begin, c_begin + c_step, ... < c_end are summed
 template <int K, int UP, int CO_T>
-__device__ __forceinline__ void conv_tile_fma(float (&acc)[2][2][CO_T], const float* img, const float* wbase, int plane,
-                                              int wp, int r0, int c0, int c_begin, int c_end, int c_step, int wcs, int cop) {
+__device__ __forceinline__ void conv_tile_fma(float (&acc)[2][2][CO_T], const float* img, const float* wtile, int plane,
+                                              int wp, int r0, int c0, int c_begin, int c_end, int c_step) {
     constexpr int PADL = (K - 1) / 2;
     constexpr int NPR = patch_row<UP, PADL>(K) + 1;  // patch rows == patch cols
     for (int c = c_begin; c < c_end; c += c_step) {
@@ -197,7 +200,7 @@ __device__ __forceinline__ void conv_tile_fma(float (&acc)[2][2][CO_T], const fl
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
                 float wv[CO_T];
-                const float* wq = wbase + ((kh * K + kw) * wcs + c) * cop;
+                const float* wq = wtile + (c * K * K + kh * K + kw) * CO_T;
 #pragma unroll
                 for (int q = 0; q < CO_T; q += 4) {
                     const float4 w4 = *reinterpret_cast<const float4*>(wq + q);
