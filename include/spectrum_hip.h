@@ -99,6 +99,16 @@ int sv_convnet_supported(const sv_net_layer* layers, int n_layers, int N, int H,
 int sv_convnet_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
                    int dtype, sv_stream_t stream);
 
+/* ---- Whole-network backward of the same chain (the gradient tape of run_model.py:281-289 / `model.fit`): given
+ *      dpred = dL/d(output of the last layer) and the y / idx tensors sv_convnet_fwd wrote, grads (+)= the gradient of
+ *      every filter and bias, laid out like params (n_params floats, a multiple of 4).  The per-layer gradients with
+ *      respect to activations stay on chip.  Partial sums of the workgroups go through the caller's workspace
+ *      (sv_convnet_bwd_workspace_bytes; 0 = chain not supported) and are summed in a fixed order (bit-reproducible). */
+size_t sv_convnet_bwd_workspace_bytes(const sv_net_layer* layers, int n_layers, int N, int H, int W, int64_t n_params);
+int sv_convnet_bwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
+                   const void* dpred, void* grads, int64_t n_params, int accumulate, void* workspace,
+                   size_t workspace_bytes, int dtype, sv_stream_t stream);
+
 /* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
 /* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */
 int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "sv_conv2d_bwd": (_i, [_g, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _sz, _i, _p]),
     "sv_convnet_supported": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i]),
     "sv_convnet_fwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _i, _p]),
+    "sv_convnet_bwd_workspace_bytes": (_sz, [C.POINTER(NetLayer), _i, _i, _i, _i, _i64]),
+    "sv_convnet_bwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _p, _p, _i64, _i, _p, _sz, _i, _p]),
     "sv_conv2d_transpose_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_transpose_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
     "sv_conv2d_transpose_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),

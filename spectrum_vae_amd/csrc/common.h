@@ -110,6 +110,16 @@ inline ActGradCoef act_grad_coef(int act, float alpha) {
         default: return {1.f, 0.f, 0.f, 1.f, 0.f, 0.f};
     }
 }
+__device__ __forceinline__ ActGradCoef act_grad_coef_dev(int act, float alpha) {
+    switch (act) {
+        case SV_ACT_RELU: return {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        case SV_ACT_ELU: return {1.f, 0.f, 0.f, 1.f, 1.f, 0.f};
+        case SV_ACT_LRELU: return {1.f, 0.f, 0.f, alpha, 0.f, 0.f};
+        case SV_ACT_TANH: return {1.f, 0.f, -1.f, 1.f, 0.f, -1.f};
+        case SV_ACT_SIGMOID: return {0.f, 1.f, -1.f, 0.f, 1.f, -1.f};
+        default: return {1.f, 0.f, 0.f, 1.f, 0.f, 0.f};
+    }
+}
 __device__ __forceinline__ float act_grad_q(float y, const ActGradCoef& k) {
     const bool pos = y > 0.f;
     const float c0 = pos ? k.p0 : k.n0, c1 = pos ? k.p1 : k.n1, c2 = pos ? k.p2 : k.n2;

@@ -80,6 +80,7 @@ class Model(Layer):
         # Run the whole forward as ONE launch when the model is a plain chain of fusable 3x3 convs (see
         # ``_conv_chain``); the per-layer buffers are filled exactly as the per-layer path fills them.
         self.use_net_fused = True
+        self.use_net_fused_bwd = True  # likewise the whole backward (needs the fused forward's bookkeeping)
         self._chain_cache: Dict[int, object] = {}
         # Optional: run the weight-gradient kernels, the gradient zero-fill and the optimizer's schedule update on
         # extra HIP streams beside the forward / input-gradient chain (fit / train_on_device_batch only).  Off by
@@ -287,6 +288,8 @@ class Model(Layer):
             return None
         arr, bufs, h, w = plan
         ops.convnet_fwd(arr, n, h, w, x, self._params)
+        if ctx.training:
+            ctx.net = (plan, x)
         prev = x
         for l, y, idx in bufs:
             if ctx.training:
@@ -311,7 +314,20 @@ class Model(Layer):
 
     def backward_raw(self, dy: torch.Tensor, call: int = -1, need_dx: bool = False):
         """Backward of the ``call``-th remembered training call; parameter gradients accumulate."""
-        return self.backward(self._calls[call], dy, need_dx=need_dx)
+        ctx = self._calls[call]
+        net = getattr(ctx, "net", None)
+        if net is not None and self.use_net_fused_bwd and not need_dx and ctx.param_grads:
+            (arr, bufs, h, w), x = net
+            n = x.shape[0]
+            key = ("bwd_ws", n)
+            nbytes = self._chain_cache.get(key)
+            if nbytes is None:
+                nbytes = self._chain_cache[key] = ops.convnet_bwd_workspace(arr, n, h, w, self._params.numel())
+            if nbytes > 0:
+                dyt = dy.as_subclass(torch.Tensor).contiguous()
+                ops.convnet_bwd(arr, n, h, w, x, self._params, dyt, self._grads, True, self._pool.workspace(nbytes))
+                return None
+        return self.backward(ctx, dy, need_dx=need_dx)
 
     def zero_grad(self):
         self._materialize()

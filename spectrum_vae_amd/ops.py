@@ -117,6 +117,15 @@ def convnet_fwd(arr, n: int, h: int, w: int, x, params):
     check(lib.sv_convnet_fwd(arr, len(arr), n, h, w, _ptr(x), _ptr(params), F32, _stream()), "sv_convnet_fwd")
 
 
+def convnet_bwd_workspace(arr, n: int, h: int, w: int, n_params: int) -> int:
+    return int(lib.sv_convnet_bwd_workspace_bytes(arr, len(arr), n, h, w, n_params))
+
+
+def convnet_bwd(arr, n: int, h: int, w: int, x, params, dpred, grads, accumulate: bool, ws: torch.Tensor):
+    check(lib.sv_convnet_bwd(arr, len(arr), n, h, w, _ptr(x), _ptr(params), _ptr(dpred), _ptr(grads), params.numel(),
+                             int(accumulate), _ptr(ws, torch.uint8), ws.numel(), F32, _stream()), "sv_convnet_bwd")
+
+
 def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float, ws: Optional[torch.Tensor]):
     check(lib.sv_conv2d_bwd(C.byref(g), _ptr(x), _ptr(w), _ptr(dy), _ptr(y), _ptr(idx, torch.uint8), _ptr(dx), _ptr(dw),
                             _ptr(db), ACT[act], alpha, _ptr(ws, torch.uint8) if ws is not None else None,

@@ -458,3 +458,31 @@ def test_whole_network_forward_matches_per_layer_path_and_oracle(n):
         assert rel(yf, yu) < 1e-5
         if idf is not None:
             assert (idf != idu).mean() < 1e-4  # a differing slot needs a tie within rounding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 64, 1100])
+def test_whole_network_backward_matches_per_layer_path(n):
+    """Gradients of the one-launch backward against the per-layer kernels, for MSE against the input."""
+    from spectrum_vae_amd import autoencoder, losses
+    from spectrum_vae_amd.losses import to_device_f32
+    x = data(n, seed=11 + n)
+    grads = {}
+    for fused in (True, False):
+        model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+        model.use_net_fused_bwd = fused
+        model.build((None, 32, 32, 3))
+        model._materialize()
+        model.compile(optimizer=None, loss=losses.MeanSquaredError())
+        xt = to_device_f32(x)
+        model.zero_grad()
+        pred = model.forward_raw(xt, True)
+        loss = torch.zeros(1, device=xt.device)
+        dpred = torch.empty_like(pred)
+        model.loss.value_and_grad(xt, pred, loss, dpred, 1.0)
+        model.backward_raw(dpred, -1, need_dx=False)
+        if fused:
+            assert model._chain_cache.get(("bwd_ws", n), 0) > 0
+        grads[fused] = model._grads.cpu().numpy().copy()
+    scale = np.abs(grads[False]).max()
+    assert np.abs(grads[True] - grads[False]).max() <= 2e-5 * scale
