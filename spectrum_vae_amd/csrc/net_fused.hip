@@ -25,6 +25,8 @@ __device__ __forceinline__ void net_mark(int slot) {
 #define NET_MARK(slot)
 #endif
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr int kMaxNetLayers = 12;
 constexpr int kNetWPre = 6;  // float4 registers per thread holding the next layer's filters
 
@@ -482,7 +484,8 @@ struct NetBwdLayer {
     int prev_pool, prev_act;         // the layer that produced the input activation (prev_act < 0: none, l == 0)
     float prev_alpha;
     int d_co_t, d_n_cot, d_ks;       // dgrad tiling over Cin
-    int w_co_t, w_n_cot, w_pg;       // wgrad tiling over Cout, strip shares
+    int w_co_t, w_n_cot, w_pg;       // wgrad tiling over Cout, strip shares (vector path)
+    int w_mfma;                      // 1: wgrad on the matrix cores (tiles fit the per-wave budget)
     const float* a_in;               // global: input activation [N][Hs][Ws][Cin]
     const uint8_t* a_idx;            // global: argmax of the producing pooling, or null
 };
@@ -608,17 +611,37 @@ __device__ __forceinline__ void net_layer_wgrad(const NetBwdArgs& a, const NetBw
     const float* g = smem + L.g_off + (size_t)cot * CO_T * L.g_plane;
     const float* xa = smem + L.a_off + (size_t)ci * L.a_plane;
 
-    float acc[K][CO_T];
+    // accumulators as (even pixel, odd pixel) pairs: two independent chains per filter tap, one v_pk_fma_f32 per pair
+    v2f acc2[K][CO_T];
     float accb[CO_T];
 #pragma unroll
     for (int kw = 0; kw < K; ++kw)
 #pragma unroll
-        for (int q = 0; q < CO_T; ++q) acc[kw][q] = 0.f;
+        for (int q = 0; q < CO_T; ++q) acc2[kw][q] = v2f{0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < CO_T; ++q) accb[q] = 0.f;
     const bool do_bias = live && ci == 0 && kh == 0 && L.b_off >= 0;
+    // the owner lane's slab entries: loaded now, so the round trip hides behind the strip loop
+#ifdef SV_EXP_NOSLAB
+    const bool owner = live && pg == 0 && a.N < 0;
+#else
+    const bool owner = live && pg == 0;
+#endif
+    const int co0 = cot * CO_T;
+    float sl[K][CO_T], slb[CO_T];
+    if (owner) {
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const float* o = slab + L.w_off + ((size_t)(kh * K + kw) * L.Cin + ci) * L.Cout + co0;
+#pragma unroll
+            for (int q = 0; q < CO_T; ++q) sl[kw][q] = co0 + q < L.Cout ? o[q] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < CO_T; ++q) slb[q] = (do_bias && co0 + q < L.Cout) ? slab[L.b_off + co0 + q] : 0.f;
+    }
 
     if (live) {
+#pragma unroll 2
         for (int w = pg; w < nstrips; w += PG) {
             const int oh = fd(w, f_spr);
             const int ow0 = (w - oh * spr) << 2;  // stored column of the strip's first pixel (logical column ow0 - 1)
@@ -635,29 +658,41 @@ __device__ __forceinline__ void net_layer_wgrad(const NetBwdArgs& a, const NetBw
                 xv[0] = v2.x; xv[1] = v2.x; xv[2] = v2.y; xv[3] = v2.y; xv[4] = v3; xv[5] = v3;
             }
             const float* zp = g + (oh + 1) * L.g_wp + ow0;
-            float zv[CO_T][4];
+            v2f z01[CO_T], z23[CO_T];
 #pragma unroll
             for (int q = 0; q < CO_T; ++q) {
                 const float4 v4 = *reinterpret_cast<const float4*>(zp + q * L.g_plane);
-                zv[q][0] = v4.x; zv[q][1] = v4.y; zv[q][2] = v4.z; zv[q][3] = v4.w;
+                z01[q] = v2f{v4.x, v4.y};
+                z23[q] = v2f{v4.z, v4.w};
             }
             if (do_bias) {
 #pragma unroll
-                for (int q = 0; q < CO_T; ++q) accb[q] += (zv[q][0] + zv[q][1]) + (zv[q][2] + zv[q][3]);
+                for (int q = 0; q < CO_T; ++q) accb[q] += (z01[q].x + z01[q].y) + (z23[q].x + z23[q].y);
             }
+            // input pairs (x[c], x[c + 1]) for c = 0..4: tap kw multiplies pixels j, j + 1 with x[kw + j], x[kw + j + 1]
+            v2f xp2[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) xp2[c] = v2f{xv[c], xv[c + 1]};
 #pragma unroll
             for (int kw = 0; kw < K; ++kw)
 #pragma unroll
                 for (int q = 0; q < CO_T; ++q) {
-                    float s = acc[kw][q];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) s = fmaf(xv[kw + j], zv[q][j], s);
-                    acc[kw][q] = s;
+                    acc2[kw][q] = __builtin_elementwise_fma(xp2[kw], z01[q], acc2[kw][q]);
+                    acc2[kw][q] = __builtin_elementwise_fma(xp2[kw + 2], z23[q], acc2[kw][q]);
                 }
         }
     }
+    float acc[K][CO_T];
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+        for (int q = 0; q < CO_T; ++q) acc[kw][q] = acc2[kw][q].x + acc2[kw][q].y;
     // fold the strip shares (adjacent lanes), then the owner lane adds to the slab
+#ifdef SV_EXP_NOFOLD
+    for (int o = 1; o < PG && a.N < 0; o <<= 1) {
+#else
     for (int o = 1; o < PG; o <<= 1) {
+#endif
 #pragma unroll
         for (int kw = 0; kw < K; ++kw)
 #pragma unroll
@@ -665,21 +700,110 @@ __device__ __forceinline__ void net_layer_wgrad(const NetBwdArgs& a, const NetBw
 #pragma unroll
         for (int q = 0; q < CO_T; ++q) accb[q] += __shfl_xor(accb[q], o, 64);
     }
-    if (live && pg == 0) {
-        const int co0 = cot * CO_T;
+#ifdef SV_EXP_MARKS
+    if (threadIdx.x == 0 && L.Cin == 8 && L.Cout == 16) NET_MARK(25);
+#endif
+    if (owner) {
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
             float* o = slab + L.w_off + ((size_t)(kh * K + kw) * L.Cin + ci) * L.Cout + co0;
 #pragma unroll
             for (int q = 0; q < CO_T; ++q)
-                if (co0 + q < L.Cout) o[q] += acc[kw][q];
+                if (co0 + q < L.Cout) o[q] = sl[kw][q] + acc[kw][q];
         }
         if (do_bias) {
 #pragma unroll
             for (int q = 0; q < CO_T; ++q)
-                if (co0 + q < L.Cout) slab[L.b_off + co0 + q] += accb[q];
+                if (co0 + q < L.Cout) slab[L.b_off + co0 + q] = slb[q] + accb[q];
         }
     }
+#ifdef SV_EXP_MARKS
+    if (threadIdx.x == 0 && L.Cin == 8 && L.Cout == 16) NET_MARK(26);
+#endif
+}
+
+// ---- wgrad on the matrix cores: dW[(tap, ci)][co] = sum over pixels of X[(tap, ci)][pixel] * dZ[pixel][co] as
+// 16x16x4 f32 MFMA tiles (exact f32 arithmetic; M = 9*Cin + 1: the extra row of ones yields the bias gradient,
+// N = Cout, K = 4 consecutive pixels of a row per instruction).  The tiles are dealt round-robin to the four waves;
+// each wave walks ALL pixels of the sample for its tiles, so nothing is folded across threads, and the finished tile
+// is added to the workgroup's slab (entries prefetched before the pixel loop).
+// Lane l feeds A[row l % 16][k l / 16] and B[k l / 16][col l % 16] and receives D[row 4 * (l / 16) + r][col l % 16].
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kWgTiles = 5;  // tiles per wave
+
+template <int K, int UP>
+__device__ __forceinline__ void net_layer_wgrad_mfma(const NetBwdArgs& a, const NetBwdLayer& L, float* smem, float* slab) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int Ho = L.Hs * UP, Wo = L.Ws * UP;
+    const int M = K * K * L.Cin;
+    const int NT = (L.Cout + 15) >> 4;
+    const int tiles = ((M + 1 + 15) >> 4) * NT;
+    const float* xa = smem + L.a_off;
+    const float* g = smem + L.g_off;
+    const FDiv fNT = fd_make(NT), fCin = fd_make(L.Cin), fK = fd_make(K);
+
+    v4f acc[kWgTiles];
+    int xb[kWgTiles], zb[kWgTiles], khm[kWgTiles], kwm[kWgTiles];
+    float amul[kWgTiles], aadd[kWgTiles], bmul[kWgTiles];
+    float sl[kWgTiles][4];
+    int so[kWgTiles][4];  // slab offset of D[4 * lk + r][li], -1: nothing to add
+#pragma unroll
+    for (int s = 0; s < kWgTiles; ++s) {
+        const int t = wave + 4 * s;
+        const bool valid = t < tiles;
+        const int mt = valid ? fd(t, fNT) : 0, nt = valid ? t - mt * NT : 0;
+        const int m = mt * 16 + li;
+        const bool is_w = valid && m < M;
+        const int tap = is_w ? fd(m, fCin) : 0, ci = is_w ? m - tap * L.Cin : 0;
+        const int kh = fd(tap, fK), kw = tap - kh * K;
+        khm[s] = kh - 1; kwm[s] = kw - 1;
+        xb[s] = UP == 1 ? ci * L.a_plane + kh * L.a_wp + kw : ci * L.a_plane;
+        amul[s] = is_w ? 1.f : 0.f;                   // padded rows contribute nothing ...
+        aadd[s] = (valid && m == M) ? 1.f : 0.f;      // ... except the row of ones behind the filter rows
+        const int n = nt * 16 + li;
+        const bool b_ok = valid && n < L.Cout;
+        zb[s] = (b_ok ? n : 0) * L.g_plane + L.g_wp + 1;
+        bmul[s] = b_ok ? 1.f : 0.f;
+        acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mr = mt * 16 + 4 * lk + r;
+            int o = -1;
+            if (valid && n < L.Cout) {
+                if (mr < M) o = L.w_off + mr * L.Cout + n;
+                else if (mr == M && L.b_off >= 0) o = L.b_off + n;
+            }
+            so[s][r] = o;
+            sl[s][r] = o >= 0 ? slab[o] : 0.f;
+        }
+    }
+    const int spr = Wo >> 2;
+    const int nsteps = Ho * spr;
+    const FDiv f_spr = fd_make(spr);
+#pragma unroll 2
+    for (int st = 0; st < nsteps; ++st) {
+        const int oh = fd(st, f_spr);
+        const int ow = ((st - oh * spr) << 2) + lk;
+        const int offz = oh * L.g_wp + ow;
+        const int offx = oh * L.a_wp + ow;
+#pragma unroll
+        for (int s = 0; s < kWgTiles; ++s) {
+            if (wave + 4 * s < tiles) {  // wave-uniform
+                int xi;
+                if (UP == 1) xi = xb[s] + offx;
+                else xi = xb[s] + (((oh + khm[s]) >> 1) + 1) * L.a_wp + ((ow + kwm[s]) >> 1) + 1;
+                const float av = fmaf(xa[xi], amul[s], aadd[s]);
+                const float bv = g[zb[s] + offz] * bmul[s];
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[s], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < kWgTiles; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (so[s][r] >= 0) slab[so[s][r]] = sl[s][r] + acc[s][r];
 }
 
 __device__ __forceinline__ void lds_zero(float* p, int floats, int nt) {
@@ -726,6 +850,7 @@ __global__ __launch_bounds__(256, 2) void net_bwd_s1(NetBwdArgs a) {
     float* slab = a.slab + (size_t)blockIdx.x * a.n_params;
     for (int i = threadIdx.x; i < (a.n_params >> 2); i += nt) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    NET_MARK(0);
     for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
         __syncthreads();  // the previous sample is done with the arena; the slab zero fill has been issued
         {   // dz of the last layer = dL/dy * act'(y)
@@ -739,6 +864,8 @@ __global__ __launch_bounds__(256, 2) void net_bwd_s1(NetBwdArgs a) {
             const PlanarDst dst{L.Cout, L.g_plane, L.g_wp, 1};
             stage_pass(src, dst, make_stage_job(src, n, 1, 0, L.Cout), smem + L.g_off, nt);
         }
+        const bool tr = n == (int)blockIdx.x;  // diagnostic marks: first sample of the workgroup only
+        if (tr) NET_MARK(1);
         for (int l = a.n_layers - 1; l >= 0; --l) {
             const NetBwdLayer& L = a.L[l];
             // zero what this step writes sparsely: the staged activation (halo), the mirrored filters (padded
@@ -766,6 +893,7 @@ __global__ __launch_bounds__(256, 2) void net_bwd_s1(NetBwdArgs a) {
                 }
             }
             __syncthreads();
+            if (tr) NET_MARK(2 + 3 * (a.n_layers - 1 - l));
             if (l > 0) {
                 if (L.up == 1) {
                     if (L.d_co_t == 8) net_layer_dgrad<K, 1, 8>(a, L, a.L[l - 1], smem, nt);
@@ -775,7 +903,14 @@ __global__ __launch_bounds__(256, 2) void net_bwd_s1(NetBwdArgs a) {
                     else net_layer_dgrad<K, 2, 4>(a, L, a.L[l - 1], smem, nt);
                 }
             }
-            if (L.up == 1) {
+#ifdef SV_EXP_MARKS
+            __syncthreads();
+#endif
+            if (tr) NET_MARK(3 + 3 * (a.n_layers - 1 - l));
+            if (L.w_mfma) {
+                if (L.up == 1) net_layer_wgrad_mfma<K, 1>(a, L, smem, slab);
+                else net_layer_wgrad_mfma<K, 2>(a, L, smem, slab);
+            } else if (L.up == 1) {
                 if (L.w_co_t == 8) net_layer_wgrad<K, 1, 8>(a, L, smem, slab, nt);
                 else net_layer_wgrad<K, 1, 4>(a, L, smem, slab, nt);
             } else {
@@ -783,6 +918,7 @@ __global__ __launch_bounds__(256, 2) void net_bwd_s1(NetBwdArgs a) {
                 else net_layer_wgrad<K, 2, 4>(a, L, smem, slab, nt);
             }
             __syncthreads();
+            if (tr) NET_MARK(4 + 3 * (a.n_layers - 1 - l));
         }
     }
 }
@@ -850,7 +986,8 @@ NetBwdPlan plan_net_bwd(const sv_net_layer* layers, int n_layers, int N, int H, 
         L.w_co_t = s.Cout > 4 ? 8 : 4;
         L.w_n_cot = (s.Cout + L.w_co_t - 1) / L.w_co_t;
         const int combos3 = s.Cin * L.w_n_cot * 3;
-        if (combos3 > nt) return p;
+        L.w_mfma = ((9 * s.Cin + 1 + 15) / 16) * ((s.Cout + 15) / 16) <= 4 * kWgTiles;
+        if (!L.w_mfma && combos3 > nt) return p;
         int pg = 1;
         while (pg * 2 * combos3 <= nt && pg < 64) pg <<= 1;
         L.w_pg = pg;

@@ -5,7 +5,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SPECTRUM_HIP_LIB"] = os.path.join(ROOT, "spectrum_vae_amd", "libspectrum_hip_trace.so")
+os.environ.setdefault("SPECTRUM_HIP_LIB", os.path.join(ROOT, "spectrum_vae_amd", "libspectrum_hip_trace.so"))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -22,21 +22,43 @@ m = autoencoder.CAEPadded(**bench.RUN_MODEL_CFG)
 m.build((None, 32, 32, 3))
 m._materialize(torch.device("cuda"))
 x = torch.rand(n, 32, 32, 3, device="cuda")
+from spectrum_vae_amd import losses  # noqa: E402
+m.compile(optimizer=None, loss=losses.MeanSquaredError())
+bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd"
+
+
+def run():
+    m.zero_grad()
+    pred = m.forward_raw(x, bwd)
+    if bwd:
+        tr.zero_()
+        loss = torch.zeros(1, device=x.device)
+        dpred = torch.empty_like(pred)
+        m.loss.value_and_grad(x, pred, loss, dpred, 1.0)
+        m.backward_raw(dpred, -1, need_dx=False)
+
+
 for _ in range(3):
-    m.forward_raw(x, False)
+    run()
 torch.cuda.synchronize()
 tr.zero_()
 torch.cuda.synchronize()
-m.forward_raw(x, False)
+run()
 torch.cuda.synchronize()
 t = tr.cpu().numpy().reshape(-1, 32)
 t = t[t[:, 0] != 0]
 t0 = t[:, 0].min()
 names = ["start", "x staged"] + [f"L{l} {w}" for l in range(6) for w in ("ready", "computed", "copied")]
+if bwd:
+    names = ["start", "dz staged"] + [f"L{5 - l} {w}" for l in range(6) for w in ("staged", "dgrad", "wgrad")]
 prev = None
 for s, nm in enumerate(names):
     v = (t[:, s] - t0) / 100.0
     d = "" if prev is None else f"   (+{np.median(v - prev):6.2f})"
     print(f"{nm:14s} min {v.min():7.2f} med {np.median(v):7.2f} max {v.max():7.2f}{d}")
     prev = v
+if bwd and t[:, 24].any():
+    for s_, nm in ((24, "e2 wgrad strips done"), (25, "folded"), (26, "slab added")):
+        v = (t[:, s_] - t0) / 100.0
+        print(f"{nm:22s} med {np.median(v):7.2f}")
 print("workgroups:", t.shape[0])
