@@ -109,6 +109,24 @@ int sv_convnet_bwd(const sv_net_layer* layers, int n_layers, int N, int H, int W
                    const void* dpred, void* grads, int64_t n_params, int accumulate, void* workspace,
                    size_t workspace_bytes, int dtype, sv_stream_t stream);
 
+/* ---- The kernel/bias-gradient half of sv_conv2d_bwd in two steps, so that the reductions of all layers of one backward
+ *      pass (the gradient tape of run_model.py:281-289) run as ONE launch: sv_conv2d_bwd_partial leaves per-workgroup
+ *      partial sums in `workspace` (sv_conv2d_wgrad_workspace_bytes(g); one workspace per layer until the finish),
+ *      sv_conv2d_wgrad_finish sums them in a fixed order into dw (and db when not NULL; the partial call must have
+ *      been made with with_bias = 1), adding to the previous contents when accumulate != 0. */
+typedef struct sv_wgrad_job {
+    sv_conv_geom g;
+    void* workspace;
+    void* dw;
+    void* db;
+    int32_t accumulate;
+    int32_t reserved;
+} sv_wgrad_job;
+int sv_conv2d_bwd_partial(const sv_conv_geom* g, const void* x, const void* dy, const void* y, const uint8_t* idx,
+                          int act, float alpha, int with_bias, void* workspace, size_t workspace_bytes, int dtype,
+                          sv_stream_t stream);
+int sv_conv2d_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, int dtype, sv_stream_t stream);
+
 /* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
 /* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */
 int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,

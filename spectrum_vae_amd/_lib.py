@@ -35,6 +35,13 @@ class NetLayer(C.Structure):
                 ("b_off", C.c_int64), ("y", C.c_void_p), ("idx", C.c_void_p)]
 
 
+class WgradJob(C.Structure):
+    """Mirror of ``sv_wgrad_job``."""
+
+    _fields_ = [("g", ConvGeom), ("workspace", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
+                ("accumulate", C.c_int32), ("reserved", C.c_int32)]
+
+
 _p, _i, _f, _i64, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64, C.c_size_t
 _g = C.POINTER(ConvGeom)
 
@@ -53,6 +60,8 @@ SIGNATURES = {
     "sv_convnet_fwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _i, _p]),
     "sv_convnet_bwd_workspace_bytes": (_sz, [C.POINTER(NetLayer), _i, _i, _i, _i, _i64]),
     "sv_convnet_bwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _p, _p, _i64, _i, _p, _sz, _i, _p]),
+    "sv_conv2d_bwd_partial": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p, _sz, _i, _p]),
+    "sv_conv2d_wgrad_finish": (_i, [C.POINTER(WgradJob), _i, _i, _p]),
     "sv_conv2d_transpose_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_transpose_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
     "sv_conv2d_transpose_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),

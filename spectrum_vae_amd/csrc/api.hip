@@ -28,7 +28,8 @@ bool tiled_wgrad_supported(int N, int Hs, int Ws, int Cin, int Cout, int K, int 
 int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, int accumulate, void* ws,
                        size_t ws_bytes, int N, int Hs, int Ws, int Cin, int Cout, int K, int UP, hipStream_t st,
                        int zmode = 0, const float* zy = nullptr, const uint8_t* zidx = nullptr, int zact = 0,
-                       float zalpha = 0.f);
+                       float zalpha = 0.f, int defer = 0, int with_bias = 0);
+int launch_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, hipStream_t st);
 
 // Stride-1 SAME conv with an odd square kernel and an isotropic folded upsampling: the LDS-tiled family.
 static bool tiled_shape(const sv_conv_geom& g) {
@@ -150,6 +151,38 @@ int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const voi
                          g->Cin, g->KH, 1, 1, g->up_h == 2 ? 2 : 0, SV_ACT_NONE, 0.f, to_stream(stream), zmode,
                          (const float*)y, idx, act, alpha);
     return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: shape not covered") : rc;
+}
+
+int sv_conv2d_bwd_partial(const sv_conv_geom* g, const void* x, const void* dy, const void* y, const uint8_t* idx,
+                          int act, float alpha, int with_bias, void* workspace, size_t workspace_bytes, int dtype,
+                          sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_bwd_partial");
+    int rc = validate_geom(g, "sv_conv2d_bwd_partial");
+    if (rc) return rc;
+    SV_REQUIRE(x && dy && y, "sv_conv2d_bwd_partial: null tensor");
+    const int pooled = idx != nullptr;
+    SV_REQUIRE(sv_conv2d_fused_supported(g, pooled), "sv_conv2d_bwd_partial: shape is outside the fused family");
+    rc = launch_tiled_wgrad((const float*)x, (const float*)dy, nullptr, nullptr, 1, workspace, workspace_bytes, g->N,
+                            g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, to_stream(stream),
+                            pooled ? 2 : 1, (const float*)y, idx, act, alpha, 1, with_bias);
+    return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd_partial: shape not covered") : rc;
+}
+
+int sv_conv2d_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_wgrad_finish");
+    SV_REQUIRE(jobs != nullptr && n_jobs >= 0, "sv_conv2d_wgrad_finish: null job list");
+    for (int j = 0; j < n_jobs; ++j) {
+        int rc = validate_geom(&jobs[j].g, "sv_conv2d_wgrad_finish");
+        if (rc) return rc;
+        SV_REQUIRE(jobs[j].workspace && jobs[j].dw, "sv_conv2d_wgrad_finish: job %d: null workspace or dw", j);
+        SV_REQUIRE(sv_conv2d_fused_supported(&jobs[j].g, 0), "sv_conv2d_wgrad_finish: job %d is outside the fused family", j);
+    }
+    for (int j0 = 0; j0 < n_jobs; j0 += 8) {
+        const int n = n_jobs - j0 < 8 ? n_jobs - j0 : 8;
+        int rc = launch_wgrad_finish(jobs + j0, n, to_stream(stream));
+        if (rc) return rc;
+    }
+    return SV_OK;
 }
 
 // Conv2DTranspose forward is the input-gradient kernel of the described conv, plus bias and activation.

@@ -697,6 +697,10 @@ WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     int S = (4 * PG + strips - 1) / strips;
     if (S < 1) S = 1;
     while (S > 1 && (int64_t)((N + S - 1) / S) * ny0 * nz0 < 512) S >>= 1;
+    // One pass per workgroup when the LDS allows it: the loads of all its samples are then in flight together
+    // instead of one exposed global round trip per pass (512 workgroups = two per CU at this LDS budget).
+    const int one_pass = (int)(((int64_t)N * ny0 * nz0 + 511) / 512);
+    if (one_pass > S && one_pass <= 8 && bytes(one_pass, cib, cob) <= kLdsBudget) S = one_pass;
     while (S > 1 && bytes(S, cib, cob) > kLdsBudget) --S;
     if (S > N) S = N;
     p.S = S; p.cib = cib; p.cob = cob; p.PG = PG;
@@ -735,10 +739,9 @@ struct ReduceArgs {
     int n_split, accumulate;
     int K2, co_t, nchunk, combos_max, ny, cib, cob, Cin, Cout;
 };
-__global__ __launch_bounds__(1024) void wgrad_reduce3(ReduceArgs a) {
-    __shared__ float red[16][64];
+__device__ __forceinline__ void wgrad_reduce_body(const ReduceArgs& a, int block, float (*red)[64]) {
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t e = (int64_t)block * 64 + lane;
     float s = 0.f;
     if (e < a.slab_floats) {
         int sp = grp;
@@ -787,15 +790,60 @@ __global__ __launch_bounds__(1024) void wgrad_reduce3(ReduceArgs a) {
     *o = t;
 }
 
+__global__ __launch_bounds__(1024) void wgrad_reduce3(ReduceArgs a) {
+    __shared__ float red[16][64];
+    wgrad_reduce_body(a, blockIdx.x, red);
+}
+
+// the same reduction for several layers in one launch: block ranges [first[j], first[j + 1]) belong to job j
+constexpr int kMaxReduceJobs = 8;
+struct ReduceMultiArgs {
+    int n_jobs;
+    int first[kMaxReduceJobs + 1];
+    ReduceArgs job[kMaxReduceJobs];
+};
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi(ReduceMultiArgs m) {
+    __shared__ float red[16][64];
+    int j = 0;
+    while (j + 1 < m.n_jobs && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    wgrad_reduce_body(m.job[j], blockIdx.x - m.first[j], red);
+}
+
 bool tiled_wgrad_supported(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return false;
     return plan_wgrad(N, Hs, Ws, Cin, Cout, K, UP).ok;
 }
 
 // Returns 1 when the shape is not covered, 0 on success, <0 on error.  db != null adds the bias gradient.
+static void fill_reduce_args(ReduceArgs& r, const WgradPlan& p, const void* ws, float* dw, float* db, int accumulate, int K,
+                             int Cin, int Cout) {
+    r.part = (const float*)ws; r.dw = dw; r.db = db; r.slab_floats = (int64_t)p.slab_floats; r.n_split = p.nblk;
+    r.accumulate = accumulate; r.K2 = K * K; r.co_t = p.co_t; r.nchunk = p.nchunk; r.combos_max = p.combos_max;
+    r.ny = (int)p.grid.y; r.cib = p.cib; r.cob = p.cob; r.Cin = Cin; r.Cout = Cout;
+}
+
+// One launch that finishes up to kMaxReduceJobs deferred kernel-gradient reductions (slabs written with defer = 1).
+int launch_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, hipStream_t st) {
+    ReduceMultiArgs m{};
+    m.n_jobs = n_jobs;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const sv_conv_geom& g = jobs[j].g;
+        WgradPlan p = plan_wgrad(g.N, g.H / g.up_h, g.W / g.up_w, g.Cin, g.Cout, g.KH, g.up_h);
+        if (!p.ok) return fail(SV_E_UNSUPPORTED, "conv2d_wgrad_finish: job %d is outside the tiled family", j);
+        fill_reduce_args(m.job[j], p, jobs[j].workspace, (float*)jobs[j].dw, (float*)jobs[j].db, jobs[j].accumulate, g.KH,
+                         g.Cin, g.Cout);
+        m.first[j] = blocks;
+        blocks += (int)ceil_div((int64_t)p.slab_floats, 64);
+    }
+    m.first[n_jobs] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_multi, dim3((unsigned)blocks), dim3(1024), 0, st, m);
+    return check_launch("wgrad_reduce_multi");
+}
+
 int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
                        int N, int Hs, int Ws, int Cin, int Cout, int K, int UP, hipStream_t st, int zmode,
-                       const float* zy, const uint8_t* zidx, int zact, float zalpha) {
+                       const float* zy, const uint8_t* zidx, int zact, float zalpha, int defer, int with_bias) {
     if (!((K == 3 || K == 5) && (UP == 1 || UP == 2))) return 1;
     WgradPlan p = plan_wgrad(N, Hs, Ws, Cin, Cout, K, UP);
     if (!p.ok) return 1;
@@ -807,7 +855,7 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
     a.x = x; a.dz = dz; a.slab = (float*)ws;
     a.N = N; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.Cout = Cout; a.Ho = Hs * UP; a.Wo = Ws * UP; a.up = UP;
     a.S = p.S; a.cib = p.cib; a.cob = p.cob; a.PG = p.PG; a.xplane = p.xplane; a.xwp = p.xwp; a.zplane = p.zplane;
-    a.zmode = zmode; a.zy = zy; a.zidx = zidx; a.zk = act_grad_coef(zact, zalpha); a.with_bias = db != nullptr;
+    a.zmode = zmode; a.zy = zy; a.zidx = zidx; a.zk = act_grad_coef(zact, zalpha); a.with_bias = db != nullptr || with_bias;
     a.combos_max = p.combos_max;
     if (K == 3) {
         if (p.co_t == 8)
@@ -818,11 +866,9 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
         hipLaunchKernelGGL((wgrad_s1_lds<5, 4>), p.grid, dim3(256), p.lds_bytes, st, a);
     }
     int rc = check_launch("wgrad_s1_lds");
-    if (rc) return rc;
+    if (rc || defer) return rc;
     ReduceArgs r{};
-    r.part = (const float*)ws; r.dw = dw; r.db = db; r.slab_floats = (int64_t)p.slab_floats; r.n_split = p.nblk;
-    r.accumulate = accumulate; r.K2 = K * K; r.co_t = p.co_t; r.nchunk = p.nchunk; r.combos_max = p.combos_max;
-    r.ny = (int)p.grid.y; r.cib = p.cib; r.cob = p.cob; r.Cin = Cin; r.Cout = Cout;
+    fill_reduce_args(r, p, ws, dw, db, accumulate, K, Cin, Cout);
     hipLaunchKernelGGL(wgrad_reduce3, dim3((unsigned)ceil_div((int64_t)p.slab_floats, 64)), dim3(1024), 0, st, r);
     return check_launch("wgrad_reduce3");
 }

@@ -700,9 +700,6 @@ __device__ __forceinline__ void net_layer_wgrad(const NetBwdArgs& a, const NetBw
 #pragma unroll
         for (int q = 0; q < CO_T; ++q) accb[q] += __shfl_xor(accb[q], o, 64);
     }
-#ifdef SV_EXP_MARKS
-    if (threadIdx.x == 0 && L.Cin == 8 && L.Cout == 16) NET_MARK(25);
-#endif
     if (owner) {
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
@@ -717,9 +714,6 @@ __device__ __forceinline__ void net_layer_wgrad(const NetBwdArgs& a, const NetBw
                 if (co0 + q < L.Cout) slab[L.b_off + co0 + q] = slb[q] + accb[q];
         }
     }
-#ifdef SV_EXP_MARKS
-    if (threadIdx.x == 0 && L.Cin == 8 && L.Cout == 16) NET_MARK(26);
-#endif
 }
 
 // ---- wgrad on the matrix cores: dW[(tap, ci)][co] = sum over pixels of X[(tap, ci)][pixel] * dZ[pixel][co] as
@@ -731,46 +725,45 @@ __device__ __forceinline__ void net_layer_wgrad(const NetBwdArgs& a, const NetBw
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kWgTiles = 5;  // tiles per wave
 
-template <int K, int UP>
-__device__ __forceinline__ void net_layer_wgrad_mfma(const NetBwdArgs& a, const NetBwdLayer& L, float* smem, float* slab) {
+template <int K, int UP, int NS>
+__device__ __forceinline__ void net_wgrad_mfma_ns(const NetBwdArgs& a, const NetBwdLayer& L, float* smem, float* slab) {
+    constexpr int U = 4;  // pixel strips per unrolled iteration: U * NS independent LDS-read -> MFMA chains in flight
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int Ho = L.Hs * UP, Wo = L.Ws * UP;
     const int M = K * K * L.Cin;
     const int NT = (L.Cout + 15) >> 4;
-    const int tiles = ((M + 1 + 15) >> 4) * NT;
     const float* xa = smem + L.a_off;
     const float* g = smem + L.g_off;
     const FDiv fNT = fd_make(NT), fCin = fd_make(L.Cin), fK = fd_make(K);
 
-    v4f acc[kWgTiles];
-    int xb[kWgTiles], zb[kWgTiles], khm[kWgTiles], kwm[kWgTiles];
-    float amul[kWgTiles], aadd[kWgTiles], bmul[kWgTiles];
-    float sl[kWgTiles][4];
-    int so[kWgTiles][4];  // slab offset of D[4 * lk + r][li], -1: nothing to add
+    v4f acc[NS];
+    int xb[NS], zb[NS], khm[NS], kwm[NS];
+    float amul[NS], aadd[NS], bmul[NS];
+    float sl[NS][4];
+    int so[NS][4];  // slab offset of D[4 * lk + r][li], -1: nothing to add
 #pragma unroll
-    for (int s = 0; s < kWgTiles; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int t = wave + 4 * s;
-        const bool valid = t < tiles;
-        const int mt = valid ? fd(t, fNT) : 0, nt = valid ? t - mt * NT : 0;
+        const int mt = fd(t, fNT), nt = t - mt * NT;
         const int m = mt * 16 + li;
-        const bool is_w = valid && m < M;
+        const bool is_w = m < M;
         const int tap = is_w ? fd(m, fCin) : 0, ci = is_w ? m - tap * L.Cin : 0;
         const int kh = fd(tap, fK), kw = tap - kh * K;
         khm[s] = kh - 1; kwm[s] = kw - 1;
         xb[s] = UP == 1 ? ci * L.a_plane + kh * L.a_wp + kw : ci * L.a_plane;
-        amul[s] = is_w ? 1.f : 0.f;                   // padded rows contribute nothing ...
-        aadd[s] = (valid && m == M) ? 1.f : 0.f;      // ... except the row of ones behind the filter rows
+        amul[s] = is_w ? 1.f : 0.f;          // padded rows contribute nothing ...
+        aadd[s] = m == M ? 1.f : 0.f;        // ... except the row of ones behind the filter rows
         const int n = nt * 16 + li;
-        const bool b_ok = valid && n < L.Cout;
-        zb[s] = (b_ok ? n : 0) * L.g_plane + L.g_wp + 1;
+        const bool b_ok = n < L.Cout;
+        zb[s] = (b_ok ? n : 0) * L.g_plane + L.g_wp + 1 + lk;
         bmul[s] = b_ok ? 1.f : 0.f;
         acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mr = mt * 16 + 4 * lk + r;
             int o = -1;
-            if (valid && n < L.Cout) {
+            if (b_ok) {
                 if (mr < M) o = L.w_off + mr * L.Cout + n;
                 else if (mr == M && L.b_off >= 0) o = L.b_off + n;
             }
@@ -778,32 +771,60 @@ __device__ __forceinline__ void net_layer_wgrad_mfma(const NetBwdArgs& a, const 
             sl[s][r] = o >= 0 ? slab[o] : 0.f;
         }
     }
-    const int spr = Wo >> 2;
-    const int nsteps = Ho * spr;
-    const FDiv f_spr = fd_make(spr);
-#pragma unroll 2
-    for (int st = 0; st < nsteps; ++st) {
-        const int oh = fd(st, f_spr);
-        const int ow = ((st - oh * spr) << 2) + lk;
-        const int offz = oh * L.g_wp + ow;
-        const int offx = oh * L.a_wp + ow;
+#ifdef SV_EXP_MARKS
+    if (L.Cin == 16 && L.Cout == 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); NET_MARK(24); asm volatile("" ::: "memory"); }
+#endif
+    for (int oh = 0; oh < Ho; ++oh) {
+        const int rowz = oh * L.g_wp;
+        const int rowx = oh * L.a_wp + lk;
+        for (int c0 = 0; c0 < Wo; c0 += 4 * U) {
+            float av[U][NS], bv[U][NS];
 #pragma unroll
-        for (int s = 0; s < kWgTiles; ++s) {
-            if (wave + 4 * s < tiles) {  // wave-uniform
-                int xi;
-                if (UP == 1) xi = xb[s] + offx;
-                else xi = xb[s] + (((oh + khm[s]) >> 1) + 1) * L.a_wp + ((ow + kwm[s]) >> 1) + 1;
-                const float av = fmaf(xa[xi], amul[s], aadd[s]);
-                const float bv = g[zb[s] + offz] * bmul[s];
-                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[s], 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + 4 * u;  // first pixel of the strip (wave-uniform)
+                const bool on = c < Wo;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    int xi;
+                    if (UP == 1) xi = xb[s] + rowx + c;
+                    else xi = xb[s] + (((oh + khm[s]) >> 1) + 1) * L.a_wp + ((c + lk + kwm[s]) >> 1) + 1;
+                    av[u][s] = on ? xa[xi] : 0.f;
+                    bv[u][s] = on ? g[zb[s] + rowz + c] : 0.f;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaf(av[u][s], amul[s], aadd[s]), bv[u][s] * bmul[s], acc[s], 0, 0, 0);
         }
     }
+#ifdef SV_EXP_MARKS
+    if (L.Cin == 16 && L.Cout == 32) { asm volatile("s_nop 0" : "+v"(acc[0]) :: "memory"); NET_MARK(25); asm volatile("" ::: "memory"); }
+#endif
 #pragma unroll
-    for (int s = 0; s < kWgTiles; ++s)
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (so[s][r] >= 0) slab[so[s][r]] = sl[s][r] + acc[s][r];
+#ifdef SV_EXP_MARKS
+    if (L.Cin == 16 && L.Cout == 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); NET_MARK(26); asm volatile("" ::: "memory"); }
+#endif
+}
+
+template <int K, int UP>
+__device__ __forceinline__ void net_layer_wgrad_mfma(const NetBwdArgs& a, const NetBwdLayer& L, float* smem, float* slab) {
+    const int wave = threadIdx.x >> 6;
+    const int tiles = ((K * K * L.Cin + 1 + 15) >> 4) * ((L.Cout + 15) >> 4);
+    const int ns = wave < tiles ? (tiles - wave + 3) >> 2 : 0;  // tiles wave, wave + 4, ... (wave-uniform)
+    switch (ns) {
+        case 1: net_wgrad_mfma_ns<K, UP, 1>(a, L, smem, slab); break;
+        case 2: net_wgrad_mfma_ns<K, UP, 2>(a, L, smem, slab); break;
+        case 3: net_wgrad_mfma_ns<K, UP, 3>(a, L, smem, slab); break;
+        case 4: net_wgrad_mfma_ns<K, UP, 4>(a, L, smem, slab); break;
+        case 5: net_wgrad_mfma_ns<K, UP, 5>(a, L, smem, slab); break;
+        default: break;
+    }
 }
 
 __device__ __forceinline__ void lds_zero(float* p, int floats, int nt) {

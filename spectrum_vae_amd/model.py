@@ -80,7 +80,10 @@ class Model(Layer):
         # Run the whole forward as ONE launch when the model is a plain chain of fusable 3x3 convs (see
         # ``_conv_chain``); the per-layer buffers are filled exactly as the per-layer path fills them.
         self.use_net_fused = True
-        self.use_net_fused_bwd = True  # likewise the whole backward (needs the fused forward's bookkeeping)
+        self.defer_wgrad_reduce = True  # one reduction launch for the kernel gradients of all fused conv layers
+        # The whole backward as one launch (sv_convnet_bwd) is correct but, with one sample in flight per workgroup,
+        # slower than the per-layer kernels at the batch sizes measured so far: opt-in.
+        self.use_net_fused_bwd = False
         self._chain_cache: Dict[int, object] = {}
         # Optional: run the weight-gradient kernels, the gradient zero-fill and the optimizer's schedule update on
         # extra HIP streams beside the forward / input-gradient chain (fit / train_on_device_batch only).  Off by
@@ -327,6 +330,12 @@ class Model(Layer):
                 dyt = dy.as_subclass(torch.Tensor).contiguous()
                 ops.convnet_bwd(arr, n, h, w, x, self._params, dyt, self._grads, True, self._pool.workspace(nbytes))
                 return None
+        if self.defer_wgrad_reduce and ctx.param_grads and ctx.wgrad_jobs is None:
+            ctx.wgrad_jobs = []
+            dx = self.backward(ctx, dy, need_dx=need_dx)
+            ops.conv2d_wgrad_finish(ctx.wgrad_jobs)
+            ctx.wgrad_jobs = None
+            return dx
         return self.backward(ctx, dy, need_dx=need_dx)
 
     def zero_grad(self):

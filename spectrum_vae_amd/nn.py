@@ -164,6 +164,9 @@ class CallCtx:
         # streams before the optimizer step.
         self.side: Optional[List[torch.cuda.Stream]] = None
         self.side_rr = 0
+        # A list: fused conv layers leave their kernel-gradient partial sums in per-layer workspaces and append a job
+        # here; the owner finishes all of them with one launch after the backward pass.  None: reduce per layer.
+        self.wgrad_jobs: Optional[list] = None
 
     def buf(self, layer, role, shape, dtype=torch.float32):
         return self.pool.get((id(layer), role, self.slot), shape, dtype)
@@ -352,6 +355,14 @@ class _ConvBase(Layer):
         if self.fused_bwd and ctx.param_grads:
             dx = ctx.buf(self, "dx", tuple(x.shape)) if need_dx else None
             db = self.bias.grad if self.bias is not None else None
+            if ctx.wgrad_jobs is not None and not ctx.side:
+                ws = ctx.buf(self, "wgrad_ws", (max(ops.conv2d_wgrad_workspace(g), 16),), torch.uint8)
+                ops.conv2d_bwd_partial(g, x, dy, y, s.get("idx"), self.act, self.alpha, db is not None, ws)
+                ctx.wgrad_jobs.append((g, ws, self.kernel.grad, db))
+                if need_dx:
+                    ops.conv2d_bwd(g, None, self.kernel.data, dy, y, s.get("idx"), dx, None, None, self.act, self.alpha,
+                                   None)
+                return dx
             if not ctx.side or not need_dx:
                 ws = ctx.pool.workspace(ops.conv2d_wgrad_workspace(g))
                 ops.conv2d_bwd(g, x, self.kernel.data, dy, y, s.get("idx"), dx, self.kernel.grad, db, self.act,

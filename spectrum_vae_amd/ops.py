@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT, F32, ConvGeom, NetLayer, check, lib
+from ._lib import ACT, F32, ConvGeom, NetLayer, WgradJob, check, lib
 
 
 def _stream() -> int:
@@ -124,6 +124,24 @@ def convnet_bwd_workspace(arr, n: int, h: int, w: int, n_params: int) -> int:
 def convnet_bwd(arr, n: int, h: int, w: int, x, params, dpred, grads, accumulate: bool, ws: torch.Tensor):
     check(lib.sv_convnet_bwd(arr, len(arr), n, h, w, _ptr(x), _ptr(params), _ptr(dpred), _ptr(grads), params.numel(),
                              int(accumulate), _ptr(ws, torch.uint8), ws.numel(), F32, _stream()), "sv_convnet_bwd")
+
+
+def conv2d_bwd_partial(g: ConvGeom, x, dy, y, idx, act: str, alpha: float, with_bias: bool, ws: torch.Tensor):
+    check(lib.sv_conv2d_bwd_partial(C.byref(g), _ptr(x), _ptr(dy), _ptr(y), _ptr(idx, torch.uint8), ACT[act], alpha,
+                                    int(with_bias), _ptr(ws, torch.uint8), ws.numel(), F32, _stream()),
+          "sv_conv2d_bwd_partial")
+
+
+def conv2d_wgrad_finish(jobs):
+    """jobs: list of (geom, workspace, dw, db or None); gradients accumulate into dw / db."""
+    if not jobs:
+        return
+    arr = (WgradJob * len(jobs))()
+    for a, (g, ws, dw, db) in zip(arr, jobs):
+        a.g = g
+        a.workspace, a.dw, a.db = _ptr(ws, torch.uint8), _ptr(dw), _ptr(db)
+        a.accumulate, a.reserved = 1, 0
+    check(lib.sv_conv2d_wgrad_finish(arr, len(jobs), F32, _stream()), "sv_conv2d_wgrad_finish")
 
 
 def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float, ws: Optional[torch.Tensor]):

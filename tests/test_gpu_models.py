@@ -474,6 +474,7 @@ def test_whole_network_backward_matches_per_layer_path(n):
         model.build((None, 32, 32, 3))
         model._materialize()
         model.compile(optimizer=None, loss=losses.MeanSquaredError())
+        assert model.use_net_fused
         xt = to_device_f32(x)
         model.zero_grad()
         pred = model.forward_raw(xt, True)

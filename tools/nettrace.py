@@ -58,7 +58,7 @@ for s, nm in enumerate(names):
     print(f"{nm:14s} min {v.min():7.2f} med {np.median(v):7.2f} max {v.max():7.2f}{d}")
     prev = v
 if bwd and t[:, 24].any():
-    for s_, nm in ((24, "e2 wgrad strips done"), (25, "folded"), (26, "slab added")):
+    for s_, nm in ((24, "e3 wgrad prologue done"), (25, "mfma loop done"), (26, "slab stored")):
         v = (t[:, s_] - t0) / 100.0
         print(f"{nm:22s} med {np.median(v):7.2f}")
 print("workgroups:", t.shape[0])
