@@ -21,6 +21,21 @@ def agg(path):
     return {f"{k[0]} | grid {k[1]}": sum(v) / len(v) for k, v in d.items()}
 res = {"FETCH_SIZE_raw_avg_per_launch": agg("$out/fetch.csv"), "WRITE_SIZE_raw_avg_per_launch": agg("$out/write.csv")}
 json.dump(res, open("$out/traffic_raw.json", "w"), indent=1)
+# HBM bytes per launch by kernel name (all launches of a name averaged): FETCH_SIZE is in KB and, on gfx950, reports half
+# of the bytes of wide coalesced reads (x2); WRITE_SIZE is in KB and exact for wide stores.
+import re
+def by_name(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if 'sv::' in r['Kernel_Name']:
+            n = re.sub(r'^void ', '', r['Kernel_Name']).split('(')[0].replace('sv::', '')
+            d[n].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in d.items()}
+fe, wr = by_name("$out/fetch.csv"), by_name("$out/write.csv")
+lat = {"unit": "bytes", "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of bench.py --no-graph; "
+       "bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950: FETCH_SIZE counts half of wide reads)",
+       "hbm_bytes_per_launch": {k: round(2 * fe.get(k, 0) * 1024 + wr.get(k, 0) * 1024) for k in set(fe) | set(wr)}}
+json.dump(lat, open("$out/traffic_latest.json", "w"), indent=1)
 for k, v in res.items():
     print(k)
     for n, x in sorted(v.items(), key=lambda t: -t[1])[:14]:
