@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-out", default=None, help="write the per-call HIP-event table to this JSON file")
     args = ap.parse_args()
+    if os.environ.get("SV_BENCH_WATCHDOG"):  # diagnostic: dump every thread's stack if the run takes longer than this
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SV_BENCH_WATCHDOG"]), exit=True)
 
     import torch.distributed as dist
 
@@ -225,7 +228,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(b["loss"].item())

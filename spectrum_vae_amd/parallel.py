@@ -27,10 +27,12 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SPECTRUM_DIST_BACKEND=gloo rehearses the multi-rank path where RCCL cannot run (ranks sharing one GPU)
+            backend = os.environ.get("SPECTRUM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend == "nccl":
+        if torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
@@ -45,10 +47,24 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.calls = 0
         self.bytes = 0
+        # gloo (CPU rehearsals, ranks sharing one GPU) reduces host memory: device buffers are staged through a
+        # pinned host copy.  RCCL ("nccl") reduces the device buffer in place on the stream.
+        self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self._host: Optional[torch.Tensor] = None
+
+    def _reduce(self, flat: torch.Tensor, fn):
+        if self._host_staged and flat.is_cuda:
+            if self._host is None or self._host.numel() != flat.numel():
+                self._host = torch.empty(flat.numel(), dtype=flat.dtype, pin_memory=True)
+            self._host.copy_(flat.view(-1))  # synchronises with the producing stream
+            fn(self._host)
+            flat.view(-1).copy_(self._host, non_blocking=True)
+        else:
+            fn(flat)
 
     def all_reduce(self, flat: torch.Tensor) -> float:
         if self.world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce(flat, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
         self.calls += 1
         self.bytes += flat.numel() * flat.element_size()
         return 1.0 / self.world
@@ -56,7 +72,7 @@ class GradReducer:
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         """Make every replica start from rank ``src``'s values (weights, BatchNorm state)."""
         if self.world > 1:
-            dist.broadcast(flat, src=src, group=self.group)
+            self._reduce(flat, lambda t: dist.broadcast(t, src=src, group=self.group))
 
 
 def shard_bounds(n: int, rank: int, world: int) -> tuple:
