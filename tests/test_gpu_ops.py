@@ -176,6 +176,19 @@ def test_conv2d_fused_pool_fwd_and_fused_bwd(cfg):
     dw2 = torch.zeros((K, K, cin, cout), device="cuda")
     ops.conv2d_bwd(g, xd, kd, dev(dy), dev(y_o), idx, None, dw2, None, act, 1.0, ws)
     close(dw2, dw_o, what="fused dw only")
+    # the two halves on their own, and the kernel gradient in its deferred form (partial sums now, one reduction later)
+    dx3 = torch.empty(x.shape, device="cuda")
+    ops.conv2d_bwd(g, None, kd, dev(dy), dev(y_o), idx, dx3, None, None, act, 1.0, None)
+    close(dx3, dx_o, what="input-gradient half")
+    ws2 = torch.empty_like(ws)
+    dw3, db3 = torch.full((K, K, cin, cout), 2.0, device="cuda"), torch.full((cout,), 2.0, device="cuda")
+    dw4 = torch.zeros((K, K, cin, cout), device="cuda")
+    ops.conv2d_bwd_partial(g, xd, dev(dy), dev(y_o), idx, act, 1.0, True, ws)
+    ops.conv2d_bwd_partial(g, xd, dev(dy), dev(y_o), idx, act, 1.0, False, ws2)
+    ops.conv2d_wgrad_finish([(g, ws, dw3, db3), (g, ws2, dw4, None)])
+    close(dw3, 2.0 + dw_o, what="deferred dw (accumulating)")
+    close(db3, 2.0 + db_o, what="deferred db (accumulating)")
+    close(dw4, dw_o, what="deferred dw, second job")
 
 
 @pytest.mark.parametrize("act", ["relu", "elu", "lrelu", "tanh", "sigmoid"])
@@ -447,3 +460,22 @@ def test_errors_are_loud():
     with pytest.raises(_lib.SpectrumHipError, match="workspace"):
         ops.conv2d_wgrad(g, x, torch.zeros((1, 8, 8, 4), device="cuda"), torch.zeros((3, 3, 3, 4), device="cuda"),
                          False, torch.empty(8, dtype=torch.uint8, device="cuda"))
+
+
+def test_convnet_entry_points_reject_what_they_do_not_cover():
+    """Chains outside the fused family are reported by the support query and refused with an error text."""
+    from spectrum_vae_amd import _lib, ops
+    ok = dict(Cin=3, Cout=8, K=3, up=1, pool=1, act="elu", alpha=1.0, w_off=0, b_off=216)
+    assert ops.convnet_supported(ops.net_layers([dict(ok, y=torch.empty(1, device="cuda"))]), 4, 32, 32)
+    bad_k = ops.net_layers([dict(ok, K=5)])
+    assert not ops.convnet_supported(bad_k, 4, 32, 32)
+    odd = ops.net_layers([dict(ok)])
+    assert not ops.convnet_supported(odd, 4, 31, 32)  # odd extent: no 2x2 tiling
+    chain = ops.net_layers([dict(ok), dict(ok, Cin=4)])  # channel mismatch between layers
+    assert not ops.convnet_supported(chain, 4, 32, 32)
+    x = torch.zeros(4, 32, 32, 3, device="cuda")
+    with pytest.raises(_lib.SpectrumHipError):
+        ops.convnet_fwd(bad_k, 4, 32, 32, x, x)
+    with pytest.raises(_lib.SpectrumHipError):  # supported shape but no output buffer
+        ops.convnet_fwd(ops.net_layers([dict(ok)]), 4, 32, 32, x, x)
+    assert ops.convnet_bwd_workspace(bad_k, 4, 32, 32, 1024) == 0
