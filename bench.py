@@ -97,6 +97,13 @@ class OpTimer:
                 info = {f: getattr(g, f) for f, _ in g._fields_}
                 if name == "sv_conv2d_bwd":  # which half ran: dx = args[6], dw = args[7]
                     info["half"] = "dgrad" if not args[7] else ("wgrad" if not args[6] else "both")
+            elif name == "sv_conv2d_wgrad_batch":
+                arr, nj = args[0], args[1]
+                fl = 0
+                for i in range(nj):
+                    q = arr[i].g
+                    fl += 2 * q.N * q.Ho * q.Wo * q.Cout * q.KH * q.KW * q.Cin
+                info = {"jobs": nj, "flops": fl, "single_launch": not args[2]}
             elif name == "sv_convnet_fwd":
                 arr, nl, n, h, w = args[0], args[1], args[2], args[3], args[4]
                 fl = 0
@@ -123,6 +130,8 @@ def kernel_of_call(name: str, g):
         return None
     if name == "sv_convnet_fwd":
         return "net_fwd_s1<3>", float(g["flops"])
+    if name == "sv_conv2d_wgrad_batch":
+        return ("wgrad_s1_multi<3>", float(g["flops"])) if g["single_launch"] else None
     if "KH" not in g:
         return None
     fl = 2.0 * g["N"] * g["Ho"] * g["Wo"] * g["Cout"] * g["KH"] * g["KW"] * g["Cin"]

@@ -120,12 +120,37 @@ typedef struct sv_wgrad_job {
     void* dw;
     void* db;
     int32_t accumulate;
-    int32_t reserved;
+    int32_t blocks;   /* workgroups per layer the producer was asked for (sv_wgrad_batch_job.blocks); 0: default */
 } sv_wgrad_job;
 int sv_conv2d_bwd_partial(const sv_conv_geom* g, const void* x, const void* dy, const void* y, const uint8_t* idx,
                           int act, float alpha, int with_bias, void* workspace, size_t workspace_bytes, int dtype,
                           sv_stream_t stream);
 int sv_conv2d_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, int dtype, sv_stream_t stream);
+
+/* ---- The kernel/bias gradients of SEVERAL layers of one backward pass in one launch: the same arithmetic as the
+ *      dw/db half of sv_conv2d_bwd per job.  The layers' gradients are independent once every dy exists (the
+ *      input-gradient chain has run), so their workgroups share the chip.  Each job needs its own workspace of
+ *      sv_conv2d_wgrad_workspace_bytes(g).  reduce != 0: also sum the partial sums into dw / db (a second launch);
+ *      reduce == 0: leave them in the workspaces for sv_conv2d_wgrad_finish (db != NULL here decides whether the
+ *      bias sums are formed).  3x3 kernels. */
+typedef struct sv_wgrad_batch_job {
+    sv_conv_geom g;
+    const void* x;        /* layer input */
+    const void* dy;       /* gradient w.r.t. the layer output (pooled extent when idx != NULL) */
+    const void* y;        /* layer output (after activation, pooled when idx != NULL) */
+    const uint8_t* idx;   /* pooling argmax or NULL */
+    void* dw;
+    void* db;             /* or NULL */
+    void* workspace;
+    uint64_t workspace_bytes;
+    int32_t act;
+    float alpha;
+    int32_t accumulate;
+    int32_t blocks;       /* workgroups for this layer, 0: default (512).  Fewer (e.g. 256) suits a batch of several
+                             layers: longer-lived workgroups, half the partial sums.  Never more than the default, which
+                             sizes the workspace. */
+} sv_wgrad_batch_job;
+int sv_conv2d_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, int dtype, sv_stream_t stream);
 
 /* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
 /* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */

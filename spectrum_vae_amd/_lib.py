@@ -39,7 +39,15 @@ class WgradJob(C.Structure):
     """Mirror of ``sv_wgrad_job``."""
 
     _fields_ = [("g", ConvGeom), ("workspace", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
-                ("accumulate", C.c_int32), ("reserved", C.c_int32)]
+                ("accumulate", C.c_int32), ("blocks", C.c_int32)]
+
+
+class WgradBatchJob(C.Structure):
+    """Mirror of ``sv_wgrad_batch_job``."""
+
+    _fields_ = [("g", ConvGeom), ("x", C.c_void_p), ("dy", C.c_void_p), ("y", C.c_void_p), ("idx", C.c_void_p),
+                ("dw", C.c_void_p), ("db", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
+                ("act", C.c_int32), ("alpha", C.c_float), ("accumulate", C.c_int32), ("blocks", C.c_int32)]
 
 
 _p, _i, _f, _i64, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64, C.c_size_t
@@ -62,6 +70,7 @@ SIGNATURES = {
     "sv_convnet_bwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _p, _p, _i64, _i, _p, _sz, _i, _p]),
     "sv_conv2d_bwd_partial": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p, _sz, _i, _p]),
     "sv_conv2d_wgrad_finish": (_i, [C.POINTER(WgradJob), _i, _i, _p]),
+    "sv_conv2d_wgrad_batch": (_i, [C.POINTER(WgradBatchJob), _i, _i, _i, _p]),
     "sv_conv2d_transpose_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_transpose_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
     "sv_conv2d_transpose_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),

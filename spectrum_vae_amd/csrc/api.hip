@@ -30,6 +30,7 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
                        int zmode = 0, const float* zy = nullptr, const uint8_t* zidx = nullptr, int zact = 0,
                        float zalpha = 0.f, int defer = 0, int with_bias = 0);
 int launch_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, hipStream_t st);
+int launch_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, hipStream_t st);
 
 // Stride-1 SAME conv with an odd square kernel and an isotropic folded upsampling: the LDS-tiled family.
 static bool tiled_shape(const sv_conv_geom& g) {
@@ -175,11 +176,31 @@ int sv_conv2d_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, int dtype, sv_s
         int rc = validate_geom(&jobs[j].g, "sv_conv2d_wgrad_finish");
         if (rc) return rc;
         SV_REQUIRE(jobs[j].workspace && jobs[j].dw, "sv_conv2d_wgrad_finish: job %d: null workspace or dw", j);
+        SV_REQUIRE(jobs[j].blocks >= 0 && jobs[j].blocks <= 512, "sv_conv2d_wgrad_finish: job %d: blocks must be 0..512", j);
         SV_REQUIRE(sv_conv2d_fused_supported(&jobs[j].g, 0), "sv_conv2d_wgrad_finish: job %d is outside the fused family", j);
     }
     for (int j0 = 0; j0 < n_jobs; j0 += 8) {
         const int n = n_jobs - j0 < 8 ? n_jobs - j0 : 8;
         int rc = launch_wgrad_finish(jobs + j0, n, to_stream(stream));
+        if (rc) return rc;
+    }
+    return SV_OK;
+}
+
+int sv_conv2d_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_wgrad_batch");
+    SV_REQUIRE(jobs != nullptr && n_jobs >= 0, "sv_conv2d_wgrad_batch: null job list");
+    for (int j = 0; j < n_jobs; ++j) {
+        int rc = validate_geom(&jobs[j].g, "sv_conv2d_wgrad_batch");
+        if (rc) return rc;
+        SV_REQUIRE(jobs[j].x && jobs[j].dy && jobs[j].y && jobs[j].dw, "sv_conv2d_wgrad_batch: job %d: null tensor", j);
+        SV_REQUIRE(jobs[j].blocks >= 0 && jobs[j].blocks <= 512, "sv_conv2d_wgrad_batch: job %d: blocks must be 0..512", j);
+        SV_REQUIRE(sv_conv2d_fused_supported(&jobs[j].g, jobs[j].idx != nullptr),
+                   "sv_conv2d_wgrad_batch: job %d is outside the fused family", j);
+    }
+    for (int j0 = 0; j0 < n_jobs; j0 += 8) {
+        const int n = n_jobs - j0 < 8 ? n_jobs - j0 : 8;
+        int rc = launch_wgrad_batch(jobs + j0, n, reduce, to_stream(stream));
         if (rc) return rc;
     }
     return SV_OK;

@@ -525,14 +525,19 @@ struct WgradArgs {
 //   offset = ((part * NCHUNK + slot / RS) * combos_max + combo) * RS + slot % RS,   combo = ci_local * n_cot + co_tile
 constexpr int kWgradRS = 20;
 
+struct BlockPos {
+    int bx, by, bz;  // workgroup coordinates
+    int gx, gy, gz;  // grid extents
+};
+
 template <int K, int CO_T>
-__global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const BlockPos bp) {
     constexpr int PADL = (K - 1) / 2;
     constexpr int XC = K + 3;  // x columns needed by a strip of 4 output pixels
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int ci_base = blockIdx.y * a.cib;
+    const int ci_base = bp.by * a.cib;
     const int cib = min(a.cib, a.Cin - ci_base);
-    const int co_base = blockIdx.z * a.cob;
+    const int co_base = bp.bz * a.cob;
     const int cob = min(a.cob, a.Cout - co_base);
     const int n_cot = (cob + CO_T - 1) / CO_T;
     float* x_lds = smem;                                       // [S][cib][xplane]   logical resolution + halo
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
         for (int q = 0; q < CO_T; ++q) acc[t][q] = 0.f;
 #pragma unroll
     for (int q = 0; q < CO_T; ++q) accb[q] = 0.f;
-    const bool do_bias = a.with_bias && live && cil == 0 && blockIdx.y == 0;
+    const bool do_bias = a.with_bias && live && cil == 0 && bp.by == 0;
 
     PlanarSrc xs;
     xs.x = a.x; xs.zy = nullptr; xs.zidx = nullptr; xs.mode = a.up == 2 ? 3 : 0; xs.zk = a.zk;
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
     for (int i = threadIdx.x; i < lds_f4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     SV_MARK(1);
 
-    for (int n0 = blockIdx.x * a.S; n0 < a.N; n0 += gridDim.x * a.S) {
+    for (int n0 = bp.bx * a.S; n0 < a.N; n0 += bp.gx * a.S) {
         const int ns = min(a.S, a.N - n0);
         __syncthreads();  // zero fill landed / previous pass is done reading
         stage_pass(xs, xd, make_stage_job(xs, n0, ns, ci_base, cib), x_lds, 256);
@@ -628,9 +633,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
     constexpr int NSLOT = K * K * CO_T + CO_T;
     constexpr int RS = kWgradRS;
     constexpr int NCHUNK = (NSLOT + RS - 1) / RS;
-    const int nparts = gridDim.y * gridDim.z;
-    const int part = blockIdx.z * gridDim.y + blockIdx.y;
-    float* out = a.slab + ((size_t)blockIdx.x * nparts + part) * NCHUNK * a.combos_max * RS;
+    const int nparts = bp.gy * bp.gz;
+    const int part = bp.bz * bp.gy + bp.by;
+    float* out = a.slab + ((size_t)bp.bx * nparts + part) * NCHUNK * a.combos_max * RS;
     float* red = smem;  // 256 * (RS + 1) floats = 21 KiB <= the LDS size the planner requests
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ++ch) {
@@ -656,6 +661,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
     SV_MARK(5);
 }
 
+template <int K, int CO_T>
+__global__ __launch_bounds__(256, 2) void wgrad_s1_lds(WgradArgs a) {
+    wgrad_body<K, CO_T>(a, BlockPos{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y,
+                                    (int)gridDim.z});
+}
+
+// The kernel gradients of several layers in ONE launch: workgroup ranges [first[j], first[j + 1]) belong to job j.
+// The layers are independent once every dy exists, so their workgroups share the chip and the staging phases of
+// one layer overlap the arithmetic of another instead of every launch idling through its own.
+constexpr int kMaxWgradJobs = 8;
+struct WgradMultiArgs {
+    int n_jobs;
+    int first[kMaxWgradJobs + 1];
+    int gx[kMaxWgradJobs], gy[kMaxWgradJobs], gz[kMaxWgradJobs], co_t[kMaxWgradJobs];
+    WgradArgs job[kMaxWgradJobs];
+};
+template <int K>
+__global__ __launch_bounds__(256, 2) void wgrad_s1_multi(WgradMultiArgs m) {
+    int j = 0;
+    while (j + 1 < m.n_jobs && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const int b = blockIdx.x - m.first[j];
+    BlockPos bp;
+    bp.gx = m.gx[j]; bp.gy = m.gy[j]; bp.gz = m.gz[j];
+    bp.bx = b % bp.gx;
+    const int r = b / bp.gx;
+    bp.by = r % bp.gy;
+    bp.bz = r / bp.gy;
+    if (m.co_t[j] == 8) wgrad_body<K, 8>(m.job[j], bp);
+    else wgrad_body<K, 4>(m.job[j], bp);
+}
+
 struct WgradPlan {
     bool ok;
     int S, cib, cob, PG, co_t, xplane, xwp, zplane, nblk, nchunk, combos_max;
@@ -663,7 +699,10 @@ struct WgradPlan {
     dim3 grid;
 };
 
-WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
+// tb: workgroups the launch should have per layer (512 = two per CU for a launch of its own; a batched launch, where
+// several layers share the chip, asks for fewer, longer-lived workgroups: less fold / slab work per sample)
+WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP, int tb = 512) {
+    if (tb < 1) tb = 512;
     WgradPlan p{};
     p.ok = false;
     const int Ho = Hs * UP, Wo = Ws * UP;
@@ -696,10 +735,10 @@ WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     const int ny0 = (Cin + cib - 1) / cib, nz0 = (Cout + cob - 1) / cob;
     int S = (4 * PG + strips - 1) / strips;
     if (S < 1) S = 1;
-    while (S > 1 && (int64_t)((N + S - 1) / S) * ny0 * nz0 < 512) S >>= 1;
+    while (S > 1 && (int64_t)((N + S - 1) / S) * ny0 * nz0 < tb) S >>= 1;
     // One pass per workgroup when the LDS allows it: the loads of all its samples are then in flight together
     // instead of one exposed global round trip per pass (512 workgroups = two per CU at this LDS budget).
-    const int one_pass = (int)(((int64_t)N * ny0 * nz0 + 511) / 512);
+    const int one_pass = (int)(((int64_t)N * ny0 * nz0 + tb - 1) / tb);
     if (one_pass > S && one_pass <= 8 && bytes(one_pass, cib, cob) <= kLdsBudget) S = one_pass;
     while (S > 1 && bytes(S, cib, cob) > kLdsBudget) --S;
     if (S > N) S = N;
@@ -709,7 +748,7 @@ WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP) {
     p.lds_bytes = (p.lds_bytes + 15) & ~(size_t)15;
     const int passes = (N + S - 1) / S;
     const int ny = (Cin + cib - 1) / cib, nz = (Cout + cob - 1) / cob;
-    int gx = 512 / (ny * nz);
+    int gx = tb / (ny * nz);
     if (gx < 1) gx = 1;
     if (gx > passes) gx = passes;
     p.nblk = gx;
@@ -829,7 +868,7 @@ int launch_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, hipStream_t st) {
     int blocks = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const sv_conv_geom& g = jobs[j].g;
-        WgradPlan p = plan_wgrad(g.N, g.H / g.up_h, g.W / g.up_w, g.Cin, g.Cout, g.KH, g.up_h);
+        WgradPlan p = plan_wgrad(g.N, g.H / g.up_h, g.W / g.up_w, g.Cin, g.Cout, g.KH, g.up_h, jobs[j].blocks);
         if (!p.ok) return fail(SV_E_UNSUPPORTED, "conv2d_wgrad_finish: job %d is outside the tiled family", j);
         fill_reduce_args(m.job[j], p, jobs[j].workspace, (float*)jobs[j].dw, (float*)jobs[j].db, jobs[j].accumulate, g.KH,
                          g.Cin, g.Cout);
@@ -838,6 +877,53 @@ int launch_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, hipStream_t st) {
     }
     m.first[n_jobs] = blocks;
     hipLaunchKernelGGL(wgrad_reduce_multi, dim3((unsigned)blocks), dim3(1024), 0, st, m);
+    return check_launch("wgrad_reduce_multi");
+}
+
+static void fill_wgrad_args(WgradArgs& a, const WgradPlan& p, const float* x, const float* dz, void* ws, int N, int Hs,
+                            int Ws, int Cin, int Cout, int UP, int zmode, const float* zy, const uint8_t* zidx, int zact,
+                            float zalpha, int with_bias) {
+    a.x = x; a.dz = dz; a.slab = (float*)ws;
+    a.N = N; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.Cout = Cout; a.Ho = Hs * UP; a.Wo = Ws * UP; a.up = UP;
+    a.S = p.S; a.cib = p.cib; a.cob = p.cob; a.PG = p.PG; a.xplane = p.xplane; a.xwp = p.xwp; a.zplane = p.zplane;
+    a.zmode = zmode; a.zy = zy; a.zidx = zidx; a.zk = act_grad_coef(zact, zalpha); a.with_bias = with_bias;
+    a.combos_max = p.combos_max;
+}
+
+// Kernel (+ bias) gradients of up to kMaxWgradJobs layers: one launch for the partial sums, one for the reductions.
+int launch_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, hipStream_t st) {
+    WgradMultiArgs m{};
+    ReduceMultiArgs rm{};
+    m.n_jobs = rm.n_jobs = n_jobs;
+    int blocks = 0, rblocks = 0;
+    size_t lds = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const sv_wgrad_batch_job& q = jobs[j];
+        const sv_conv_geom& g = q.g;
+        if (g.KH != 3) return fail(SV_E_UNSUPPORTED, "conv2d_wgrad_batch: job %d: 3x3 kernels only", j);
+        const int Hs = g.H / g.up_h, Ws = g.W / g.up_w;
+        WgradPlan p = plan_wgrad(g.N, Hs, Ws, g.Cin, g.Cout, g.KH, g.up_h, q.blocks);
+        if (!p.ok) return fail(SV_E_UNSUPPORTED, "conv2d_wgrad_batch: job %d is outside the tiled family", j);
+        const size_t need = (size_t)p.nblk * p.slab_floats * sizeof(float);
+        if (q.workspace == nullptr || q.workspace_bytes < need)
+            return fail(SV_E_WORKSPACE, "conv2d_wgrad_batch: job %d: workspace %zu bytes < required %zu", j,
+                        (size_t)q.workspace_bytes, need);
+        fill_wgrad_args(m.job[j], p, (const float*)q.x, (const float*)q.dy, q.workspace, g.N, Hs, Ws, g.Cin, g.Cout, g.up_h,
+                        q.idx != nullptr ? 2 : 1, (const float*)q.y, q.idx, q.act, q.alpha, q.db != nullptr);
+        m.first[j] = blocks;
+        m.gx[j] = (int)p.grid.x; m.gy[j] = (int)p.grid.y; m.gz[j] = (int)p.grid.z; m.co_t[j] = p.co_t;
+        blocks += (int)(p.grid.x * p.grid.y * p.grid.z);
+        if (p.lds_bytes > lds) lds = p.lds_bytes;
+        fill_reduce_args(rm.job[j], p, q.workspace, (float*)q.dw, (float*)q.db, q.accumulate, g.KH, g.Cin, g.Cout);
+        rm.first[j] = rblocks;
+        rblocks += (int)ceil_div((int64_t)p.slab_floats, 64);
+    }
+    m.first[n_jobs] = blocks;
+    rm.first[n_jobs] = rblocks;
+    hipLaunchKernelGGL((wgrad_s1_multi<3>), dim3((unsigned)blocks), dim3(256), lds, st, m);
+    int rc = check_launch("wgrad_s1_multi");
+    if (rc || !reduce) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_multi, dim3((unsigned)rblocks), dim3(1024), 0, st, rm);
     return check_launch("wgrad_reduce_multi");
 }
 

@@ -80,6 +80,7 @@ class Model(Layer):
         # Run the whole forward as ONE launch when the model is a plain chain of fusable 3x3 convs (see
         # ``_conv_chain``); the per-layer buffers are filled exactly as the per-layer path fills them.
         self.use_net_fused = True
+        self.wgrad_batch_blocks = 256   # workgroups per layer when >= 3 layers share the batched kernel-gradient launch
         self.defer_wgrad_reduce = True  # one reduction launch for the kernel gradients of all fused conv layers
         # The whole backward as one launch (sv_convnet_bwd) is correct but, with one sample in flight per workgroup,
         # slower than the per-layer kernels at the batch sizes measured so far: opt-in.
@@ -331,9 +332,11 @@ class Model(Layer):
                 ops.convnet_bwd(arr, n, h, w, x, self._params, dyt, self._grads, True, self._pool.workspace(nbytes))
                 return None
         if self.defer_wgrad_reduce and ctx.param_grads and ctx.wgrad_jobs is None:
-            ctx.wgrad_jobs = []
+            ctx.wgrad_jobs, ctx.wgrad_finish = [], []
             dx = self.backward(ctx, dy, need_dx=need_dx)
-            ops.conv2d_wgrad_finish(ctx.wgrad_jobs)
+            nb = self.wgrad_batch_blocks if len(ctx.wgrad_jobs) >= 3 else 0
+            ops.conv2d_wgrad_batch(ctx.wgrad_jobs, reduce=False, blocks=nb)
+            ops.conv2d_wgrad_finish(ctx.wgrad_finish + [(j["g"], j["ws"], j["dw"], j["db"], nb) for j in ctx.wgrad_jobs])
             ctx.wgrad_jobs = None
             return dx
         return self.backward(ctx, dy, need_dx=need_dx)

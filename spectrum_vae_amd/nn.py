@@ -167,6 +167,7 @@ class CallCtx:
         # A list: fused conv layers leave their kernel-gradient partial sums in per-layer workspaces and append a job
         # here; the owner finishes all of them with one launch after the backward pass.  None: reduce per layer.
         self.wgrad_jobs: Optional[list] = None
+        self.wgrad_finish: list = []
 
     def buf(self, layer, role, shape, dtype=torch.float32):
         return self.pool.get((id(layer), role, self.slot), shape, dtype)
@@ -357,8 +358,13 @@ class _ConvBase(Layer):
             db = self.bias.grad if self.bias is not None else None
             if ctx.wgrad_jobs is not None and not ctx.side:
                 ws = ctx.buf(self, "wgrad_ws", (max(ops.conv2d_wgrad_workspace(g), 16),), torch.uint8)
-                ops.conv2d_bwd_partial(g, x, dy, y, s.get("idx"), self.act, self.alpha, db is not None, ws)
-                ctx.wgrad_jobs.append((g, ws, self.kernel.grad, db))
+                if self.kernel_size == (3, 3):
+                    # launched by the owner, together with the other layers' jobs, once the whole dy chain exists
+                    ctx.wgrad_jobs.append(dict(g=g, x=x, dy=dy, y=y, idx=s.get("idx"), act=self.act, alpha=self.alpha,
+                                               dw=self.kernel.grad, db=db, ws=ws))
+                else:
+                    ops.conv2d_bwd_partial(g, x, dy, y, s.get("idx"), self.act, self.alpha, db is not None, ws)
+                    ctx.wgrad_finish.append((g, ws, self.kernel.grad, db))
                 if need_dx:
                     ops.conv2d_bwd(g, None, self.kernel.data, dy, y, s.get("idx"), dx, None, None, self.act, self.alpha,
                                    None)

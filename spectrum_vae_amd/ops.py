@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT, F32, ConvGeom, NetLayer, WgradJob, check, lib
+from ._lib import ACT, F32, ConvGeom, NetLayer, WgradBatchJob, WgradJob, check, lib
 
 
 def _stream() -> int:
@@ -132,15 +132,31 @@ def conv2d_bwd_partial(g: ConvGeom, x, dy, y, idx, act: str, alpha: float, with_
           "sv_conv2d_bwd_partial")
 
 
+def conv2d_wgrad_batch(jobs, reduce: bool = True, blocks: int = 0):
+    """jobs: list of dicts g, x, dy, y, idx, act, alpha, dw, db, ws; gradients accumulate into dw / db (reduce=False:
+    the partial sums stay in the workspaces for ``conv2d_wgrad_finish``)."""
+    if not jobs:
+        return
+    arr = (WgradBatchJob * len(jobs))()
+    for a, d in zip(arr, jobs):
+        a.g = d["g"]
+        a.x, a.dy, a.y, a.idx = _ptr(d["x"]), _ptr(d["dy"]), _ptr(d["y"]), _ptr(d.get("idx"), torch.uint8)
+        a.dw, a.db = _ptr(d["dw"]), _ptr(d.get("db"))
+        a.workspace, a.workspace_bytes = _ptr(d["ws"], torch.uint8), d["ws"].numel()
+        a.act, a.alpha, a.accumulate, a.blocks = ACT[d["act"]], float(d["alpha"] or 0.0), 1, blocks
+    check(lib.sv_conv2d_wgrad_batch(arr, len(jobs), int(reduce), F32, _stream()), "sv_conv2d_wgrad_batch")
+
+
 def conv2d_wgrad_finish(jobs):
-    """jobs: list of (geom, workspace, dw, db or None); gradients accumulate into dw / db."""
+    """jobs: list of (geom, workspace, dw, db or None[, blocks]); gradients accumulate into dw / db."""
     if not jobs:
         return
     arr = (WgradJob * len(jobs))()
-    for a, (g, ws, dw, db) in zip(arr, jobs):
+    for a, job in zip(arr, jobs):
+        g, ws, dw, db = job[:4]
         a.g = g
         a.workspace, a.dw, a.db = _ptr(ws, torch.uint8), _ptr(dw), _ptr(db)
-        a.accumulate, a.reserved = 1, 0
+        a.accumulate, a.blocks = 1, (job[4] if len(job) > 4 else 0)
     check(lib.sv_conv2d_wgrad_finish(arr, len(jobs), F32, _stream()), "sv_conv2d_wgrad_finish")
 
 

@@ -479,3 +479,45 @@ def test_convnet_entry_points_reject_what_they_do_not_cover():
     with pytest.raises(_lib.SpectrumHipError):  # supported shape but no output buffer
         ops.convnet_fwd(ops.net_layers([dict(ok)]), 4, 32, 32, x, x)
     assert ops.convnet_bwd_workspace(bad_k, 4, 32, 32, 1024) == 0
+
+
+def test_conv2d_wgrad_batch_matches_per_layer_calls():
+    """Several layers' kernel gradients from one launch equal the per-layer fused backward, bit for bit."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(5)
+    specs = [(16, 16, 8, 16, 1, True, "elu"), (4, 4, 32, 16, 2, False, "elu"), (32, 32, 3, 8, 1, True, "relu"),
+             (16, 16, 8, 3, 2, False, "tanh")]
+    n = 6
+    jobs, want = [], []
+    for h, w, cin, cout, up, pooled, act in specs:
+        H, W = h * up, w * up
+        g = ops.conv_geom(n, H, W, cin, 3, 3, 1, 1, "same", cout, (up, up))
+        oh, ow = (H // 2, W // 2) if pooled else (H, W)
+        x = dev(rng.standard_normal((n, h, w, cin)))
+        y = dev(rng.standard_normal((n, oh, ow, cout)))
+        dy = dev(rng.standard_normal((n, oh, ow, cout)))
+        idx = torch.from_numpy(rng.integers(0, 4, (n, oh, ow, cout)).astype(np.uint8)).cuda() if pooled else None
+        wt = dev(rng.standard_normal((3, 3, cin, cout)))
+        ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device="cuda")
+        dw_ref, db_ref = torch.zeros(3, 3, cin, cout, device="cuda"), torch.zeros(cout, device="cuda")
+        ops.conv2d_bwd(g, x, wt, dy, y, idx, None, dw_ref, db_ref, act, 1.0, ws)
+        want.append((dw_ref, db_ref))
+        jobs.append(dict(g=g, x=x, dy=dy, y=y, idx=idx, act=act, alpha=1.0, dw=torch.zeros_like(dw_ref),
+                         db=torch.zeros_like(db_ref), ws=torch.empty_like(ws)))
+    ops.conv2d_wgrad_batch(jobs, reduce=True)
+    for j, (dw_ref, db_ref) in zip(jobs, want):
+        assert torch.equal(j["dw"], dw_ref) and torch.equal(j["db"], db_ref)
+    for j in jobs:
+        j["dw"].zero_(), j["db"].zero_()
+    ops.conv2d_wgrad_batch(jobs, reduce=False)
+    ops.conv2d_wgrad_finish([(j["g"], j["ws"], j["dw"], j["db"]) for j in jobs])
+    for j, (dw_ref, db_ref) in zip(jobs, want):
+        assert torch.equal(j["dw"], dw_ref) and torch.equal(j["db"], db_ref)
+    # fewer, longer-lived workgroups per layer: another summation order, same sums to rounding
+    for j in jobs:
+        j["dw"].zero_(), j["db"].zero_()
+    ops.conv2d_wgrad_batch(jobs, reduce=False, blocks=2)
+    ops.conv2d_wgrad_finish([(j["g"], j["ws"], j["dw"], j["db"], 2) for j in jobs])
+    for j, (dw_ref, db_ref) in zip(jobs, want):
+        close(j["dw"], dw_ref.cpu().numpy(), what="batched dw, 2 workgroups")
+        close(j["db"], db_ref.cpu().numpy(), what="batched db, 2 workgroups")
