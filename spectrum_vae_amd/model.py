@@ -9,6 +9,7 @@ batch_size=)`` -> ``.history["loss"|"val_loss"]``, ``model.predict(X, batch_size
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -80,7 +81,7 @@ class Model(Layer):
         # Run the whole forward as ONE launch when the model is a plain chain of fusable 3x3 convs (see
         # ``_conv_chain``); the per-layer buffers are filled exactly as the per-layer path fills them.
         self.use_net_fused = True
-        self.wgrad_batch_blocks = 256   # workgroups per layer when >= 3 layers share the batched kernel-gradient launch
+        self.wgrad_batch_blocks = int(os.environ.get("SPECTRUM_WGRAD_BLOCKS", "256"))  # workgroups per layer when >= 3 layers share the batched kernel-gradient launch
         self.defer_wgrad_reduce = True  # one reduction launch for the kernel gradients of all fused conv layers
         # The whole backward as one launch (sv_convnet_bwd) is correct but, with one sample in flight per workgroup,
         # slower than the per-layer kernels at the batch sizes measured so far: opt-in.
