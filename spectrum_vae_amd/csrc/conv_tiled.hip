@@ -85,27 +85,52 @@ __device__ __forceinline__ WJob make_wjob(const TiledArgs& a, int ci0, int cic, 
 template <int K, int CO_T>
 __device__ __forceinline__ void w_pass(const TiledArgs& a, const WJob& j, float* w_lds, int nt) {
     const FDiv fcic = fd_make(j.cic), fcoc = fd_make(j.coc);
+    constexpr int U = 4;  // float4 loads issued per thread before the first LDS write (indices clamped: unconditional)
     if (j.kind == 0) {
         const int c4n = j.coc >> 2;
         const FDiv f4 = fd_make(c4n);
-#pragma unroll 4
-        for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int r = fd(u, f4), co4 = u - r * c4n;
-            const int tap = fd(r, fcic), c = r - tap * j.cic;
-            const float4 v = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.Cin + j.ci0 + c) * a.Cout + j.co_base + 4 * co4);
-            *reinterpret_cast<float4*>(w_lds + w_lds_index<K, CO_T>(4 * co4, c, tap, a.cic)) = v;
+        for (int u0 = threadIdx.x; u0 < j.units; u0 += U * nt) {
+            float4 v[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = min(u0 + i * nt, j.units - 1);
+                const int r = fd(u, f4), co4 = u - r * c4n;
+                const int tap = fd(r, fcic), c = r - tap * j.cic;
+                v[i] = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.Cin + j.ci0 + c) * a.Cout + j.co_base + 4 * co4);
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = u0 + i * nt;
+                if (u < j.units) {
+                    const int r = fd(u, f4), co4 = u - r * c4n;
+                    const int tap = fd(r, fcic), c = r - tap * j.cic;
+                    *reinterpret_cast<float4*>(w_lds + w_lds_index<K, CO_T>(4 * co4, c, tap, a.cic)) = v[i];
+                }
+            }
         }
     } else if (j.kind == 1) {
         const int c4n = j.cic >> 2;
         const FDiv f4 = fd_make(c4n);
-#pragma unroll 4
-        for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int r = fd(u, f4), c4 = u - r * c4n;
-            const int tap = fd(r, fcoc), co = r - tap * j.coc;
-            const float4 v = *reinterpret_cast<const float4*>(a.w + ((size_t)(K * K - 1 - tap) * a.Cout + j.co_base + co) * a.Cin +
-                                                              j.ci0 + 4 * c4);
-            float* q = w_lds + w_lds_index<K, CO_T>(co, 4 * c4, tap, a.cic);
-            q[0] = v.x; q[K * K * CO_T] = v.y; q[2 * K * K * CO_T] = v.z; q[3 * K * K * CO_T] = v.w;
+        for (int u0 = threadIdx.x; u0 < j.units; u0 += U * nt) {
+            float4 v[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = min(u0 + i * nt, j.units - 1);
+                const int r = fd(u, f4), c4 = u - r * c4n;
+                const int tap = fd(r, fcoc), co = r - tap * j.coc;
+                v[i] = *reinterpret_cast<const float4*>(a.w + ((size_t)(K * K - 1 - tap) * a.Cout + j.co_base + co) * a.Cin +
+                                                        j.ci0 + 4 * c4);
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = u0 + i * nt;
+                if (u < j.units) {
+                    const int r = fd(u, f4), c4 = u - r * c4n;
+                    const int tap = fd(r, fcoc), co = r - tap * j.coc;
+                    float* q = w_lds + w_lds_index<K, CO_T>(co, 4 * c4, tap, a.cic);
+                    q[0] = v[i].x; q[K * K * CO_T] = v[i].y; q[2 * K * K * CO_T] = v[i].z; q[3 * K * K * CO_T] = v[i].w;
+                }
+            }
         }
     } else if (a.wflip) {
 #pragma unroll 4

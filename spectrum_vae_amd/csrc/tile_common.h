@@ -93,44 +93,68 @@ __device__ __forceinline__ void stage_pass_m(const PlanarSrc& s, const PlanarDst
     const int HW = s.Hs * s.Ws;
     const FDiv fHW = fd_make(HW), fW = fd_make(s.Ws);
     constexpr bool need_y = MODE == 1 || MODE == 2;
+    constexpr int U = 4;  // units per batch: all their loads are issued (index clamped, so unconditional) before any use
     if (j.kind == 0) {
         const FDiv fC4 = fd_make(j.C4);
-#pragma unroll 4
-        for (int u = threadIdx.x; u < j.units; u += nt) {
-            const int p = fd(u, fC4), cl = u - p * j.C4;
-            const size_t gi = j.base + (size_t)p * s.C + j.c0 + 4 * cl;
-            const float4 v = *reinterpret_cast<const float4*>(s.x + gi);
-            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t k = 0;
-            if (need_y) y = *reinterpret_cast<const float4*>(s.zy + gi);
-            if (MODE == 2) k = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
-            const int ss = fd(p, fHW), pp = p - ss * HW;
-            const int row = fd(pp, fW), col = pp - row * s.Ws;
-            float* q = lds + (size_t)(ss * d.cpl + 4 * cl) * d.plane;
-            stage_put<MODE>(s, d, q, row, col, v.x, y.x, k & 0xff);
-            stage_put<MODE>(s, d, q + d.plane, row, col, v.y, y.y, (k >> 8) & 0xff);
-            stage_put<MODE>(s, d, q + 2 * d.plane, row, col, v.z, y.z, (k >> 16) & 0xff);
-            stage_put<MODE>(s, d, q + 3 * d.plane, row, col, v.w, y.w, k >> 24);
+        for (int u0 = threadIdx.x; u0 < j.units; u0 += U * nt) {
+            float4 v[U], y[U];
+            uint32_t k[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = min(u0 + i * nt, j.units - 1);
+                const int p = fd(u, fC4), cl = u - p * j.C4;
+                const size_t gi = j.base + (size_t)p * s.C + j.c0 + 4 * cl;
+                v[i] = *reinterpret_cast<const float4*>(s.x + gi);
+                y[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                k[i] = 0;
+                if (need_y) y[i] = *reinterpret_cast<const float4*>(s.zy + gi);
+                if (MODE == 2) k[i] = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = u0 + i * nt;
+                if (u < j.units) {
+                    const int p = fd(u, fC4), cl = u - p * j.C4;
+                    const int ss = fd(p, fHW), pp = p - ss * HW;
+                    const int row = fd(pp, fW), col = pp - row * s.Ws;
+                    float* q = lds + (size_t)(ss * d.cpl + 4 * cl) * d.plane;
+                    stage_put<MODE>(s, d, q, row, col, v[i].x, y[i].x, k[i] & 0xff);
+                    stage_put<MODE>(s, d, q + d.plane, row, col, v[i].y, y[i].y, (k[i] >> 8) & 0xff);
+                    stage_put<MODE>(s, d, q + 2 * d.plane, row, col, v[i].z, y[i].z, (k[i] >> 16) & 0xff);
+                    stage_put<MODE>(s, d, q + 3 * d.plane, row, col, v[i].w, y[i].w, k[i] >> 24);
+                }
+            }
         }
     } else if (j.kind == 1) {
         const FDiv fC = fd_make(s.C);
-#pragma unroll 4
-        for (int u = threadIdx.x; u < j.units; u += nt) {
-            const size_t gi = j.base + 4 * (size_t)u;
-            const float4 v = *reinterpret_cast<const float4*>(s.x + gi);
-            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t k = 0;
-            if (need_y) y = *reinterpret_cast<const float4*>(s.zy + gi);
-            if (MODE == 2) k = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
-            const float xv[4] = {v.x, v.y, v.z, v.w};
-            const float yv[4] = {y.x, y.y, y.z, y.w};
+        for (int u0 = threadIdx.x; u0 < j.units; u0 += U * nt) {
+            float4 v[U], y[U];
+            uint32_t k[U];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int e = 4 * u + t;
-                const int p = fd(e, fC), c = e - p * s.C;
-                const int ss = fd(p, fHW), pp = p - ss * HW;
-                const int row = fd(pp, fW), col = pp - row * s.Ws;
-                stage_put<MODE>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, row, col, xv[t], yv[t], (k >> (8 * t)) & 0xff);
+            for (int i = 0; i < U; ++i) {
+                const size_t gi = j.base + 4 * (size_t)min(u0 + i * nt, j.units - 1);
+                v[i] = *reinterpret_cast<const float4*>(s.x + gi);
+                y[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                k[i] = 0;
+                if (need_y) y[i] = *reinterpret_cast<const float4*>(s.zy + gi);
+                if (MODE == 2) k[i] = *reinterpret_cast<const uint32_t*>(s.zidx + gi);
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = u0 + i * nt;
+                if (u < j.units) {
+                    const float xv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                    const float yv[4] = {y[i].x, y[i].y, y[i].z, y[i].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = 4 * u + t;
+                        const int p = fd(e, fC), c = e - p * s.C;
+                        const int ss = fd(p, fHW), pp = p - ss * HW;
+                        const int row = fd(pp, fW), col = pp - row * s.Ws;
+                        stage_put<MODE>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, row, col, xv[t], yv[t],
+                                        (k[i] >> (8 * t)) & 0xff);
+                    }
+                }
             }
         }
     } else {
