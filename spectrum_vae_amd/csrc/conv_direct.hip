@@ -9,6 +9,16 @@
 
 namespace sv {
 
+// conv_gemm.hip: implicit GEMM on the matrix cores for the GEMM-shaped geometries
+bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode);
+int conv_gemm_wgrad_splits(const sv_conv_geom& g);
+size_t conv_gemm_wgrad_workspace(const sv_conv_geom& g);
+int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                         float alpha, hipStream_t st);
+int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx, int act,
+                           float alpha, hipStream_t st);
+int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------------ forward
 // y[n,oh,ow,co] = act(bias[co] + sum_{kh,kw,ci} x[n, (oh*SH+kh-pt)/up_h, (ow*SW+kw-pl)/up_w, ci] * w[kh,kw,ci,co])
 template <int CO_T>
@@ -208,6 +218,7 @@ int validate_geom(const sv_conv_geom* g, const char* who) {
 
 int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
                       float alpha, hipStream_t st) {
+    if (conv_gemm_worthwhile(g, 0)) return launch_conv_gemm_fwd(g, x, w, bias, y, act, alpha, st);
     const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
     const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
     dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cout, cot));
@@ -222,6 +233,7 @@ int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, con
 
 int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx,
                         int act, float alpha, hipStream_t st) {
+    if (conv_gemm_worthwhile(g, 1)) return launch_conv_gemm_dgrad(g, dz, w, bias, dx, act, alpha, st);
     const int64_t npix = (int64_t)g.N * (g.H / g.up_h) * (g.W / g.up_w);
     const int cit = g.Cin >= 16 ? 16 : (g.Cin > 4 ? 8 : 4);
     dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cin, cit));
@@ -248,16 +260,26 @@ int wgrad_direct_splits(const sv_conv_geom& g) {
 }
 
 size_t wgrad_direct_workspace(const sv_conv_geom& g) {
-    return (size_t)wgrad_direct_splits(g) * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
+    const size_t direct = (size_t)wgrad_direct_splits(g) * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
+    const size_t gemm = conv_gemm_wgrad_workspace(g);
+    return direct > gemm ? direct : gemm;
 }
 
 int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, float* dw, int accumulate,
                         void* ws, size_t ws_bytes, hipStream_t st) {
-    const int ns = wgrad_direct_splits(g);
     const int64_t kc = (int64_t)g.KH * g.KW * g.Cin * g.Cout;
     if (ws == nullptr || ws_bytes < wgrad_direct_workspace(g))
         return fail(SV_E_WORKSPACE, "conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes,
                     wgrad_direct_workspace(g));
+    if (conv_gemm_worthwhile(g, 2)) {
+        const int splits = conv_gemm_wgrad_splits(g);
+        int rc = launch_conv_gemm_wgrad(g, x, dz, (float*)ws, splits, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, (const float*)ws, dw, kc, splits,
+                           accumulate);
+        return check_launch("wgrad_reduce");
+    }
+    const int ns = wgrad_direct_splits(g);
     const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
     const int64_t pps = ceil_div(npix, ns);
     const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);

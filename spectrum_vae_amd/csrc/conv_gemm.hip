@@ -1,0 +1,274 @@
+// Implicit-GEMM convolution on the matrix cores (f32 MFMA 16x16x4) for the GEMM-shaped geometries that the LDS-tiled
+// family does not cover: strided 4x4 / 2x2 convs and transposed convs with 16..1000 channels (U-Net, context encoder,
+// discriminators), the 4x4 VALID bottleneck pair (a 2048 x 1000 GEMM), any kernel size / stride / padding.
+//
+//   forward        Y[(n,oh,ow)][co]   = sum_k  X(n, oh*SH-pt+kh, ow*SW-pl+kw, ci) * W[(kh,kw,ci)][co]
+//   input gradient dX[(n,ih,iw)][ci]  = sum_k  dZ(n, (ih+pt-kh)/SH, (iw+pl-kw)/SW, co) * W[kh][kw][ci][co],  k = (kh,kw,co)
+//   kernel gradient dW[(kh,kw,ci)][co] = sum_r X(...) * dZ[r][co],  r = (n,oh,ow), split over workgroups (slabs + fixed-order sum)
+//
+// Nothing is materialised: a workgroup (4 waves) owns a 64 x 64 tile of the result and walks the reduction in steps of
+// 16; the A / B tiles are gathered straight from the NHWC tensors into LDS (k-major, so the MFMA operand reads are
+// conflict-free), each wave holds a 32 x 32 sub-tile as 2 x 2 MFMA accumulators.
+// Lane l of an MFMA feeds A[row l % 16][k l / 16], B[k l / 16][col l % 16] and receives D[4 * (l / 16) + r][l % 16].
+#include "tile_common.h"
+
+namespace sv {
+
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+enum { GEMM_FWD = 0, GEMM_DGRAD = 1, GEMM_WGRAD = 2 };
+
+struct ConvGemmArgs {
+    sv_conv_geom g;
+    const float* a;     // FWD/WGRAD: x;  DGRAD: dz
+    const float* b;     // FWD/DGRAD: w;  WGRAD: dz
+    const float* bias;  // FWD / DGRAD epilogue (may be null)
+    float* c;           // FWD: y;  DGRAD: dx;  WGRAD: slabs [split][M][N]
+    int M, N, K;        // GEMM extents (K: reduction)
+    int k_per_split;    // WGRAD: reduction elements per blockIdx.z
+    int act;
+    float alpha;
+    FDiv f_wo, f_howo;  // FWD/WGRAD rows r -> (n, oh, ow);  DGRAD rows -> (n, ih, iw) (then these divide by W, H*W)
+    FDiv f_ck, f_kw;    // reduction / row index (tap, channel): divide by the channel count, then by KW
+};
+
+constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS row pitch (floats): 64 + 4
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+    const sv_conv_geom& g = p.g;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+
+    int kbeg = 0, kend = p.K;
+    if (MODE == GEMM_WGRAD) {
+        kbeg = blockIdx.z * p.k_per_split;
+        kend = min(p.K, kbeg + p.k_per_split);
+    }
+
+    // ---- per-thread row bookkeeping of the A gather (fixed over the reduction loop)
+    // FWD / DGRAD: thread loads k = t & 15 of rows (t >> 4) + 16 i;  WGRAD: row m = t & 63, reduction (t >> 6) + 4 i
+    int r_img[4], r_h[4], r_w[4];
+    bool r_ok[4];
+    int a_kh = 0, a_kw = 0, a_ci = 0;
+    bool a_ok = true;
+    if (MODE == GEMM_WGRAD) {
+        const int m = m0 + (t & 63);
+        a_ok = m < p.M;
+        const int tap = a_ok ? fd(m, p.f_ck) : 0;
+        a_ci = a_ok ? m - tap * g.Cin : 0;
+        a_kh = fd(tap, p.f_kw);
+        a_kw = tap - a_kh * g.KW;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (t >> 4) + 16 * i;
+            r_ok[i] = m < p.M;
+            const int mm = r_ok[i] ? m : 0;
+            const int img = fd(mm, p.f_howo);
+            const int rem = mm - img * p.f_howo.d;
+            const int hh = fd(rem, p.f_wo);
+            r_img[i] = img; r_h[i] = hh; r_w[i] = rem - hh * p.f_wo.d;
+        }
+    }
+
+    v4f_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = v4f_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        float av[4], bv[4];
+        // ---- gather A
+        if (MODE == GEMM_FWD) {
+            const int k = k0 + (t & 15);
+            const bool kok = k < kend;
+            const int kk = kok ? k : 0;
+            const int tap = fd(kk, p.f_ck), ci = kk - tap * g.Cin;
+            const int kh = fd(tap, p.f_kw), kw = tap - kh * g.KW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ih = r_h[i] * g.SH - g.pad_t + kh, iw = r_w[i] * g.SW - g.pad_l + kw;
+                const bool ok = kok && r_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+                av[i] = ok ? p.a[(((int64_t)r_img[i] * g.H + ih) * g.W + iw) * g.Cin + ci] : 0.f;
+            }
+        } else if (MODE == GEMM_DGRAD) {
+            const int k = k0 + (t & 15);
+            const bool kok = k < kend;
+            const int kk = kok ? k : 0;
+            const int tap = fd(kk, p.f_ck), co = kk - tap * g.Cout;
+            const int kh = fd(tap, p.f_kw), kw = tap - kh * g.KW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
+                const int oh = th / g.SH, ow = tw / g.SW;
+                const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh * g.SH == th && ow * g.SW == tw && oh < g.Ho &&
+                                ow < g.Wo;
+                av[i] = ok ? p.a[(((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = k0 + (t >> 6) + 4 * i;
+                const bool rok = a_ok && r < kend;
+                const int rr = rok ? r : 0;
+                const int img = fd(rr, p.f_howo);
+                const int rem = rr - img * p.f_howo.d;
+                const int oh = fd(rem, p.f_wo), ow = rem - oh * p.f_wo.d;
+                const int ih = oh * g.SH - g.pad_t + a_kh, iw = ow * g.SW - g.pad_l + a_kw;
+                const bool ok = rok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+                av[i] = ok ? p.a[(((int64_t)img * g.H + ih) * g.W + iw) * g.Cin + a_ci] : 0.f;
+            }
+        }
+        // ---- gather B
+        if (MODE == GEMM_DGRAD) {
+            const int k = k0 + (t & 15);
+            const bool kok = k < kend;
+            const int kk = kok ? k : 0;
+            const int tap = fd(kk, p.f_ck), co = kk - tap * g.Cout;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + (t >> 4) + 16 * i;
+                bv[i] = (kok && n < p.N) ? p.b[((int64_t)tap * g.Cin + n) * g.Cout + co] : 0.f;
+            }
+        } else {
+            const int n = n0 + (t & 63);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + (t >> 6) + 4 * i;
+                bv[i] = (k < kend && n < p.N) ? p.b[(int64_t)k * p.N + n] : 0.f;
+            }
+        }
+        __syncthreads();  // the previous step's MFMA reads are done
+        if (MODE == GEMM_WGRAD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[(t >> 6) + 4 * i][t & 63] = av[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[t & 15][(t >> 4) + 16 * i] = av[i];
+        }
+        if (MODE == GEMM_DGRAD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Bs[t & 15][(t >> 4) + 16 * i] = bv[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Bs[(t >> 6) + 4 * i][t & 63] = bv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[kk + lk][wm + 16 * i + li];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[kk + lk][wn + 16 * j + li];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue
+    float* out = p.c;
+    if (MODE == GEMM_WGRAD) out += (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 16 * j + li;
+            if (n >= p.N) continue;
+            const float bb = (MODE != GEMM_WGRAD && p.bias != nullptr) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + 16 * i + 4 * lk + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (MODE != GEMM_WGRAD) v = act_apply(v + bb, p.act, p.alpha);
+                out[(size_t)m * p.N + n] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------ host side
+// The GEMM path pays off when the "column" dimension fills a good part of a 16-wide MFMA tile.
+bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode) {
+    if (g.up_h != 1 || g.up_w != 1) return false;
+    const int ncols = mode == GEMM_DGRAD ? g.Cin : g.Cout;
+    const int64_t kdim = mode == GEMM_DGRAD ? (int64_t)g.KH * g.KW * g.Cout
+                                            : (mode == GEMM_FWD ? (int64_t)g.KH * g.KW * g.Cin : (int64_t)g.N * g.Ho * g.Wo);
+    const int64_t rows = mode == GEMM_FWD ? (int64_t)g.N * g.Ho * g.Wo
+                                          : (mode == GEMM_DGRAD ? (int64_t)g.N * g.H * g.W : (int64_t)g.KH * g.KW * g.Cin);
+    // index decoding uses 32-bit multiply-shift division: keep index * divisor below 2^32
+    const int64_t sp = mode == GEMM_DGRAD ? (int64_t)g.H * g.W : (int64_t)g.Ho * g.Wo;
+    const int64_t rdec = mode == GEMM_WGRAD ? kdim : rows, cdec = mode == GEMM_WGRAD ? rows : kdim;
+    if (rdec * sp >= (1ll << 32) || cdec * (g.Cin > g.Cout ? g.Cin : g.Cout) >= (1ll << 32)) return false;
+    return ncols >= 12 && kdim >= 4 && rows < (1ll << 30) && kdim < (1ll << 30);
+}
+
+int conv_gemm_wgrad_splits(const sv_conv_geom& g) {
+    const int64_t M = (int64_t)g.KH * g.KW * g.Cin, R = (int64_t)g.N * g.Ho * g.Wo;
+    const int64_t tiles = ceil_div(M, BM) * ceil_div(g.Cout, BN);
+    int64_t s = ceil_div(512, tiles);
+    const int64_t maxs = ceil_div(R, 4 * BK);
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
+size_t conv_gemm_wgrad_workspace(const sv_conv_geom& g) {
+    if (!conv_gemm_worthwhile(g, GEMM_WGRAD)) return 0;
+    return (size_t)conv_gemm_wgrad_splits(g) * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
+}
+
+static void fill_common(ConvGemmArgs& p, const sv_conv_geom& g, int mode) {
+    p.g = g;
+    if (mode == GEMM_DGRAD) {
+        p.f_wo = fd_make(g.W); p.f_howo = fd_make(g.H * g.W); p.f_ck = fd_make(g.Cout);
+    } else {
+        p.f_wo = fd_make(g.Wo); p.f_howo = fd_make(g.Ho * g.Wo); p.f_ck = fd_make(g.Cin);
+    }
+    p.f_kw = fd_make(g.KW);
+}
+
+int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                         float alpha, hipStream_t st) {
+    ConvGemmArgs p{};
+    fill_common(p, g, GEMM_FWD);
+    p.a = x; p.b = w; p.bias = bias; p.c = y; p.act = act; p.alpha = alpha;
+    p.M = g.N * g.Ho * g.Wo; p.N = g.Cout; p.K = g.KH * g.KW * g.Cin;
+    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN));
+    hipLaunchKernelGGL(conv_gemm_mfma<GEMM_FWD>, grid, dim3(256), 0, st, p);
+    return check_launch("conv_gemm_mfma<fwd>");
+}
+
+int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx, int act,
+                           float alpha, hipStream_t st) {
+    ConvGemmArgs p{};
+    fill_common(p, g, GEMM_DGRAD);
+    p.a = dz; p.b = w; p.bias = bias; p.c = dx; p.act = act; p.alpha = alpha;
+    p.M = g.N * g.H * g.W; p.N = g.Cin; p.K = g.KH * g.KW * g.Cout;
+    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN));
+    hipLaunchKernelGGL(conv_gemm_mfma<GEMM_DGRAD>, grid, dim3(256), 0, st, p);
+    return check_launch("conv_gemm_mfma<dgrad>");
+}
+
+// slabs only; the caller sums them (wgrad_reduce)
+int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st) {
+    ConvGemmArgs p{};
+    fill_common(p, g, GEMM_WGRAD);
+    p.a = x; p.b = dz; p.bias = nullptr; p.c = slabs; p.act = SV_ACT_NONE; p.alpha = 0.f;
+    p.M = g.KH * g.KW * g.Cin; p.N = g.Cout; p.K = g.N * g.Ho * g.Wo;
+    p.k_per_split = (int)(ceil_div(ceil_div(p.K, splits), BK) * BK);
+    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)splits);
+    hipLaunchKernelGGL(conv_gemm_mfma<GEMM_WGRAD>, grid, dim3(256), 0, st, p);
+    return check_launch("conv_gemm_mfma<wgrad>");
+}
+
+}  // namespace sv

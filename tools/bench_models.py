@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Training-step rates of the secondary configurations (not the bench line): the context-encoder + discriminator
+step of run_context_encoder.py at batch 64 and the U-Net GAN step of run_unet.py at batch 32, f32, device-resident
+inputs, HIP-graph replay.  These models run on the generic (non-tiled) conv kernels.
+
+  python tools/bench_models.py [--steps 50]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from spectrum_vae_amd import context_encoder, run_context_encoder, run_unet, unet  # noqa: E402
+from spectrum_vae_amd.data import synth_training_tensor  # noqa: E402
+
+
+def timed(fn, steps):
+    for _ in range(4):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    out = {}
+    # context encoder + discriminator, batch 64 (run_context_encoder.py:380)
+    B = 64
+    X = torch.from_numpy(synth_training_tensor(B, 7)).to(dev)
+    mask = torch.from_numpy(run_context_encoder.batch_random_mask(X.cpu().numpy(), 0.25, np.random.default_rng(1))).to(dev)
+    ce, disc = context_encoder.ContextEncoder(), context_encoder.Discriminator()
+    o1, o2 = run_context_encoder.build_optimizer(2e-3), run_context_encoder.build_optimizer(2e-4)
+    dt = timed(lambda: run_context_encoder.train_step(ce, disc, o1, o2, X, mask), a.steps)
+    out["context_encoder_step_b64"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1)}
+    # U-Net generator + discriminator, batch 32 (run_unet.py:296)
+    B = 32
+    Y = torch.from_numpy(synth_training_tensor(B, 9)).to(dev)
+    Xu = Y[..., :1].contiguous()
+    gen, d2 = unet.Generator(), unet.Discriminator()
+    g1, g2 = run_unet.build_optimizer(2e-4), run_unet.build_optimizer(2e-4)
+    dt = timed(lambda: run_unet.train_step(gen, d2, g1, g2, Xu, Y), a.steps)
+    out["unet_gan_step_b32"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
