@@ -30,6 +30,7 @@ struct ConvGemmArgs {
     float alpha;
     FDiv f_wo, f_howo;  // FWD/WGRAD rows r -> (n, oh, ow);  DGRAD rows -> (n, ih, iw) (then these divide by W, H*W)
     FDiv f_ck, f_kw;    // reduction / row index (tap, channel): divide by the channel count, then by KW
+    int one_out;        // DGRAD: the conv has a single output position (Ho == Wo == 1): one row class per input pixel
 };
 
 constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS row pitch (floats): 64 + 4
@@ -51,6 +52,50 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         kend = min(p.K, kbeg + p.k_per_split);
     }
 
+    // ---- DGRAD: rows are grouped into classes (blockIdx.z) that share their set of contributing filter taps, so the
+    // reduction only walks taps that can hit: with stride s only every s-th tap reaches a given input row / column
+    // (class = (ih % SH, iw % SW)); a conv with a single output position has exactly one tap per input pixel
+    // (class = the pixel, rows = images).
+    __shared__ int row_img[BM], row_h[BM], row_w[BM];
+    int kh0 = 0, kw0 = 0, nkw = 1;
+    FDiv f_nkw = fd_make(1);
+    if (MODE == GEMM_DGRAD) {
+        int Mc;
+        const int z = blockIdx.z;
+        if (p.one_out) {
+            const int ih = z / g.W, iw = z - ih * g.W;
+            kh0 = ih + g.pad_t; kw0 = iw + g.pad_l;
+            Mc = g.N;
+            kend = (kh0 < g.KH && kw0 < g.KW) ? g.Cout : 0;
+            if (t < BM) {
+                const int m = m0 + t;
+                row_img[t] = m < Mc ? m : -1; row_h[t] = ih; row_w[t] = iw;
+            }
+        } else {
+            const int ph = z / g.SW, pw = z - ph * g.SW;
+            const int Ha = (g.H - ph + g.SH - 1) / g.SH, Wa = (g.W - pw + g.SW - 1) / g.SW;
+            Mc = g.N * Ha * Wa;
+            kh0 = (ph + g.pad_t) % g.SH; kw0 = (pw + g.pad_l) % g.SW;
+            const int nkh = kh0 < g.KH ? (g.KH - kh0 + g.SH - 1) / g.SH : 0;
+            nkw = kw0 < g.KW ? (g.KW - kw0 + g.SW - 1) / g.SW : 0;
+            kend = nkh * nkw * g.Cout;
+            if (nkw > 0) f_nkw = fd_make(nkw);
+            if (t < BM) {
+                const int m = m0 + t;
+                int img = -1, hh = 0, ww = 0;
+                if (m < Mc) {
+                    img = m / (Ha * Wa);
+                    const int rem = m - img * (Ha * Wa);
+                    const int a = rem / Wa;
+                    hh = ph + a * g.SH; ww = pw + (rem - a * Wa) * g.SW;
+                }
+                row_img[t] = img; row_h[t] = hh; row_w[t] = ww;
+            }
+        }
+        if (m0 >= Mc) return;  // whole workgroup: this class has fewer rows
+        __syncthreads();
+    }
+
     // ---- per-thread row bookkeeping of the A gather (fixed over the reduction loop)
     // FWD / DGRAD: thread loads k = t & 15 of rows (t >> 4) + 16 i;  WGRAD: row m = t & 63, reduction (t >> 6) + 4 i
     int r_img[4], r_h[4], r_w[4];
@@ -64,6 +109,13 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         a_ci = a_ok ? m - tap * g.Cin : 0;
         a_kh = fd(tap, p.f_kw);
         a_kw = tap - a_kh * g.KW;
+    } else if (MODE == GEMM_DGRAD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = (t >> 4) + 16 * i;
+            r_img[i] = row_img[rl]; r_h[i] = row_h[rl]; r_w[i] = row_w[rl];
+            r_ok[i] = r_img[i] >= 0;
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -102,14 +154,14 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             const int k = k0 + (t & 15);
             const bool kok = k < kend;
             const int kk = kok ? k : 0;
-            const int tap = fd(kk, p.f_ck), co = kk - tap * g.Cout;
-            const int kh = fd(tap, p.f_kw), kw = tap - kh * g.KW;
+            const int j = fd(kk, p.f_ck), co = kk - j * g.Cout;  // j: index among the class's taps
+            const int jh = fd(j, f_nkw), jw = j - jh * nkw;
+            const int kh = p.one_out ? kh0 : kh0 + jh * g.SH, kw = p.one_out ? kw0 : kw0 + jw * g.SW;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
-                const int oh = th / g.SH, ow = tw / g.SW;
-                const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh * g.SH == th && ow * g.SW == tw && oh < g.Ho &&
-                                ow < g.Wo;
+                const int oh = th / g.SH, ow = tw / g.SW;  // exact by construction of the class
+                const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo;
                 av[i] = ok ? p.a[(((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co] : 0.f;
             }
         } else {
@@ -131,7 +183,10 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             const int k = k0 + (t & 15);
             const bool kok = k < kend;
             const int kk = kok ? k : 0;
-            const int tap = fd(kk, p.f_ck), co = kk - tap * g.Cout;
+            const int j = fd(kk, p.f_ck), co = kk - j * g.Cout;
+            const int jh = fd(j, f_nkw), jw = j - jh * nkw;
+            const int kh = p.one_out ? kh0 : kh0 + jh * g.SH, kw = p.one_out ? kw0 : kw0 + jw * g.SW;
+            const int tap = kh * g.KW + kw;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = n0 + (t >> 4) + 16 * i;
@@ -186,11 +241,17 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             const float bb = (MODE != GEMM_WGRAD && p.bias != nullptr) ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm + 16 * i + 4 * lk + r;
-                if (m >= p.M) continue;
+                const int rl = wm + 16 * i + 4 * lk + r;
+                const int m = m0 + rl;
                 float v = acc[i][j][r];
                 if (MODE != GEMM_WGRAD) v = act_apply(v + bb, p.act, p.alpha);
-                out[(size_t)m * p.N + n] = v;
+                if (MODE == GEMM_DGRAD) {
+                    if (row_img[rl] < 0) continue;
+                    out[(((size_t)row_img[rl] * g.H + row_h[rl]) * g.W + row_w[rl]) * g.Cin + n] = v;
+                } else {
+                    if (m >= p.M) continue;
+                    out[(size_t)m * p.N + n] = v;
+                }
             }
         }
 }
@@ -208,7 +269,8 @@ bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode) {
     const int64_t sp = mode == GEMM_DGRAD ? (int64_t)g.H * g.W : (int64_t)g.Ho * g.Wo;
     const int64_t rdec = mode == GEMM_WGRAD ? kdim : rows, cdec = mode == GEMM_WGRAD ? rows : kdim;
     if (rdec * sp >= (1ll << 32) || cdec * (g.Cin > g.Cout ? g.Cin : g.Cout) >= (1ll << 32)) return false;
-    return ncols >= 12 && kdim >= 4 && rows < (1ll << 30) && kdim < (1ll << 30);
+    if ((int64_t)g.SH * g.SW > 65535 || (int64_t)g.H * g.W > 65535) return false;  // row classes ride on grid.z
+    return ncols >= 1 && kdim >= 16 && rows < (1ll << 30) && kdim < (1ll << 30);
 }
 
 int conv_gemm_wgrad_splits(const sv_conv_geom& g) {
@@ -254,7 +316,16 @@ int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* 
     fill_common(p, g, GEMM_DGRAD);
     p.a = dz; p.b = w; p.bias = bias; p.c = dx; p.act = act; p.alpha = alpha;
     p.M = g.N * g.H * g.W; p.N = g.Cin; p.K = g.KH * g.KW * g.Cout;
-    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN));
+    p.one_out = g.Ho == 1 && g.Wo == 1;
+    int classes, rows;  // row classes and the largest class's row count
+    if (p.one_out) {
+        classes = g.H * g.W;
+        rows = g.N;
+    } else {
+        classes = g.SH * g.SW;
+        rows = g.N * (int)ceil_div(g.H, g.SH) * (int)ceil_div(g.W, g.SW);
+    }
+    dim3 grid((unsigned)ceil_div(rows, BM), (unsigned)ceil_div(p.N, BN), (unsigned)classes);
     hipLaunchKernelGGL(conv_gemm_mfma<GEMM_DGRAD>, grid, dim3(256), 0, st, p);
     return check_launch("conv_gemm_mfma<dgrad>");
 }
