@@ -96,14 +96,52 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ z, flo
     }
 }
 
-// out[c] (+)= sum_b part[b][c], in block order (deterministic)
-__global__ void fold_partials_k(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C,
-                                int accumulate) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        float s = accumulate ? out[c] : 0.f;
-        for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * C + c];
-        out[c] = s;
+// Column sums of per-block partials, part[(b * NV + v) * C + c]: a workgroup of 256 owns 64 channels, its 4 waves walk
+// every 4th block (8 loads in flight each) and the four sums are combined in a fixed order - latency-parallel and
+// bitwise reproducible.  Returns true for the lanes (wave 0, c < C) that hold the result in out[].
+template <int NV, typename T>
+__device__ __forceinline__ bool fold_cols(const float* __restrict__ part, int nblocks, int C, int& c, T (&out)[NV]) {
+    __shared__ T red[3][NV][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    c = blockIdx.x * 64 + lane;
+    T s[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s[v] = (T)0;
+    if (c < C) {
+        int b = grp;
+        for (; b + 28 < nblocks; b += 32) {
+            float t[8][NV];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) t[u][v] = part[((int64_t)(b + 4 * u) * NV + v) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s[v] += (T)t[u][v];
+        }
+        for (; b < nblocks; b += 4)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s[v] += (T)part[((int64_t)b * NV + v) * C + c];
     }
+    if (grp > 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) red[grp - 1][v][lane] = s[v];
+    }
+    __syncthreads();
+    if (grp != 0 || c >= C) return false;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[v] = ((s[v] + red[0][v][lane]) + red[1][v][lane]) + red[2][v][lane];
+    return true;
+}
+
+// out[c] (+)= sum_b part[b][c] (fixed order: deterministic)
+__global__ __launch_bounds__(256) void fold_partials_k(const float* __restrict__ part, float* __restrict__ out, int nblocks,
+                                                       int C, int accumulate) {
+    int c;
+    float s[1];
+    if (!fold_cols<1, float>(part, nblocks, C, c, s)) return;
+    out[c] = (accumulate ? out[c] : 0.f) + s[0];
 }
 
 // ------------------------------------------------------------------------------------------------ max pooling
@@ -246,12 +284,11 @@ __global__ void bn_finalize_k(const float* __restrict__ x, const float* __restri
                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
                               float* __restrict__ moving_mean, float* __restrict__ moving_var, int64_t rows, int C,
                               float eps, float momentum, int unbiased) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < nblocks; ++b) {
-            s += (double)part[((int64_t)b * 2 + 0) * C + c];
-            q += (double)part[((int64_t)b * 2 + 1) * C + c];
-        }
+    {
+        int c;
+        double sq[2];
+        if (!fold_cols<2, double>(part, nblocks, C, c, sq)) return;
+        const double s = sq[0], q = sq[1];
         const double m = (double)rows;
         const double dmean = s / m;
         double var = q / m - dmean * dmean;
@@ -330,12 +367,11 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const float* __restrict__ 
 // fold -> stats2[0][C] = sum dy (dbeta), stats2[1][C] = sum dy*xhat (dgamma); also emit dgamma/dbeta
 __global__ void bn_bwd_fold_k(const float* __restrict__ part, int nblocks, float* __restrict__ stats2,
                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int C) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        float s = 0.f, q = 0.f;
-        for (int b = 0; b < nblocks; ++b) {
-            s += part[((int64_t)b * 2 + 0) * C + c];
-            q += part[((int64_t)b * 2 + 1) * C + c];
-        }
+    {
+        int c;
+        float sq[2];
+        if (!fold_cols<2, float>(part, nblocks, C, c, sq)) return;
+        const float s = sq[0], q = sq[1];
         stats2[c] = s;
         stats2[C + c] = q;
         dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s;
@@ -520,7 +556,7 @@ int sv_act_bwd(const void* dy, const void* y, void* dz, void* db, int db_accumul
                        (const float*)dy, (const float*)y, (float*)dz, part, rows, C, act, alpha, p.rows_per_block);
     int rc = check_launch("sv_act_bwd");
     if (rc || db == nullptr) return rc;
-    hipLaunchKernelGGL(fold_partials_k, dim3(ew_grid(C)), dim3(256), 0, to_stream(stream), part, (float*)db,
+    hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, to_stream(stream), part, (float*)db,
                        p.nblocks, C, db_accumulate);
     return check_launch("sv_act_bwd/fold");
 }
@@ -537,7 +573,7 @@ int sv_bias_grad(const void* dz, void* db, int accumulate, int64_t rows, int C, 
                        (const float*)dz, part, rows, C, p.rows_per_block);
     rc = check_launch("sv_bias_grad");
     if (rc) return rc;
-    hipLaunchKernelGGL(fold_partials_k, dim3(ew_grid(C)), dim3(256), 0, to_stream(stream), part, (float*)db,
+    hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, to_stream(stream), part, (float*)db,
                        p.nblocks, C, accumulate);
     return check_launch("sv_bias_grad/fold");
 }
@@ -606,7 +642,7 @@ int sv_batchnorm_fwd_train(const void* x, const float* gamma, const float* beta,
                        C, p.rows_per_block);
     rc = check_launch("bn_stats");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_k, dim3(ew_grid(C)), dim3(256), 0, st, (const float*)x, part, p.nblocks,
+    hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, st, (const float*)x, part, p.nblocks,
                        save_mean, save_invstd, moving_mean, moving_var, rows, C, eps, momentum, unbiased_moving_var);
     rc = check_launch("bn_finalize");
     if (rc) return rc;
@@ -644,7 +680,7 @@ int sv_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const fl
                        (const float*)dy, save_mean, save_invstd, part, rows, C, p.rows_per_block);
     rc = check_launch("bn_bwd_stats");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_fold_k, dim3(ew_grid(C)), dim3(256), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_fold_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
                        accumulate, C);
     rc = check_launch("bn_bwd_fold");
     if (rc) return rc;
