@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = v4f_t{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        float av[4], bv[4];
+    // global -> registers for one reduction step (issued one step ahead of its use, so the round trip overlaps the MFMAs)
+    auto gather = [&](int k0, float (&av)[4], float (&bv)[4]) {
         // ---- gather A
         if (MODE == GEMM_FWD) {
             const int k = k0 + (t & 15);
@@ -200,6 +200,11 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
                 bv[i] = (k < kend && n < p.N) ? p.b[(int64_t)k * p.N + n] : 0.f;
             }
         }
+    };
+
+    float av[4], bv[4];
+    if (kbeg < kend) gather(kbeg, av, bv);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();  // the previous step's MFMA reads are done
         if (MODE == GEMM_WGRAD) {
 #pragma unroll
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             for (int i = 0; i < 4; ++i) Bs[(t >> 6) + 4 * i][t & 63] = bv[i];
         }
         __syncthreads();
+        if (k0 + BK < kend) gather(k0 + BK, av, bv);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float a[2], b[2];
