@@ -161,6 +161,27 @@ int sv_conv2d_transpose_dgrad(const sv_conv_geom* g, const void* dz, const void*
 int sv_conv2d_transpose_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate,
                               void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
 
+/* ---- The four operations above with a caller-provided scratch buffer.  The strided 4x4 convs and transposed convs
+ *      deep in the U-Net / context-encoder / discriminator stacks (unet.py:45-52,69-78,123; context_encoder.py:63-119,
+ *      189-290: 512..1000 channels on 4x4..1x1 maps at batch 32 / 64) have a result of only a few tiles and a reduction
+ *      of thousands of terms; with scratch the reduction is cut over many workgroups (partial results in the scratch,
+ *      summed in a fixed order together with bias + activation), so results stay bit-reproducible.
+ *      sv_conv2d_scratch_bytes gives the size for an operation (0: the geometry gains nothing, pass NULL);
+ *      workspace == NULL or too small is not an error: the operation then runs as the plain entry point does. */
+#define SV_CONV_OP_FWD 0
+#define SV_CONV_OP_DGRAD 1
+#define SV_CONV_OP_TRANSPOSE_FWD 2
+#define SV_CONV_OP_TRANSPOSE_DGRAD 3
+size_t sv_conv2d_scratch_bytes(const sv_conv_geom* g, int op);
+int sv_conv2d_fwd_ws(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
+                     float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
+int sv_conv2d_dgrad_ws(const sv_conv_geom* g, const void* dz, const void* w, void* dx, void* workspace,
+                       size_t workspace_bytes, int dtype, sv_stream_t stream);
+int sv_conv2d_transpose_fwd_ws(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
+                               float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
+int sv_conv2d_transpose_dgrad_ws(const sv_conv_geom* g, const void* dz, const void* w, void* dx, void* workspace,
+                                 size_t workspace_bytes, int dtype, sv_stream_t stream);
+
 /* ---- activation layers and the backward of fused activations
  *      (LeakyReLU unet.py:53,79; activation= arguments of every Conv2D/Dense above) */
 int sv_act_fwd(const void* x, void* y, int64_t n, int act, float alpha, int dtype, sv_stream_t stream);

@@ -74,6 +74,11 @@ SIGNATURES = {
     "sv_conv2d_transpose_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_transpose_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
     "sv_conv2d_transpose_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),
+    "sv_conv2d_scratch_bytes": (_sz, [_g, _i]),
+    "sv_conv2d_fwd_ws": (_i, [_g, _p, _p, _p, _p, _i, _f, _p, _sz, _i, _p]),
+    "sv_conv2d_dgrad_ws": (_i, [_g, _p, _p, _p, _p, _sz, _i, _p]),
+    "sv_conv2d_transpose_fwd_ws": (_i, [_g, _p, _p, _p, _p, _i, _f, _p, _sz, _i, _p]),
+    "sv_conv2d_transpose_dgrad_ws": (_i, [_g, _p, _p, _p, _p, _sz, _i, _p]),
     "sv_act_fwd": (_i, [_p, _p, _i64, _i, _f, _i, _p]),
     "sv_colreduce_workspace_bytes": (_sz, [_i64, _i]),
     "sv_act_bwd": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _f, _p, _sz, _i, _p]),

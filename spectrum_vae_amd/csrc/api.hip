@@ -9,10 +9,11 @@ thread_local char g_last_error[512] = "";
 
 // conv_direct.hip
 int validate_geom(const sv_conv_geom* g, const char* who);
+size_t conv_direct_scratch(const sv_conv_geom& g, int mode);
 int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
-                      float alpha, hipStream_t st);
+                      float alpha, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx,
-                        int act, float alpha, hipStream_t st);
+                        int act, float alpha, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 size_t wgrad_direct_workspace(const sv_conv_geom& g);
 int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, float* dw, int accumulate, void* ws,
                         size_t ws_bytes, hipStream_t st);
@@ -50,6 +51,18 @@ int sv_version(void) { return 1; }
 
 int sv_conv2d_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
                   float alpha, int dtype, sv_stream_t stream) {
+    return sv_conv2d_fwd_ws(g, x, w, bias, y, act, alpha, nullptr, 0, dtype, stream);
+}
+
+size_t sv_conv2d_scratch_bytes(const sv_conv_geom* g, int op) {
+    if (validate_geom(g, "sv_conv2d_scratch_bytes") || op < 0 || op > 3) return 0;
+    if (tiled_shape(*g) || g->up_h != 1 || g->up_w != 1) return 0;
+    // a transposed conv's forward is the input-gradient kernel of the described conv and vice versa
+    return conv_direct_scratch(*g, (op == SV_CONV_OP_DGRAD || op == SV_CONV_OP_TRANSPOSE_FWD) ? 1 : 0);
+}
+
+int sv_conv2d_fwd_ws(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
+                     float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
     SV_F32_ONLY(dtype, "sv_conv2d_fwd");
     int rc = validate_geom(g, "sv_conv2d_fwd");
     if (rc) return rc;
@@ -61,10 +74,15 @@ int sv_conv2d_fwd(const sv_conv_geom* g, const void* x, const void* w, const voi
         if (rc <= 0) return rc;
     }
     return launch_fwd_direct(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, act, alpha,
-                             to_stream(stream));
+                             to_stream(stream), workspace, workspace_bytes);
 }
 
 int sv_conv2d_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* dx, int dtype, sv_stream_t stream) {
+    return sv_conv2d_dgrad_ws(g, dz, w, dx, nullptr, 0, dtype, stream);
+}
+
+int sv_conv2d_dgrad_ws(const sv_conv_geom* g, const void* dz, const void* w, void* dx, void* workspace,
+                       size_t workspace_bytes, int dtype, sv_stream_t stream) {
     SV_F32_ONLY(dtype, "sv_conv2d_dgrad");
     int rc = validate_geom(g, "sv_conv2d_dgrad");
     if (rc) return rc;
@@ -77,7 +95,7 @@ int sv_conv2d_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* 
         if (rc <= 0) return rc;
     }
     return launch_dgrad_direct(*g, (const float*)dz, (const float*)w, nullptr, (float*)dx, SV_ACT_NONE, 0.f,
-                               to_stream(stream));
+                               to_stream(stream), workspace, workspace_bytes);
 }
 
 size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g) {
@@ -209,25 +227,35 @@ int sv_conv2d_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce
 // Conv2DTranspose forward is the input-gradient kernel of the described conv, plus bias and activation.
 int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
                             float alpha, int dtype, sv_stream_t stream) {
+    return sv_conv2d_transpose_fwd_ws(g, x, w, bias, y, act, alpha, nullptr, 0, dtype, stream);
+}
+
+int sv_conv2d_transpose_fwd_ws(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
+                               float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
     SV_F32_ONLY(dtype, "sv_conv2d_transpose_fwd");
     int rc = validate_geom(g, "sv_conv2d_transpose_fwd");
     if (rc) return rc;
     SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_transpose_fwd: folded upsampling is not defined here");
     SV_REQUIRE(x && w && y, "sv_conv2d_transpose_fwd: null tensor");
     return launch_dgrad_direct(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, act, alpha,
-                               to_stream(stream));
+                               to_stream(stream), workspace, workspace_bytes);
 }
 
 // ... and its input-gradient is the described conv run forward without epilogue.
 int sv_conv2d_transpose_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* dx, int dtype,
                               sv_stream_t stream) {
+    return sv_conv2d_transpose_dgrad_ws(g, dz, w, dx, nullptr, 0, dtype, stream);
+}
+
+int sv_conv2d_transpose_dgrad_ws(const sv_conv_geom* g, const void* dz, const void* w, void* dx, void* workspace,
+                                 size_t workspace_bytes, int dtype, sv_stream_t stream) {
     SV_F32_ONLY(dtype, "sv_conv2d_transpose_dgrad");
     int rc = validate_geom(g, "sv_conv2d_transpose_dgrad");
     if (rc) return rc;
     SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_transpose_dgrad: folded upsampling is not defined here");
     SV_REQUIRE(dz && w && dx, "sv_conv2d_transpose_dgrad: null tensor");
     return launch_fwd_direct(*g, (const float*)dz, (const float*)w, nullptr, (float*)dx, SV_ACT_NONE, 0.f,
-                             to_stream(stream));
+                             to_stream(stream), workspace, workspace_bytes);
 }
 
 // dw[kh,kw,co_T,ci_T] = sum dz_T[(H,W,Cin) side] * x_T[(Ho,Wo,Cout) side]: the conv kernel-gradient with the

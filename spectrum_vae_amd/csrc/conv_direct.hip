@@ -13,10 +13,11 @@ namespace sv {
 bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode);
 int conv_gemm_wgrad_splits(const sv_conv_geom& g);
 size_t conv_gemm_wgrad_workspace(const sv_conv_geom& g);
+size_t conv_gemm_splitk_workspace(const sv_conv_geom& g, int mode);
 int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
-                         float alpha, hipStream_t st);
+                         float alpha, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx, int act,
-                           float alpha, hipStream_t st);
+                           float alpha, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -216,9 +217,13 @@ int validate_geom(const sv_conv_geom* g, const char* who) {
     return SV_OK;
 }
 
+// Optional scratch of the forward (mode 0) / input-gradient (mode 1) launches: lets a result with few tiles cut its
+// reduction over more workgroups.  0 when the geometry gains nothing from it.
+size_t conv_direct_scratch(const sv_conv_geom& g, int mode) { return conv_gemm_splitk_workspace(g, mode); }
+
 int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
-                      float alpha, hipStream_t st) {
-    if (conv_gemm_worthwhile(g, 0)) return launch_conv_gemm_fwd(g, x, w, bias, y, act, alpha, st);
+                      float alpha, hipStream_t st, void* ws, size_t ws_bytes) {
+    if (conv_gemm_worthwhile(g, 0)) return launch_conv_gemm_fwd(g, x, w, bias, y, act, alpha, ws, ws_bytes, st);
     const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
     const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
     dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cout, cot));
@@ -232,8 +237,8 @@ int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, con
 }
 
 int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx,
-                        int act, float alpha, hipStream_t st) {
-    if (conv_gemm_worthwhile(g, 1)) return launch_conv_gemm_dgrad(g, dz, w, bias, dx, act, alpha, st);
+                        int act, float alpha, hipStream_t st, void* ws, size_t ws_bytes) {
+    if (conv_gemm_worthwhile(g, 1)) return launch_conv_gemm_dgrad(g, dz, w, bias, dx, act, alpha, ws, ws_bytes, st);
     const int64_t npix = (int64_t)g.N * (g.H / g.up_h) * (g.W / g.up_w);
     const int cit = g.Cin >= 16 ? 16 : (g.Cin > 4 ? 8 : 4);
     dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cin, cit));

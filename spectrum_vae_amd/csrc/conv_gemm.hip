@@ -31,6 +31,8 @@ struct ConvGemmArgs {
     FDiv f_wo, f_howo;  // FWD/WGRAD rows r -> (n, oh, ow);  DGRAD rows -> (n, ih, iw) (then these divide by W, H*W)
     FDiv f_ck, f_kw;    // reduction / row index (tap, channel): divide by the channel count, then by KW
     int one_out;        // DGRAD: the conv has a single output position (Ho == Wo == 1): one row class per input pixel
+    int splits;         // FWD / DGRAD: > 1 cuts the reduction into `splits` ranges over blockIdx.z; raw partial sums go to
+    float* slabs;       //              slabs[split][M][N] (indexed like c) and splitk_finish_k applies bias + activation
 };
 
 constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS row pitch (floats): 64 + 4
@@ -59,9 +61,10 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     __shared__ int row_img[BM], row_h[BM], row_w[BM];
     int kh0 = 0, kw0 = 0, nkw = 1;
     FDiv f_nkw = fd_make(1);
+    const int split = p.splits > 1 ? blockIdx.z % p.splits : 0;
     if (MODE == GEMM_DGRAD) {
         int Mc;
-        const int z = blockIdx.z;
+        const int z = p.splits > 1 ? blockIdx.z / p.splits : blockIdx.z;
         if (p.one_out) {
             const int ih = z / g.W, iw = z - ih * g.W;
             kh0 = ih + g.pad_t; kw0 = iw + g.pad_l;
@@ -94,6 +97,11 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         }
         if (m0 >= Mc) return;  // whole workgroup: this class has fewer rows
         __syncthreads();
+    }
+    if (MODE != GEMM_WGRAD && p.splits > 1) {
+        const int kper = ((kend + p.splits - 1) / p.splits + BK - 1) / BK * BK;
+        kbeg = split * kper;
+        kend = min(kend, kbeg + kper);  // may leave an empty range: the workgroup then stores zeros
     }
 
     // ---- per-thread row bookkeeping of the A gather (fixed over the reduction loop)
@@ -238,19 +246,21 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     // ---- epilogue
     float* out = p.c;
     if (MODE == GEMM_WGRAD) out += (size_t)blockIdx.z * p.M * p.N;
+    const bool raw = MODE == GEMM_WGRAD || p.splits > 1;
+    if (MODE != GEMM_WGRAD && p.splits > 1) out = p.slabs + (size_t)split * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn + 16 * j + li;
             if (n >= p.N) continue;
-            const float bb = (MODE != GEMM_WGRAD && p.bias != nullptr) ? p.bias[n] : 0.f;
+            const float bb = (!raw && p.bias != nullptr) ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rl = wm + 16 * i + 4 * lk + r;
                 const int m = m0 + rl;
                 float v = acc[i][j][r];
-                if (MODE != GEMM_WGRAD) v = act_apply(v + bb, p.act, p.alpha);
+                if (!raw) v = act_apply(v + bb, p.act, p.alpha);
                 if (MODE == GEMM_DGRAD) {
                     if (row_img[rl] < 0) continue;
                     out[(((size_t)row_img[rl] * g.H + row_h[rl]) * g.W + row_w[rl]) * g.Cin + n] = v;
@@ -260,6 +270,24 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
                 }
             }
         }
+}
+
+// out[i] = act(sum_s slabs[s][i] + bias[i % N]), splits summed in index order (bit-reproducible)
+__global__ __launch_bounds__(256) void splitk_finish_k(const float* __restrict__ slabs, int splits, int64_t MN, int N,
+                                                       const float* __restrict__ bias, int act, float alpha,
+                                                       float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+        const float v0 = slabs[(int64_t)k * MN + i], v1 = slabs[(int64_t)(k + 1) * MN + i];
+        const float v2 = slabs[(int64_t)(k + 2) * MN + i], v3 = slabs[(int64_t)(k + 3) * MN + i];
+        s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; k < splits; ++k) s += slabs[(int64_t)k * MN + i];
+    if (bias != nullptr) s += bias[(int)(i % N)];
+    out[i] = act_apply(s, act, alpha);
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
@@ -277,6 +305,54 @@ bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode) {
     if (rdec * sp >= (1ll << 32) || cdec * (g.Cin > g.Cout ? g.Cin : g.Cout) >= (1ll << 32)) return false;
     if ((int64_t)g.SH * g.SW > 65535 || (int64_t)g.H * g.W > 65535) return false;  // row classes ride on grid.z
     return ncols >= 1 && kdim >= 16 && rows < (1ll << 30) && kdim < (1ll << 30);
+}
+
+// FWD / DGRAD: a result with few 64 x 64 tiles leaves most of the 256 CUs idle while each workgroup walks a long
+// reduction; cut the reduction so that about 512 workgroups exist, each keeping at least 4 steps.
+static void dgrad_classes(const sv_conv_geom& g, int& classes, int& rows, int64_t& kclass) {
+    if (g.Ho == 1 && g.Wo == 1) {
+        classes = g.H * g.W; rows = g.N; kclass = g.Cout;
+    } else {
+        classes = g.SH * g.SW;
+        rows = g.N * (int)ceil_div(g.H, g.SH) * (int)ceil_div(g.W, g.SW);
+        kclass = (int64_t)ceil_div(g.KH, g.SH) * ceil_div(g.KW, g.SW) * g.Cout;
+    }
+}
+
+int conv_gemm_splits(const sv_conv_geom& g, int mode) {
+    int64_t blocks, kdim;
+    int zbase = 1;
+    if (mode == GEMM_FWD) {
+        blocks = ceil_div((int64_t)g.N * g.Ho * g.Wo, BM) * ceil_div(g.Cout, BN);
+        kdim = (int64_t)g.KH * g.KW * g.Cin;
+    } else {
+        int classes, rows;
+        dgrad_classes(g, classes, rows, kdim);
+        blocks = ceil_div(rows, BM) * ceil_div(g.Cin, BN) * classes;
+        zbase = classes;
+    }
+    if (blocks >= 192) return 1;
+    int64_t s = ceil_div(512, blocks);
+    const int64_t maxs = kdim / (4 * BK);
+    if (s > maxs) s = maxs;
+    if (s > 256) s = 256;
+    if (s * zbase > 65535) s = 65535 / zbase;
+    return s < 2 ? 1 : (int)s;
+}
+
+size_t conv_gemm_splitk_workspace(const sv_conv_geom& g, int mode) {
+    if (mode == GEMM_WGRAD || !conv_gemm_worthwhile(g, mode)) return 0;
+    const int s = conv_gemm_splits(g, mode);
+    if (s < 2) return 0;
+    const size_t mn = mode == GEMM_FWD ? (size_t)g.N * g.Ho * g.Wo * g.Cout : (size_t)g.N * g.H * g.W * g.Cin;
+    return (size_t)s * mn * sizeof(float);
+}
+
+static int launch_splitk_finish(const ConvGemmArgs& p, hipStream_t st) {
+    const int64_t mn = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL(splitk_finish_k, dim3((unsigned)ceil_div(mn, 256)), dim3(256), 0, st, p.slabs, p.splits, mn, p.N,
+                       p.bias, p.act, p.alpha, p.c);
+    return check_launch("splitk_finish_k");
 }
 
 int conv_gemm_wgrad_splits(const sv_conv_geom& g) {
@@ -305,35 +381,47 @@ static void fill_common(ConvGemmArgs& p, const sv_conv_geom& g, int mode) {
     p.f_kw = fd_make(g.KW);
 }
 
+// ws / ws_bytes: optional scratch of conv_gemm_splitk_workspace(g, mode) bytes; without it the reduction is not cut
 int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
-                         float alpha, hipStream_t st) {
+                         float alpha, void* ws, size_t ws_bytes, hipStream_t st) {
     ConvGemmArgs p{};
     fill_common(p, g, GEMM_FWD);
     p.a = x; p.b = w; p.bias = bias; p.c = y; p.act = act; p.alpha = alpha;
     p.M = g.N * g.Ho * g.Wo; p.N = g.Cout; p.K = g.KH * g.KW * g.Cin;
-    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN));
+    p.splits = 1;
+    const size_t need = conv_gemm_splitk_workspace(g, GEMM_FWD);
+    if (need > 0 && ws != nullptr && ws_bytes >= need) {
+        p.splits = conv_gemm_splits(g, GEMM_FWD);
+        p.slabs = (float*)ws;
+    }
+    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)p.splits);
     hipLaunchKernelGGL(conv_gemm_mfma<GEMM_FWD>, grid, dim3(256), 0, st, p);
-    return check_launch("conv_gemm_mfma<fwd>");
+    int rc = check_launch("conv_gemm_mfma<fwd>");
+    if (rc || p.splits == 1) return rc;
+    return launch_splitk_finish(p, st);
 }
 
 int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx, int act,
-                           float alpha, hipStream_t st) {
+                           float alpha, void* ws, size_t ws_bytes, hipStream_t st) {
     ConvGemmArgs p{};
     fill_common(p, g, GEMM_DGRAD);
     p.a = dz; p.b = w; p.bias = bias; p.c = dx; p.act = act; p.alpha = alpha;
     p.M = g.N * g.H * g.W; p.N = g.Cin; p.K = g.KH * g.KW * g.Cout;
     p.one_out = g.Ho == 1 && g.Wo == 1;
     int classes, rows;  // row classes and the largest class's row count
-    if (p.one_out) {
-        classes = g.H * g.W;
-        rows = g.N;
-    } else {
-        classes = g.SH * g.SW;
-        rows = g.N * (int)ceil_div(g.H, g.SH) * (int)ceil_div(g.W, g.SW);
+    int64_t kclass;
+    dgrad_classes(g, classes, rows, kclass);
+    p.splits = 1;
+    const size_t need = conv_gemm_splitk_workspace(g, GEMM_DGRAD);
+    if (need > 0 && ws != nullptr && ws_bytes >= need) {
+        p.splits = conv_gemm_splits(g, GEMM_DGRAD);
+        p.slabs = (float*)ws;
     }
-    dim3 grid((unsigned)ceil_div(rows, BM), (unsigned)ceil_div(p.N, BN), (unsigned)classes);
+    dim3 grid((unsigned)ceil_div(rows, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(classes * p.splits));
     hipLaunchKernelGGL(conv_gemm_mfma<GEMM_DGRAD>, grid, dim3(256), 0, st, p);
-    return check_launch("conv_gemm_mfma<dgrad>");
+    int rc = check_launch("conv_gemm_mfma<dgrad>");
+    if (rc || p.splits == 1) return rc;
+    return launch_splitk_finish(p, st);
 }
 
 // slabs only; the caller sums them (wgrad_reduce)

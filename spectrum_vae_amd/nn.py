@@ -326,6 +326,16 @@ class _ConvBase(Layer):
         self.fused_bwd = ops.conv2d_fused_supported(g, self.pool is not None)
         return self.pool is not None
 
+    def _scratch(self, ctx, g, op):
+        """The shared scratch sized for operation ``op`` of this layer (None when the geometry needs none): lets a
+        result of few tiles cut its reduction over many workgroups."""
+        cache = self.__dict__.setdefault("_scratch_bytes", {})
+        key = (g.N, op)
+        nbytes = cache.get(key)
+        if nbytes is None:
+            nbytes = cache[key] = ops.conv2d_scratch(g, op)
+        return ctx.pool.workspace(nbytes) if nbytes else None
+
     def forward(self, ctx, x):
         n = x.shape[0]
         g = self.geom(n)
@@ -340,9 +350,10 @@ class _ConvBase(Layer):
             return y
         y = ctx.buf(self, "y", (n,) + self.output_shape_)
         if self.transposed:
-            ops.conv2d_transpose_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha)
+            ops.conv2d_transpose_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha,
+                                     self._scratch(ctx, g, ops.OP_TRANSPOSE_FWD))
         else:
-            ops.conv2d_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha)
+            ops.conv2d_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha, self._scratch(ctx, g, ops.OP_FWD))
         if ctx.training:
             ctx.saved[id(self)] = {"x": x, "y": y}
         return y
@@ -413,9 +424,9 @@ class _ConvBase(Layer):
             return None
         dx = ctx.buf(self, "dx", tuple(x.shape))
         if self.transposed:
-            ops.conv2d_transpose_dgrad(g, dz, self.kernel.data, dx)
+            ops.conv2d_transpose_dgrad(g, dz, self.kernel.data, dx, self._scratch(ctx, g, ops.OP_TRANSPOSE_DGRAD))
         else:
-            ops.conv2d_dgrad(g, dz, self.kernel.data, dx)
+            ops.conv2d_dgrad(g, dz, self.kernel.data, dx, self._scratch(ctx, g, ops.OP_DGRAD))
         return dx
 
 

@@ -69,13 +69,26 @@ def deconv_geom(n, h, w, cin, kh, kw, sh, sw, padding, cout) -> ConvGeom:
 
 
 # --------------------------------------------------------------------------- conv family
-def conv2d_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float):
-    check(lib.sv_conv2d_fwd(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha, F32, _stream()),
-          "sv_conv2d_fwd")
+OP_FWD, OP_DGRAD, OP_TRANSPOSE_FWD, OP_TRANSPOSE_DGRAD = 0, 1, 2, 3
 
 
-def conv2d_dgrad(g: ConvGeom, dz, w, dx):
-    check(lib.sv_conv2d_dgrad(C.byref(g), _ptr(dz), _ptr(w), _ptr(dx), F32, _stream()), "sv_conv2d_dgrad")
+def conv2d_scratch(g: ConvGeom, op: int) -> int:
+    """Bytes of optional scratch with which operation ``op`` spreads a long reduction over more workgroups (0: none)."""
+    return int(lib.sv_conv2d_scratch_bytes(C.byref(g), op))
+
+
+def _ws_args(ws):
+    return (_ptr(ws, torch.uint8), ws.numel()) if ws is not None else (None, 0)
+
+
+def conv2d_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float, ws=None):
+    check(lib.sv_conv2d_fwd_ws(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha, *_ws_args(ws), F32,
+                               _stream()), "sv_conv2d_fwd_ws")
+
+
+def conv2d_dgrad(g: ConvGeom, dz, w, dx, ws=None):
+    check(lib.sv_conv2d_dgrad_ws(C.byref(g), _ptr(dz), _ptr(w), _ptr(dx), *_ws_args(ws), F32, _stream()),
+          "sv_conv2d_dgrad_ws")
 
 
 def conv2d_wgrad_workspace(g: ConvGeom) -> int:
@@ -166,14 +179,14 @@ def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float
                             ws.numel() if ws is not None else 0, F32, _stream()), "sv_conv2d_bwd")
 
 
-def conv2d_transpose_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float):
-    check(lib.sv_conv2d_transpose_fwd(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha, F32,
-                                      _stream()), "sv_conv2d_transpose_fwd")
+def conv2d_transpose_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float, ws=None):
+    check(lib.sv_conv2d_transpose_fwd_ws(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha,
+                                         *_ws_args(ws), F32, _stream()), "sv_conv2d_transpose_fwd_ws")
 
 
-def conv2d_transpose_dgrad(g: ConvGeom, dz, w, dx):
-    check(lib.sv_conv2d_transpose_dgrad(C.byref(g), _ptr(dz), _ptr(w), _ptr(dx), F32, _stream()),
-          "sv_conv2d_transpose_dgrad")
+def conv2d_transpose_dgrad(g: ConvGeom, dz, w, dx, ws=None):
+    check(lib.sv_conv2d_transpose_dgrad_ws(C.byref(g), _ptr(dz), _ptr(w), _ptr(dx), *_ws_args(ws), F32, _stream()),
+          "sv_conv2d_transpose_dgrad_ws")
 
 
 def conv2d_transpose_wgrad(g: ConvGeom, x, dz, dw, accumulate: bool, ws: torch.Tensor):

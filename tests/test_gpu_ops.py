@@ -95,6 +95,66 @@ def test_conv2d_transpose(case, ch):
     close(dw, dw_o, what="convT wgrad")
 
 
+@pytest.mark.parametrize("cfg", [
+    # (kh, kw, s, padding, H, W, cin, cout, n): few result tiles, reductions of hundreds to thousands of terms
+    (4, 4, 2, "same", 8, 8, 128, 96, 2), (4, 4, 1, "valid", 4, 4, 128, 200, 5), (4, 4, 2, "same", 4, 4, 256, 64, 3),
+    (3, 3, 2, "same", 7, 9, 70, 33, 1),
+])
+def test_conv2d_with_scratch_cuts_the_reduction(cfg):
+    """The scratch-taking entry points (reduction cut over workgroups, fixed-order sum + bias + activation) against the
+    oracle, against the plain entry points, and bit-identical from run to run; plain and transposed convs."""
+    from spectrum_vae_amd import ops
+    kh, kw, st, pad, H, W, cin, cout, n = cfg
+    rng = np.random.default_rng(zlib.crc32(repr(cfg).encode()))
+
+    def scratch(g, op, must=False):
+        nb = ops.conv2d_scratch(g, op)
+        assert nb > 0 or not must, "this geometry was chosen to need scratch"
+        return torch.empty(nb, dtype=torch.uint8, device="cuda") if nb else None
+
+    x = rng.standard_normal((n, H, W, cin))
+    w = rng.standard_normal((kh, kw, cin, cout)) * 0.1
+    b = rng.standard_normal(cout)
+    g = ops.conv_geom(n, H, W, cin, kh, kw, st, st, pad, cout)
+    y_o = np_ops.act_fwd(np_ops.conv2d(x, w, b, (st, st), pad), "elu")
+    ys = []
+    for ws in (scratch(g, ops.OP_FWD, True), scratch(g, ops.OP_FWD), None):
+        y = torch.full((n, g.Ho, g.Wo, cout), 9.0, device="cuda")
+        ops.conv2d_fwd(g, dev(x), dev(w), dev(b), y, "elu", 1.0, ws)
+        close(y, y_o, what="fwd")
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
+    dz = rng.standard_normal((n, g.Ho, g.Wo, cout))
+    dx_o, _, _ = np_ops.conv2d_grads(x, w, dz, (st, st), pad)
+    dxs = []
+    for ws in (scratch(g, ops.OP_DGRAD), scratch(g, ops.OP_DGRAD), None):
+        dx = torch.full((n, H, W, cin), 9.0, device="cuda")
+        ops.conv2d_dgrad(g, dev(dz), dev(w), dx, ws)
+        close(dx, dx_o, what="dgrad")
+        dxs.append(dx)
+    assert torch.equal(dxs[0], dxs[1])
+    # the transposed conv with the same geometry struct: input on the (Ho, Wo, cout) side, output on the (H, W, cin) side
+    if (H, W) == (ops.deconv_out_size(g.Ho, kh, st, pad), ops.deconv_out_size(g.Wo, kw, st, pad)):
+        gt = ops.deconv_geom(n, g.Ho, g.Wo, cout, kh, kw, st, st, pad, cin)
+        xt = rng.standard_normal((n, g.Ho, g.Wo, cout))
+        bt = rng.standard_normal(cin)
+        yt_o = np_ops.act_fwd(np_ops.conv2d_transpose(xt, w, bt, (st, st), pad), "tanh")
+        for ws in (scratch(gt, ops.OP_TRANSPOSE_FWD), None):
+            yt = torch.full((n, H, W, cin), 9.0, device="cuda")
+            ops.conv2d_transpose_fwd(gt, dev(xt), dev(w), dev(bt), yt, "tanh", 1.0, ws)
+            close(yt, yt_o, what="convT fwd")
+        dzt = rng.standard_normal(yt_o.shape)
+        dxt_o, _, _ = np_ops.conv2d_transpose_grads(xt, w, dzt, (st, st), pad)
+        for ws in (scratch(gt, ops.OP_TRANSPOSE_DGRAD, True), None):
+            dxt = torch.full((n, g.Ho, g.Wo, cout), 9.0, device="cuda")
+            ops.conv2d_transpose_dgrad(gt, dev(dzt), dev(w), dxt, ws)
+            close(dxt, dxt_o, what="convT dgrad")
+    # a scratch that is too small is ignored, not an error
+    y = torch.empty((n, g.Ho, g.Wo, cout), device="cuda")
+    ops.conv2d_fwd(g, dev(x), dev(w), dev(b), y, "elu", 1.0, torch.empty(16, dtype=torch.uint8, device="cuda"))
+    close(y, y_o, what="fwd, short scratch")
+
+
 @pytest.mark.parametrize("up", [(2, 2), (1, 2)])
 def test_conv2d_folded_upsampling(up):
     """UpSampling2D folded into the conv gather == explicit upsample then conv, forward and both gradients."""
