@@ -18,7 +18,8 @@ int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, 
                          float alpha, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx, int act,
                            float alpha, void* ws, size_t ws_bytes, hipStream_t st);
-int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st);
+int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st,
+                           int accumulate);
 
 // ------------------------------------------------------------------------------------------------ forward
 // y[n,oh,ow,co] = act(bias[co] + sum_{kh,kw,ci} x[n, (oh*SH+kh-pt)/up_h, (ow*SW+kw-pl)/up_w, ci] * w[kh,kw,ci,co])
@@ -278,7 +279,8 @@ int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, 
                     wgrad_direct_workspace(g));
     if (conv_gemm_worthwhile(g, 2)) {
         const int splits = conv_gemm_wgrad_splits(g);
-        int rc = launch_conv_gemm_wgrad(g, x, dz, (float*)ws, splits, st);
+        if (splits == 1) return launch_conv_gemm_wgrad(g, x, dz, dw, 1, st, accumulate);  // tiles go straight into dw
+        int rc = launch_conv_gemm_wgrad(g, x, dz, (float*)ws, splits, st, 0);
         if (rc) return rc;
         hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, (const float*)ws, dw, kc, splits,
                            accumulate);

@@ -33,6 +33,7 @@ struct ConvGemmArgs {
     int one_out;        // DGRAD: the conv has a single output position (Ho == Wo == 1): one row class per input pixel
     int splits;         // FWD / DGRAD: > 1 cuts the reduction into `splits` ranges over blockIdx.z; raw partial sums go to
     float* slabs;       //              slabs[split][M][N] (indexed like c) and splitk_finish_k applies bias + activation
+    int accumulate;     // WGRAD with a single split: c is dw itself and the tile is added to it when set
 };
 
 constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS row pitch (floats): 64 + 4
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
                     out[(((size_t)row_img[rl] * g.H + row_h[rl]) * g.W + row_w[rl]) * g.Cin + n] = v;
                 } else {
                     if (m >= p.M) continue;
+                    if (MODE == GEMM_WGRAD && p.accumulate) v += out[(size_t)m * p.N + n];
                     out[(size_t)m * p.N + n] = v;
                 }
             }
@@ -424,11 +426,13 @@ int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* 
     return launch_splitk_finish(p, st);
 }
 
-// slabs only; the caller sums them (wgrad_reduce)
-int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st) {
+// splits > 1: slabs only, the caller sums them (wgrad_reduce); splits == 1: `slabs` is dw itself (accumulate applies)
+int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st,
+                           int accumulate) {
     ConvGemmArgs p{};
     fill_common(p, g, GEMM_WGRAD);
     p.a = x; p.b = dz; p.bias = nullptr; p.c = slabs; p.act = SV_ACT_NONE; p.alpha = 0.f;
+    p.accumulate = splits == 1 && accumulate;
     p.M = g.KH * g.KW * g.Cin; p.N = g.Cout; p.K = g.N * g.Ho * g.Wo;
     p.k_per_split = (int)(ceil_div(ceil_div(p.K, splits), BK) * BK);
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)splits);

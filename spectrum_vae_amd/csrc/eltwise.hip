@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void act_bwd_k(const float* __restrict__ dy, c
         const int rr = threadIdx.x / C;
         float acc = 0.f;
         if (rr < rif) {
+#pragma unroll 4
             for (int64_t r = r0 + rr; r < r1; r += rif) {
                 const int64_t i = r * C + c;
                 const float g = dy[i] * act_grad_from_y(y[i], act, alpha);
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void act_bwd_k(const float* __restrict__ dy, c
     } else {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float acc = 0.f;
+#pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) {
                 const int64_t i = r * C + c;
                 const float g = dy[i] * act_grad_from_y(y[i], act, alpha);
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ z, flo
         const int c = threadIdx.x % C, rr = threadIdx.x / C;
         float acc = 0.f;
         if (rr < rif)
+#pragma unroll 4
             for (int64_t r = r0 + rr; r < r1; r += rif) acc += z[r * C + c];
         sm[threadIdx.x] = (rr < rif) ? acc : 0.f;
         __syncthreads();
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ z, flo
     } else {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float acc = 0.f;
+#pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) acc += z[r * C + c];
             part[(int64_t)blockIdx.x * C + c] = acc;
         }
@@ -246,6 +250,7 @@ __global__ __launch_bounds__(256) void bn_stats_k(const float* __restrict__ x, f
         float s = 0.f, q = 0.f;
         if (rr < rif) {
             const float piv = x[c];
+#pragma unroll 4
             for (int64_t r = r0 + rr; r < r1; r += rif) {
                 const float d = x[r * C + c] - piv;
                 s += d;
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(256) void bn_stats_k(const float* __restrict__ x, f
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             const float piv = x[c];
             float s = 0.f, q = 0.f;
+#pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) {
                 const float d = x[r * C + c] - piv;
                 s += d;
@@ -331,6 +337,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const float* __restrict__ 
         float s = 0.f, q = 0.f;
         if (rr < rif) {
             const float mu = mean[c], inv = invstd[c];
+#pragma unroll 4
             for (int64_t r = r0 + rr; r < r1; r += rif) {
                 const float g = dy[r * C + c];
                 s += g;
@@ -353,6 +360,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const float* __restrict__ 
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             const float mu = mean[c], inv = invstd[c];
             float s = 0.f, q = 0.f;
+#pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) {
                 const float g = dy[r * C + c];
                 s += g;
@@ -498,14 +506,15 @@ struct ColPlan {
     int64_t rows_per_block;
 };
 ColPlan col_plan(int64_t rows, int C) {
-    // at least ~64 rows of work per block, at most 1024 blocks
-    int64_t nb = ceil_div(rows, 64);
-    if (nb > 1024) nb = 1024;
-    if (nb < 1) nb = 1;
+    // A thread's row loop is a chain of dependent-latency loads, so keep it near 8 iterations (a block sweeps
+    // 256 / C rows at once when C < 256); at most 256 blocks, which the 4-wave fold then sums in 8 rounds of loads.
+    const int64_t sweep = C < 256 ? 256 / C : 1;
+    int64_t rpb = 8 * sweep;
+    const int64_t floor_rpb = ceil_div(rows, 256);
+    if (rpb < floor_rpb) rpb = floor_rpb;
     ColPlan p;
-    p.rows_per_block = ceil_div(rows, nb);
-    p.nblocks = (int)ceil_div(rows, p.rows_per_block);
-    (void)C;
+    p.rows_per_block = rpb;
+    p.nblocks = (int)ceil_div(rows, rpb);
     return p;
 }
 

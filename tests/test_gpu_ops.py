@@ -155,6 +155,25 @@ def test_conv2d_with_scratch_cuts_the_reduction(cfg):
     close(y, y_o, what="fwd, short scratch")
 
 
+def test_conv2d_wgrad_of_a_wide_kernel_goes_straight_into_dw():
+    """A kernel gradient with >= 512 result tiles (the 4x4x128x1000 bottleneck conv, context_encoder.py:77) is not cut
+    into partial sums: the tiles are written / added to dw by the GEMM itself."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(77)
+    n, cin, cout = 3, 128, 1000
+    x = rng.standard_normal((n, 4, 4, cin))
+    dz = rng.standard_normal((n, 1, 1, cout))
+    w = np.zeros((4, 4, cin, cout))
+    g = ops.conv_geom(n, 4, 4, cin, 4, 4, 1, 1, "valid", cout)
+    _, dw_o, _ = np_ops.conv2d_grads(x, w, dz, (1, 1), "valid")
+    ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device="cuda")
+    dw = torch.full((4, 4, cin, cout), 7.0, device="cuda")
+    ops.conv2d_wgrad(g, dev(x), dev(dz), dw, False, ws)
+    close(dw, dw_o, what="wgrad")
+    ops.conv2d_wgrad(g, dev(x), dev(dz), dw, True, ws)
+    close(dw, 2 * dw_o, what="wgrad accumulate")
+
+
 @pytest.mark.parametrize("up", [(2, 2), (1, 2)])
 def test_conv2d_folded_upsampling(up):
     """UpSampling2D folded into the conv gather == explicit upsample then conv, forward and both gradients."""
