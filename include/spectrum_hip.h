@@ -306,6 +306,30 @@ int sv_axpy_f32(float* y, const float* x, float a, int64_t n, sv_stream_t stream
 int sv_cast_f32_bf16(const float* x, void* y, int64_t n, sv_stream_t stream);
 int sv_cast_bf16_f32(const void* x, float* y, int64_t n, sv_stream_t stream);
 
+/* ---- data preparation, the step upstream of the models (generator.py:92-98 builds every training image with it):
+ *      util.process_region (util.py:152-225) with inter_snp_distances (util.py:34-45) and major_minor (util.py:228-256)
+ *      for a whole batch of ragged regions.  x holds the regions' (n_sites, n_haps, n_mut) genotype arrays back to back,
+ *      positions their int64 site positions, site_offsets[r] .. site_offsets[r + 1] the sites of region r (every region
+ *      needs at least one site).  out[r] is the (n_haps, n_snps, n_channels) float32 image: channel 0 the centre-cropped /
+ *      zero-padded, minor-allele-polarised haplotype matrix, the last channel the inter-SNP distances scaled to [-1, 1]
+ *      (float64 arithmetic in the reference's operation order, rounded to float32 on the store), other channels 0.
+ *      distances (optional, [total sites], float64) receives each region's full normalised distance vector.
+ *      status[r] = 1 where the reference's `assert np.max(X) == 1` (util.py:198) would fail.  n_snps even,
+ *      n_haps * n_snps <= 8192.  Bit-identical to the NumPy path. */
+int sv_process_regions(const float* x, const int64_t* positions, const int64_t* site_offsets, int64_t n_regions,
+                       int n_haps, int n_mut, int n_snps, int n_channels, int64_t norm_len, float* out, double* distances,
+                       int32_t* status, sv_stream_t stream);
+/* util.sort_min_diff (util.py:48-58) for a batch: order[r] = the haplotype rows of image r sorted by Manhattan distance
+ * (negative entries clamped to 0, util.py:54) from the row whose summed distance to all rows is smallest (first such
+ * row); equal distances keep row order (the reference inherits an unspecified tie order from scikit-learn).
+ * images: [n_images][n_haps][n_snps][n_channels], the matrix is channel `channel`; n_haps <= 64. */
+int sv_sort_min_diff(const float* images, int64_t n_images, int n_haps, int n_snps, int n_channels, int channel,
+                     int64_t* order, sv_stream_t stream);
+/* out[r][k] = images[r][order[r][k]] with rows of row_elems floats: sort_batch (run_model.py:22-29), batch_sort
+ * (run_context_encoder.py:101-112).  Not in place. */
+int sv_reorder_rows(const float* images, const int64_t* order, float* out, int64_t n_images, int n_rows, int row_elems,
+                    sv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

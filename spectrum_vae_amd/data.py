@@ -71,6 +71,70 @@ def sort_min_diff(X: np.ndarray) -> np.ndarray:
     return np.lexsort((np.arange(D.shape[0]), D[start]))
 
 
+# --------------------------------------------------------------------------- the same functions on the device
+def pack_regions(regions):
+    """Host-side packing of ragged regions for ``process_regions_device``: ``regions`` is a sequence of
+    (X (n_sites, n_haps, n_mut), positions (n_sites,)) pairs.  Returns float32 genotypes back to back, int64
+    positions, int64 offsets (len + 1).  Raises what the reference raises: ragged X / positions (util.py:176) and
+    empty regions (``np.min`` of an empty distance vector, util.py:44)."""
+    if len(regions) == 0:
+        raise ValueError("no regions")
+    n_haps, n_mut = regions[0][0].shape[1:]
+    xs, ps, off = [], [], [0]
+    for X, pos in regions:
+        X, pos = np.asarray(X), np.asarray(pos)
+        if X.ndim != 3 or X.shape[1:] != (n_haps, n_mut):
+            raise ValueError("every region must be (n_sites, n_haps, n_mut) with the same n_haps and n_mut")
+        if X.shape[0] != pos.shape[0]:
+            raise ValueError("one position per site is required")
+        if X.shape[0] == 0:
+            raise ValueError("a region needs at least one site")
+        xs.append(np.ascontiguousarray(X, dtype=np.float32).reshape(-1))
+        ps.append(np.ascontiguousarray(pos, dtype=np.int64))
+        off.append(off[-1] + X.shape[0])
+    return np.concatenate(xs), np.concatenate(ps), np.asarray(off, dtype=np.int64), n_haps, n_mut
+
+
+def process_regions_device(x, positions, offsets, n_haps: int, n_mut: int, return_distances: bool = False, check: bool = True):
+    """util.process_region (util.py:152-225) for a packed batch of regions on the GPU: ``x`` / ``positions`` /
+    ``offsets`` are device tensors laid out as ``pack_regions`` returns them.  Returns the (R, n_haps, NUM_SNPS,
+    NUM_CHANNELS) float32 device tensor (and the float64 distance vectors of all sites when asked).  ``check``
+    reads the status words back (one host sync) and raises where the reference's assertion (util.py:198) fails."""
+    import torch
+    from . import ops
+    n_regions = offsets.numel() - 1
+    out = torch.empty((n_regions, n_haps, global_vars.NUM_SNPS, global_vars.NUM_CHANNELS), dtype=torch.float32,
+                      device=x.device)
+    status = torch.empty(n_regions, dtype=torch.int32, device=x.device)
+    dist = torch.empty(positions.numel(), dtype=torch.float64, device=x.device) if return_distances else None
+    ops.process_regions(x, positions, offsets, n_regions, n_haps, n_mut, global_vars.NUM_SNPS, global_vars.NUM_CHANNELS,
+                        global_vars.L, out, dist, status)
+    if check and bool(status.any().item()):
+        bad = torch.nonzero(status).flatten().tolist()
+        raise ValueError(f"each (site, haplotype) must carry at most one mutation type (regions {bad[:8]})")
+    return (out, dist) if return_distances else out
+
+
+def sort_min_diff_device(images, channel: int = 0):
+    """util.sort_min_diff (util.py:48-58) of every image of a (R, n_haps, n_snps, C) float32 device tensor:
+    (R, n_haps) int64 row orders; ties keep row order, as in ``sort_min_diff`` above."""
+    import torch
+    from . import ops
+    order = torch.empty(images.shape[:2], dtype=torch.int64, device=images.device)
+    ops.sort_min_diff(images, channel, order)
+    return order
+
+
+def sort_batch_device(images, channel: int = 0):
+    """run_model.py:22-29 / run_context_encoder.py:101-112 on the device: every image with its haplotype rows
+    reordered by ``sort_min_diff_device``."""
+    import torch
+    from . import ops
+    out = torch.empty_like(images)
+    ops.reorder_rows(images, sort_min_diff_device(images, channel), out)
+    return out
+
+
 def synth_genotypes(rng: np.random.Generator, n_sites: int, n_haps: int = global_vars.NUM_HAPLOTYPES,
                     n_mut: int = 6):
     """A (n_sites, n_haps, 6) one-hot-by-mutation-type array and sorted positions in [0, L)."""

@@ -365,6 +365,26 @@ def gather_rows(src, idx, dst):
                              n_rows, row, _stream()), "sv_gather_rows")
 
 
+# --------------------------------------------------------------------------- data preparation
+def process_regions(x, positions, offsets, n_regions: int, n_haps: int, n_mut: int, n_snps: int, n_channels: int,
+                    norm_len: int, out, distances, status):
+    check(lib.sv_process_regions(_ptr(x), _ptr(positions, torch.int64), _ptr(offsets, torch.int64), n_regions, n_haps,
+                                 n_mut, n_snps, n_channels, norm_len, _ptr(out), _ptr(distances, torch.float64),
+                                 _ptr(status, torch.int32), _stream()), "sv_process_regions")
+
+
+def sort_min_diff(images, channel: int, order):
+    n, h, s, c = images.shape
+    check(lib.sv_sort_min_diff(_ptr(images), n, h, s, c, channel, _ptr(order, torch.int64), _stream()),
+          "sv_sort_min_diff")
+
+
+def reorder_rows(images, order, out):
+    n, h = order.shape
+    check(lib.sv_reorder_rows(_ptr(images), _ptr(order, torch.int64), _ptr(out), n, h, images[0, 0].numel(), _stream()),
+          "sv_reorder_rows")
+
+
 def mask_input(x, mask, y):
     if not (x.numel() == mask.numel() == y.numel()):
         raise ValueError("mask_input: sizes differ")
