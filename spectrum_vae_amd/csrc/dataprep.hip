@@ -95,16 +95,41 @@ __global__ __launch_bounds__(kPrepThreads) void process_regions_k(PrepArgs a) {
     // matrix); the window's sums and per-site derived-allele counts stay in LDS
     float vmax = -INFINITY;
     const int64_t pairs = (int64_t)n * H;
-    for (int64_t p = threadIdx.x; p < pairs; p += kPrepThreads) {
-        const int s = (int)(p / H), h = (int)(p - (int64_t)s * H);
-        const float* q = x + (size_t)p * M;
-        float v = q[0];
-        for (int c = 1; c < M; ++c) v += q[c];
+    auto keep = [&](int64_t p, float v) {  // p = s * H + h
         vmax = v > vmax ? v : vmax;
+        const int s = (int)(p / H), h = (int)(p - (int64_t)s * H);
         const int j = s - src0;
         if (j >= 0 && j < nwin) {
             hs[h * S + dst0 + j] = v;
             if (v != 0.f) atomicAdd(&cnt[dst0 + j], 1);
+        }
+    };
+    if (M == 6 && (H & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        // two (site, haplotype) pairs = 12 floats = three 16-byte loads per lane, consecutive lanes on consecutive
+        // 48-byte pieces; two couples per iteration keep six loads in flight
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const int64_t couples = pairs >> 1;
+        int64_t q = threadIdx.x;
+        for (; q + kPrepThreads < couples; q += 2 * kPrepThreads) {
+            const float4 a0 = x4[3 * q], a1 = x4[3 * q + 1], a2 = x4[3 * q + 2];
+            const int64_t q2 = q + kPrepThreads;
+            const float4 b0 = x4[3 * q2], b1 = x4[3 * q2 + 1], b2 = x4[3 * q2 + 2];
+            keep(2 * q, ((((a0.x + a0.y) + a0.z) + a0.w) + a1.x) + a1.y);
+            keep(2 * q + 1, ((((a1.z + a1.w) + a2.x) + a2.y) + a2.z) + a2.w);
+            keep(2 * q2, ((((b0.x + b0.y) + b0.z) + b0.w) + b1.x) + b1.y);
+            keep(2 * q2 + 1, ((((b1.z + b1.w) + b2.x) + b2.y) + b2.z) + b2.w);
+        }
+        for (; q < couples; q += kPrepThreads) {
+            const float4 a0 = x4[3 * q], a1 = x4[3 * q + 1], a2 = x4[3 * q + 2];
+            keep(2 * q, ((((a0.x + a0.y) + a0.z) + a0.w) + a1.x) + a1.y);
+            keep(2 * q + 1, ((((a1.z + a1.w) + a2.x) + a2.y) + a2.z) + a2.w);
+        }
+    } else {
+        for (int64_t p = threadIdx.x; p < pairs; p += kPrepThreads) {
+            const float* q = x + (size_t)p * M;
+            float v = q[0];
+            for (int c = 1; c < M; ++c) v += q[c];
+            keep(p, v);
         }
     }
 #pragma unroll
@@ -199,8 +224,9 @@ __global__ __launch_bounds__(kPrepThreads) void sort_min_diff_k(SortArgs a) {
     }
 }
 
-// out[r][k][:] = img[r][order[r][k]][:], rows of `row` floats
-__global__ void reorder_rows_k(const float* __restrict__ img, const int64_t* __restrict__ order, float* __restrict__ out,
+// out[r][k][:] = img[r][order[r][k]][:], rows of `row` elements of type T (float4 when the row allows it)
+template <typename T>
+__global__ void reorder_rows_k(const T* __restrict__ img, const int64_t* __restrict__ order, T* __restrict__ out,
                                int64_t R, int H, int row) {
     const int64_t total = R * H * row;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -258,8 +284,13 @@ int sv_reorder_rows(const float* images, const int64_t* order, float* out, int64
     SV_REQUIRE(images && order && out && images != out, "sv_reorder_rows: null tensor or in-place call");
     SV_REQUIRE(n_images >= 0 && n_rows > 0 && row_elems > 0, "sv_reorder_rows: bad shape");
     if (n_images == 0) return SV_OK;
-    hipLaunchKernelGGL(reorder_rows_k, dim3(ew_grid(n_images * n_rows * row_elems, 256, 8192)), dim3(256), 0,
-                       to_stream(stream), images, order, out, n_images, n_rows, row_elems);
+    if ((row_elems & 3) == 0 && ((reinterpret_cast<uintptr_t>(images) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+        hipLaunchKernelGGL(reorder_rows_k<float4>, dim3(ew_grid(n_images * n_rows * (row_elems / 4), 256, 16384)), dim3(256),
+                           0, to_stream(stream), reinterpret_cast<const float4*>(images), order,
+                           reinterpret_cast<float4*>(out), n_images, n_rows, row_elems / 4);
+    else
+        hipLaunchKernelGGL(reorder_rows_k<float>, dim3(ew_grid(n_images * n_rows * row_elems, 256, 16384)), dim3(256), 0,
+                           to_stream(stream), images, order, out, n_images, n_rows, row_elems);
     return check_launch("sv_reorder_rows");
 }
 
