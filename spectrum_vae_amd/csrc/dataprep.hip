@@ -11,7 +11,7 @@
 // written once, with consecutive lanes on consecutive addresses.  Floating point appears only in the distance channel,
 // which is formed in float64 with the reference's operation order ((2 * (d - min)) / (max - min) - 1) and rounded to
 // float32 on the store, so results are bit-identical to the NumPy path.
-#include "common.h"
+#include "tile_common.h"
 
 namespace sv {
 
@@ -48,11 +48,12 @@ __device__ __forceinline__ double block_reduce_minmax(double v, bool is_max, dou
 }
 
 __global__ __launch_bounds__(kPrepThreads) void process_regions_k(PrepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // hs[n_haps][S] | cnt[S] (int) | red[4] (double)
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // hs[n_haps][S] | cnt[S] (int) | dwin[S] | red[4] (double)
     const int H = a.n_haps, S = a.S, C = a.C, M = a.n_mut;
     float* hs = sm;
     int* cnt = reinterpret_cast<int*>(sm + (size_t)H * S);
-    double* red = reinterpret_cast<double*>(sm + (((size_t)H * S + S + 1) & ~(size_t)1));
+    float* dwin = sm + (size_t)H * S + S;
+    double* red = reinterpret_cast<double*>(sm + (((size_t)H * S + 2 * S + 1) & ~(size_t)1));
     __shared__ float wave_max[kPrepThreads / 64];
 
     const int r = blockIdx.x;
@@ -88,21 +89,30 @@ __global__ __launch_bounds__(kPrepThreads) void process_regions_k(PrepArgs a) {
     }
 
     for (int i = threadIdx.x; i < H * S; i += kPrepThreads) hs[i] = 0.f;
-    for (int i = threadIdx.x; i < S; i += kPrepThreads) cnt[i] = 0;
+    for (int col = threadIdx.x; col < S; col += kPrepThreads) {  // the window's distance channel, rounded once
+        const int j = col - dst0;
+        float v = 0.f;
+        if (j >= 0 && j < nwin) {
+            const int k = src0 + j;
+            const double d = k == 0 ? 0.0 : (double)(pos[k] - pos[k - 1]) / a.norm_len;
+            v = (float)((2.0 * (d - dmin)) / span - 1.0);
+        }
+        dwin[col] = v;
+    }
     __syncthreads();
 
     // ---- haplotype sums over the mutation-type channels for EVERY site (the reference checks the maximum of the whole
     // matrix); the window's sums and per-site derived-allele counts stay in LDS
     float vmax = -INFINITY;
     const int64_t pairs = (int64_t)n * H;
+    const FDiv fH = fd_make(H);
+    const bool muldiv = (uint64_t)pairs * (uint64_t)H < (1ull << 32);  // range in which the multiply-based division is exact
     auto keep = [&](int64_t p, float v) {  // p = s * H + h
         vmax = v > vmax ? v : vmax;
-        const int s = (int)(p / H), h = (int)(p - (int64_t)s * H);
+        const int s = muldiv ? fd((int)p, fH) : (int)(p / H);
+        const int h = (int)(p - (int64_t)s * H);
         const int j = s - src0;
-        if (j >= 0 && j < nwin) {
-            hs[h * S + dst0 + j] = v;
-            if (v != 0.f) atomicAdd(&cnt[dst0 + j], 1);
-        }
+        if (j >= 0 && j < nwin) hs[h * S + dst0 + j] = v;
     };
     if (M == 6 && (H & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         // two (site, haplotype) pairs = 12 floats = three 16-byte loads per lane, consecutive lanes on consecutive
@@ -145,24 +155,27 @@ __global__ __launch_bounds__(kPrepThreads) void process_regions_k(PrepArgs a) {
         for (int k = 1; k < kPrepThreads / 64; ++k) mx = wave_max[k] > mx ? wave_max[k] : mx;
         a.status[r] = (mx == 1.0f) ? 0 : 1;
     }
+    // derived-allele count of each window column
+    for (int col = threadIdx.x; col < S; col += kPrepThreads) {
+        int k = 0;
+        for (int h = 0; h < H; ++h) k += hs[h * S + col] != 0.f;
+        cnt[col] = k;
+    }
+    __syncthreads();
 
     // ---- write the image: channel 0 = polarised haplotypes, channels 1 .. C-2 = 0, channel C-1 = distances
     float* out = a.out + (size_t)r * H * S * C;
     const int total = H * S * C;
+    const FDiv fC = fd_make(C), fS = fd_make(S);  // total * max(C, S) stays far below 2^32 (n_haps * S <= 8192)
     for (int e = threadIdx.x; e < total; e += kPrepThreads) {
-        const int c = e % C;
-        const int col = (e / C) % S;
-        const int h = e / (C * S);
-        const int j = col - dst0;
-        const bool inwin = j >= 0 && j < nwin;
+        const int px = fd(e, fC), c = e - px * C;
+        const int h = fd(px, fS), col = px - h * S;
         float v = 0.f;
-        if (inwin && c == C - 1) {
-            const int k = src0 + j;
-            const double d = k == 0 ? 0.0 : (double)(pos[k] - pos[k - 1]) / a.norm_len;
-            v = (float)((2.0 * (d - dmin)) / span - 1.0);
-        } else if (inwin && c == 0) {
+        if (c == C - 1) {
+            v = dwin[col];
+        } else if (c == 0) {
             // util.py:228-256: untouched when no haplotype carries the derived allele; flipped (1 - x) when more than
-            // half do; zeros become -1 in both remaining cases
+            // half do; zeros become -1 in both remaining cases.  Columns outside the window hold zeros and count 0.
             v = hs[h * S + col];
             const int k = cnt[col];
             if (k != 0) {
@@ -257,7 +270,7 @@ int sv_process_regions(const float* x, const int64_t* positions, const int64_t* 
     SV_REQUIRE(norm_len != 0, "sv_process_regions: norm_len is 0");
     if (n_regions == 0) return SV_OK;
     PrepArgs a{x, positions, site_offsets, out, distances, status, n_haps, n_mut, n_snps, n_channels, (double)norm_len};
-    const size_t lds = ((((size_t)n_haps * n_snps + n_snps + 1) & ~(size_t)1)) * sizeof(float) + 4 * sizeof(double);
+    const size_t lds = ((((size_t)n_haps * n_snps + 2 * n_snps + 1) & ~(size_t)1)) * sizeof(float) + 4 * sizeof(double);
     hipLaunchKernelGGL(process_regions_k, dim3((unsigned)n_regions), dim3(kPrepThreads), lds, to_stream(stream), a);
     return check_launch("sv_process_regions");
 }
