@@ -38,16 +38,22 @@ struct ConvGemmArgs {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS row pitch (floats): 64 + 4
 
-template <int MODE>
+// BNT: columns of the result tile.  64: the 4 waves sit 2 x 2, each on 32 x 32 (2 x 2 accumulators);  16 (results with at
+// most 16 columns: the 3-channel image convs, single-logit heads): the waves sit 4 x 1, each on 16 x 16.
+template <int MODE, int BNT>
 __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
+    constexpr int WAVES_N = BNT == 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    constexpr int TI = BM / WAVES_M / 16, TJ = BNT / WAVES_N / 16;  // accumulators per wave
+    constexpr int NB = BK * BNT / 256;                               // B elements per thread and step
+    constexpr int BROWS = 256 / BNT;                                 // reduction rows one sweep of the threads covers (k-major B)
     __shared__ __attribute__((aligned(16))) float As[BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
     const sv_conv_geom& g = p.g;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BNT;
+    const int wm = (wave % WAVES_M) * (16 * TI), wn = (wave / WAVES_M) * (16 * TJ);
 
     int kbeg = 0, kend = p.K;
     if (MODE == GEMM_WGRAD) {
@@ -138,14 +144,14 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         }
     }
 
-    v4f_t acc[2][2];
+    v4f_t acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = v4f_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = v4f_t{0.f, 0.f, 0.f, 0.f};
 
     // global -> registers for one reduction step (issued one step ahead of its use, so the round trip overlaps the MFMAs)
-    auto gather = [&](int k0, float (&av)[4], float (&bv)[4]) {
+    auto gather = [&](int k0, float (&av)[4], float (&bv)[NB]) {
         // ---- gather A
         if (MODE == GEMM_FWD) {
             const int k = k0 + (t & 15);
@@ -197,21 +203,21 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             const int kh = p.one_out ? kh0 : kh0 + jh * g.SH, kw = p.one_out ? kw0 : kw0 + jw * g.SW;
             const int tap = kh * g.KW + kw;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NB; ++i) {
                 const int n = n0 + (t >> 4) + 16 * i;
                 bv[i] = (kok && n < p.N) ? p.b[((int64_t)tap * g.Cin + n) * g.Cout + co] : 0.f;
             }
         } else {
-            const int n = n0 + (t & 63);
+            const int n = n0 + (t & (BNT - 1));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = k0 + (t >> 6) + 4 * i;
+            for (int i = 0; i < NB; ++i) {
+                const int k = k0 + (t / BNT) + BROWS * i;
                 bv[i] = (k < kend && n < p.N) ? p.b[(int64_t)k * p.N + n] : 0.f;
             }
         }
     };
 
-    float av[4], bv[4];
+    float av[4], bv[NB];
     if (kbeg < kend) gather(kbeg, av, bv);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();  // the previous step's MFMA reads are done
@@ -224,24 +230,24 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         }
         if (MODE == GEMM_DGRAD) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Bs[t & 15][(t >> 4) + 16 * i] = bv[i];
+            for (int i = 0; i < NB; ++i) Bs[t & 15][(t >> 4) + 16 * i] = bv[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Bs[(t >> 6) + 4 * i][t & 63] = bv[i];
+            for (int i = 0; i < NB; ++i) Bs[(t / BNT) + BROWS * i][t & (BNT - 1)] = bv[i];
         }
         __syncthreads();
         if (k0 + BK < kend) gather(k0 + BK, av, bv);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
-            float a[2], b[2];
+            float a[TI], b[TJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[kk + lk][wm + 16 * i + li];
+            for (int i = 0; i < TI; ++i) a[i] = As[kk + lk][wm + 16 * i + li];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[kk + lk][wn + 16 * j + li];
+            for (int j = 0; j < TJ; ++j) b[j] = Bs[kk + lk][wn + 16 * j + li];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
     // ---- epilogue
@@ -250,9 +256,9 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     const bool raw = MODE == GEMM_WGRAD || p.splits > 1;
     if (MODE != GEMM_WGRAD && p.splits > 1) out = p.slabs + (size_t)split * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TJ; ++j) {
             const int n = n0 + wn + 16 * j + li;
             if (n >= p.N) continue;
             const float bb = (!raw && p.bias != nullptr) ? p.bias[n] : 0.f;
@@ -309,6 +315,8 @@ bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode) {
     return ncols >= 1 && kdim >= 16 && rows < (1ll << 30) && kdim < (1ll << 30);
 }
 
+static int tile_cols(int ncols) { return ncols <= 16 ? 16 : BN; }
+
 // FWD / DGRAD: a result with few 64 x 64 tiles leaves most of the 256 CUs idle while each workgroup walks a long
 // reduction; cut the reduction so that about 512 workgroups exist, each keeping at least 4 steps.
 static void dgrad_classes(const sv_conv_geom& g, int& classes, int& rows, int64_t& kclass) {
@@ -325,12 +333,12 @@ int conv_gemm_splits(const sv_conv_geom& g, int mode) {
     int64_t blocks, kdim;
     int zbase = 1;
     if (mode == GEMM_FWD) {
-        blocks = ceil_div((int64_t)g.N * g.Ho * g.Wo, BM) * ceil_div(g.Cout, BN);
+        blocks = ceil_div((int64_t)g.N * g.Ho * g.Wo, BM) * ceil_div(g.Cout, tile_cols(g.Cout));
         kdim = (int64_t)g.KH * g.KW * g.Cin;
     } else {
         int classes, rows;
         dgrad_classes(g, classes, rows, kdim);
-        blocks = ceil_div(rows, BM) * ceil_div(g.Cin, BN) * classes;
+        blocks = ceil_div(rows, BM) * ceil_div(g.Cin, tile_cols(g.Cin)) * classes;
         zbase = classes;
     }
     if (blocks >= 192) return 1;
@@ -359,7 +367,7 @@ static int launch_splitk_finish(const ConvGemmArgs& p, hipStream_t st) {
 
 int conv_gemm_wgrad_splits(const sv_conv_geom& g) {
     const int64_t M = (int64_t)g.KH * g.KW * g.Cin, R = (int64_t)g.N * g.Ho * g.Wo;
-    const int64_t tiles = ceil_div(M, BM) * ceil_div(g.Cout, BN);
+    const int64_t tiles = ceil_div(M, BM) * ceil_div(g.Cout, tile_cols(g.Cout));
     int64_t s = ceil_div(512, tiles);
     const int64_t maxs = ceil_div(R, 4 * BK);
     if (s > maxs) s = maxs;
@@ -396,8 +404,10 @@ int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, 
         p.splits = conv_gemm_splits(g, GEMM_FWD);
         p.slabs = (float*)ws;
     }
-    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)p.splits);
-    hipLaunchKernelGGL(conv_gemm_mfma<GEMM_FWD>, grid, dim3(256), 0, st, p);
+    const int bnt = tile_cols(p.N);
+    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, bnt), (unsigned)p.splits);
+    if (bnt == 16) hipLaunchKernelGGL((conv_gemm_mfma<GEMM_FWD, 16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_gemm_mfma<GEMM_FWD, 64>), grid, dim3(256), 0, st, p);
     int rc = check_launch("conv_gemm_mfma<fwd>");
     if (rc || p.splits == 1) return rc;
     return launch_splitk_finish(p, st);
@@ -419,8 +429,10 @@ int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* 
         p.splits = conv_gemm_splits(g, GEMM_DGRAD);
         p.slabs = (float*)ws;
     }
-    dim3 grid((unsigned)ceil_div(rows, BM), (unsigned)ceil_div(p.N, BN), (unsigned)(classes * p.splits));
-    hipLaunchKernelGGL(conv_gemm_mfma<GEMM_DGRAD>, grid, dim3(256), 0, st, p);
+    const int bnt = tile_cols(p.N);
+    dim3 grid((unsigned)ceil_div(rows, BM), (unsigned)ceil_div(p.N, bnt), (unsigned)(classes * p.splits));
+    if (bnt == 16) hipLaunchKernelGGL((conv_gemm_mfma<GEMM_DGRAD, 16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_gemm_mfma<GEMM_DGRAD, 64>), grid, dim3(256), 0, st, p);
     int rc = check_launch("conv_gemm_mfma<dgrad>");
     if (rc || p.splits == 1) return rc;
     return launch_splitk_finish(p, st);
@@ -435,8 +447,10 @@ int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* d
     p.accumulate = splits == 1 && accumulate;
     p.M = g.KH * g.KW * g.Cin; p.N = g.Cout; p.K = g.N * g.Ho * g.Wo;
     p.k_per_split = (int)(ceil_div(ceil_div(p.K, splits), BK) * BK);
-    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, BN), (unsigned)splits);
-    hipLaunchKernelGGL(conv_gemm_mfma<GEMM_WGRAD>, grid, dim3(256), 0, st, p);
+    const int bnt = tile_cols(p.N);
+    dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, bnt), (unsigned)splits);
+    if (bnt == 16) hipLaunchKernelGGL((conv_gemm_mfma<GEMM_WGRAD, 16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_gemm_mfma<GEMM_WGRAD, 64>), grid, dim3(256), 0, st, p);
     return check_launch("conv_gemm_mfma<wgrad>");
 }
 

@@ -507,10 +507,10 @@ struct ColPlan {
 };
 ColPlan col_plan(int64_t rows, int C) {
     // A thread's row loop is a chain of dependent-latency loads, so keep it near 8 iterations (a block sweeps
-    // 256 / C rows at once when C < 256); at most 256 blocks, which the 4-wave fold then sums in 8 rounds of loads.
+    // 256 / C rows at once when C < 256); at most 1024 blocks, which the 4-wave fold then sums in 32 rounds of loads.
     const int64_t sweep = C < 256 ? 256 / C : 1;
     int64_t rpb = 8 * sweep;
-    const int64_t floor_rpb = ceil_div(rows, 256);
+    const int64_t floor_rpb = ceil_div(rows, 1024);
     if (rpb < floor_rpb) rpb = floor_rpb;
     ColPlan p;
     p.rows_per_block = rpb;

@@ -34,25 +34,30 @@ def timed(fn, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=0, help="override both batch sizes (default: the drivers' 64 and 32)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     out = {}
     # context encoder + discriminator, batch 64 (run_context_encoder.py:380)
-    B = 64
+    B = a.batch or 64
     X = torch.from_numpy(synth_training_tensor(B, 7)).to(dev)
     mask = torch.from_numpy(run_context_encoder.batch_random_mask(X.cpu().numpy(), 0.25, np.random.default_rng(1))).to(dev)
     ce, disc = context_encoder.ContextEncoder(), context_encoder.Discriminator()
     o1, o2 = run_context_encoder.build_optimizer(2e-3), run_context_encoder.build_optimizer(2e-4)
     dt = timed(lambda: run_context_encoder.train_step(ce, disc, o1, o2, X, mask), a.steps)
-    out["context_encoder_step_b64"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1)}
+    # algorithmic FLOP per sample of one step: generator fwd + bwd, discriminator fwd + bwd on real and fake for its own
+    # update, plus its fwd + input-gradient pass for the generator's adversarial term (2 MAC, convs and dense only)
+    flop = 107_937_792 + 2 * 40_906_752 + 14_159_872 * 2
+    out[f"context_encoder_step_b{B}"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1),
+                                         "model_tflops": round(flop * B / dt / 1e12, 2)}
     # U-Net generator + discriminator, batch 32 (run_unet.py:296)
-    B = 32
+    B = a.batch or 32
     Y = torch.from_numpy(synth_training_tensor(B, 9)).to(dev)
     Xu = Y[..., :1].contiguous()
     gen, d2 = unet.Generator(), unet.Discriminator()
     g1, g2 = run_unet.build_optimizer(2e-4), run_unet.build_optimizer(2e-4)
     dt = timed(lambda: run_unet.train_step(gen, d2, g1, g2, Xu, Y), a.steps)
-    out["unet_gan_step_b32"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1)}
+    out[f"unet_gan_step_b{B}"] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1)}
     print(json.dumps(out))
 
 
