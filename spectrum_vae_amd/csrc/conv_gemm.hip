@@ -40,12 +40,16 @@ constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS row pitch (floats): 6
 
 // BNT: columns of the result tile.  64: the 4 waves sit 2 x 2, each on 32 x 32 (2 x 2 accumulators);  16 (results with at
 // most 16 columns: the 3-channel image convs, single-logit heads): the waves sit 4 x 1, each on 16 x 16.
-template <int MODE, int BNT>
+// VA / VB: the A / B operand is gathered with 16-byte loads along its memory-contiguous index (channels); needs that
+// channel count to be a multiple of 4 and a 16-byte aligned tensor, else the operand falls back to 4-byte gathers.
+template <int MODE, int BNT, bool VA, bool VB>
 __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     constexpr int WAVES_N = BNT == 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int TI = BM / WAVES_M / 16, TJ = BNT / WAVES_N / 16;  // accumulators per wave
-    constexpr int NB = BK * BNT / 256;                               // B elements per thread and step
+    constexpr int NB = BK * BNT / 256;                               // B elements per thread and step (4-byte gathers)
     constexpr int BROWS = 256 / BNT;                                 // reduction rows one sweep of the threads covers (k-major B)
+    constexpr int NR = VA ? 1 : 4;                                   // result rows a thread gathers A for (FWD / DGRAD)
+    constexpr int NBR = VB ? 4 : NB;                                 // B registers per thread
     __shared__ __attribute__((aligned(16))) float As[BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
     const sv_conv_geom& g = p.g;
@@ -111,14 +115,15 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         kend = min(kend, kbeg + kper);  // may leave an empty range: the workgroup then stores zeros
     }
 
-    // ---- per-thread row bookkeeping of the A gather (fixed over the reduction loop)
-    // FWD / DGRAD: thread loads k = t & 15 of rows (t >> 4) + 16 i;  WGRAD: row m = t & 63, reduction (t >> 6) + 4 i
-    int r_img[4], r_h[4], r_w[4];
-    bool r_ok[4];
+    // ---- per-thread bookkeeping of the A gather (fixed over the reduction loop)
+    // 4-byte gathers: FWD / DGRAD thread loads k = t & 15 of rows (t >> 4) + 16 i;  WGRAD: row m = t & 63, reduction (t >> 6) + 4 i
+    // 16-byte gathers: FWD / DGRAD thread loads k = 4 (t & 3) .. + 3 of row t >> 2;  WGRAD: rows m = 4 (t & 15) .. + 3, reduction t >> 4
+    int r_img[NR], r_h[NR], r_w[NR];
+    bool r_ok[NR];
     int a_kh = 0, a_kw = 0, a_ci = 0;
     bool a_ok = true;
     if (MODE == GEMM_WGRAD) {
-        const int m = m0 + (t & 63);
+        const int m = m0 + (VA ? (t & 15) * 4 : (t & 63));
         a_ok = m < p.M;
         const int tap = a_ok ? fd(m, p.f_ck) : 0;
         a_ci = a_ok ? m - tap * g.Cin : 0;
@@ -126,15 +131,15 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         a_kw = tap - a_kh * g.KW;
     } else if (MODE == GEMM_DGRAD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rl = (t >> 4) + 16 * i;
+        for (int i = 0; i < NR; ++i) {
+            const int rl = VA ? (t >> 2) : (t >> 4) + 16 * i;
             r_img[i] = row_img[rl]; r_h[i] = row_h[rl]; r_w[i] = row_w[rl];
             r_ok[i] = r_img[i] >= 0;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + (t >> 4) + 16 * i;
+        for (int i = 0; i < NR; ++i) {
+            const int m = m0 + (VA ? (t >> 2) : (t >> 4) + 16 * i);
             r_ok[i] = m < p.M;
             const int mm = r_ok[i] ? m : 0;
             const int img = fd(mm, p.f_howo);
@@ -150,39 +155,53 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = v4f_t{0.f, 0.f, 0.f, 0.f};
 
+    auto ld4 = [](const float* q, bool ok, float* dst) {
+        const float4 v = ok ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    };
+    const bool b_lane = BNT == 64 || t < 64;  // 16-byte B gathers of a 16-column tile need 64 threads only
+
     // global -> registers for one reduction step (issued one step ahead of its use, so the round trip overlaps the MFMAs)
-    auto gather = [&](int k0, float (&av)[4], float (&bv)[NB]) {
+    auto gather = [&](int k0, float (&av)[4], float (&bv)[NBR]) {
+        // ---- the reduction index this thread decodes (FWD / DGRAD)
+        const int kt = k0 + (VA ? (t & 3) * 4 : (t & 15));
         // ---- gather A
         if (MODE == GEMM_FWD) {
-            const int k = k0 + (t & 15);
-            const bool kok = k < kend;
-            const int kk = kok ? k : 0;
+            const bool kok = kt < kend;
+            const int kk = kok ? kt : 0;
             const int tap = fd(kk, p.f_ck), ci = kk - tap * g.Cin;
             const int kh = fd(tap, p.f_kw), kw = tap - kh * g.KW;
+            if (VA) {
+                const int ih = r_h[0] * g.SH - g.pad_t + kh, iw = r_w[0] * g.SW - g.pad_l + kw;
+                const bool ok = kok && r_ok[0] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+                ld4(p.a + (((int64_t)r_img[0] * g.H + ih) * g.W + iw) * g.Cin + ci, ok, av);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ih = r_h[i] * g.SH - g.pad_t + kh, iw = r_w[i] * g.SW - g.pad_l + kw;
-                const bool ok = kok && r_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                av[i] = ok ? p.a[(((int64_t)r_img[i] * g.H + ih) * g.W + iw) * g.Cin + ci] : 0.f;
+                for (int i = 0; i < NR; ++i) {
+                    const int ih = r_h[i] * g.SH - g.pad_t + kh, iw = r_w[i] * g.SW - g.pad_l + kw;
+                    const bool ok = kok && r_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+                    av[i] = ok ? p.a[(((int64_t)r_img[i] * g.H + ih) * g.W + iw) * g.Cin + ci] : 0.f;
+                }
             }
         } else if (MODE == GEMM_DGRAD) {
-            const int k = k0 + (t & 15);
-            const bool kok = k < kend;
-            const int kk = kok ? k : 0;
+            const bool kok = kt < kend;
+            const int kk = kok ? kt : 0;
             const int j = fd(kk, p.f_ck), co = kk - j * g.Cout;  // j: index among the class's taps
             const int jh = fd(j, f_nkw), jw = j - jh * nkw;
             const int kh = p.one_out ? kh0 : kh0 + jh * g.SH, kw = p.one_out ? kw0 : kw0 + jw * g.SW;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
                 const int oh = th / g.SH, ow = tw / g.SW;  // exact by construction of the class
                 const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo;
-                av[i] = ok ? p.a[(((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co] : 0.f;
+                const float* q = p.a + (((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co;
+                if (VA) ld4(q, ok, av);
+                else av[i] = ok ? *q : 0.f;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = k0 + (t >> 6) + 4 * i;
+            for (int i = 0; i < (VA ? 1 : 4); ++i) {
+                const int r = k0 + (VA ? (t >> 4) : (t >> 6) + 4 * i);
                 const bool rok = a_ok && r < kend;
                 const int rr = rok ? r : 0;
                 const int img = fd(rr, p.f_howo);
@@ -190,23 +209,34 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
                 const int oh = fd(rem, p.f_wo), ow = rem - oh * p.f_wo.d;
                 const int ih = oh * g.SH - g.pad_t + a_kh, iw = ow * g.SW - g.pad_l + a_kw;
                 const bool ok = rok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                av[i] = ok ? p.a[(((int64_t)img * g.H + ih) * g.W + iw) * g.Cin + a_ci] : 0.f;
+                const float* q = p.a + (((int64_t)img * g.H + ih) * g.W + iw) * g.Cin + a_ci;
+                if (VA) ld4(q, ok, av);
+                else av[i] = ok ? *q : 0.f;
             }
         }
         // ---- gather B
         if (MODE == GEMM_DGRAD) {
-            const int k = k0 + (t & 15);
-            const bool kok = k < kend;
-            const int kk = kok ? k : 0;
+            const int kb = k0 + (VB ? (t & 3) * 4 : (t & 15));
+            const bool kok = kb < kend;
+            const int kk = kok ? kb : 0;
             const int j = fd(kk, p.f_ck), co = kk - j * g.Cout;
             const int jh = fd(j, f_nkw), jw = j - jh * nkw;
             const int kh = p.one_out ? kh0 : kh0 + jh * g.SH, kw = p.one_out ? kw0 : kw0 + jw * g.SW;
             const int tap = kh * g.KW + kw;
+            if (VB) {
+                const int n = n0 + (t >> 2);
+                ld4(p.b + ((int64_t)tap * g.Cin + n) * g.Cout + co, b_lane && kok && n < p.N, bv);
+            } else {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int n = n0 + (t >> 4) + 16 * i;
-                bv[i] = (kok && n < p.N) ? p.b[((int64_t)tap * g.Cin + n) * g.Cout + co] : 0.f;
+                for (int i = 0; i < NB; ++i) {
+                    const int n = n0 + (t >> 4) + 16 * i;
+                    bv[i] = (kok && n < p.N) ? p.b[((int64_t)tap * g.Cin + n) * g.Cout + co] : 0.f;
+                }
             }
+        } else if (VB) {
+            const int k = k0 + (BNT == 64 ? (t >> 4) : (t >> 2));
+            const int n = n0 + (BNT == 64 ? (t & 15) : (t & 3)) * 4;
+            ld4(p.b + (int64_t)k * p.N + n, b_lane && k < kend && n < p.N, bv);
         } else {
             const int n = n0 + (t & (BNT - 1));
 #pragma unroll
@@ -217,20 +247,38 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         }
     };
 
-    float av[4], bv[NB];
+    float av[4], bv[NBR];
     if (kbeg < kend) gather(kbeg, av, bv);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();  // the previous step's MFMA reads are done
         if (MODE == GEMM_WGRAD) {
+            if (VA) {
+                *reinterpret_cast<float4*>(&As[t >> 4][(t & 15) * 4]) = make_float4(av[0], av[1], av[2], av[3]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) As[(t >> 6) + 4 * i][t & 63] = av[i];
+                for (int i = 0; i < 4; ++i) As[(t >> 6) + 4 * i][t & 63] = av[i];
+            }
+        } else if (VA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[(t & 3) * 4 + i][t >> 2] = av[i];
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) As[t & 15][(t >> 4) + 16 * i] = av[i];
         }
         if (MODE == GEMM_DGRAD) {
+            if (VB) {
+                if (b_lane) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) Bs[t & 15][(t >> 4) + 16 * i] = bv[i];
+                    for (int i = 0; i < 4; ++i) Bs[(t & 3) * 4 + i][t >> 2] = bv[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) Bs[t & 15][(t >> 4) + 16 * i] = bv[i];
+            }
+        } else if (VB) {
+            if (b_lane)
+                *reinterpret_cast<float4*>(&Bs[BNT == 64 ? (t >> 4) : (t >> 2)][(BNT == 64 ? (t & 15) : (t & 3)) * 4]) =
+                    make_float4(bv[0], bv[1], bv[2], bv[3]);
         } else {
 #pragma unroll
             for (int i = 0; i < NB; ++i) Bs[(t / BNT) + BROWS * i][t & (BNT - 1)] = bv[i];
@@ -316,6 +364,17 @@ bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode) {
 }
 
 static int tile_cols(int ncols) { return ncols <= 16 ? 16 : BN; }
+
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+template <int MODE>
+static void launch_variant(const ConvGemmArgs& p, dim3 grid, int bnt, bool va, bool vb, hipStream_t st) {
+#define SV_GEMM_CASE(B, A_, B_) \
+    if (bnt == B && va == A_ && vb == B_) { hipLaunchKernelGGL((conv_gemm_mfma<MODE, B, A_, B_>), grid, dim3(256), 0, st, p); return; }
+    SV_GEMM_CASE(64, true, true) SV_GEMM_CASE(64, true, false) SV_GEMM_CASE(64, false, true) SV_GEMM_CASE(64, false, false)
+    SV_GEMM_CASE(16, true, true) SV_GEMM_CASE(16, true, false) SV_GEMM_CASE(16, false, true) SV_GEMM_CASE(16, false, false)
+#undef SV_GEMM_CASE
+}
 
 // FWD / DGRAD: a result with few 64 x 64 tiles leaves most of the 256 CUs idle while each workgroup walks a long
 // reduction; cut the reduction so that about 512 workgroups exist, each keeping at least 4 steps.
@@ -406,8 +465,7 @@ int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, 
     }
     const int bnt = tile_cols(p.N);
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, bnt), (unsigned)p.splits);
-    if (bnt == 16) hipLaunchKernelGGL((conv_gemm_mfma<GEMM_FWD, 16>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_gemm_mfma<GEMM_FWD, 64>), grid, dim3(256), 0, st, p);
+    launch_variant<GEMM_FWD>(p, grid, bnt, (g.Cin & 3) == 0 && aligned16(x), (g.Cout & 3) == 0 && aligned16(w), st);
     int rc = check_launch("conv_gemm_mfma<fwd>");
     if (rc || p.splits == 1) return rc;
     return launch_splitk_finish(p, st);
@@ -431,8 +489,7 @@ int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* 
     }
     const int bnt = tile_cols(p.N);
     dim3 grid((unsigned)ceil_div(rows, BM), (unsigned)ceil_div(p.N, bnt), (unsigned)(classes * p.splits));
-    if (bnt == 16) hipLaunchKernelGGL((conv_gemm_mfma<GEMM_DGRAD, 16>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_gemm_mfma<GEMM_DGRAD, 64>), grid, dim3(256), 0, st, p);
+    launch_variant<GEMM_DGRAD>(p, grid, bnt, (g.Cout & 3) == 0 && aligned16(dz), (g.Cout & 3) == 0 && aligned16(w), st);
     int rc = check_launch("conv_gemm_mfma<dgrad>");
     if (rc || p.splits == 1) return rc;
     return launch_splitk_finish(p, st);
@@ -449,8 +506,7 @@ int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* d
     p.k_per_split = (int)(ceil_div(ceil_div(p.K, splits), BK) * BK);
     const int bnt = tile_cols(p.N);
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, bnt), (unsigned)splits);
-    if (bnt == 16) hipLaunchKernelGGL((conv_gemm_mfma<GEMM_WGRAD, 16>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_gemm_mfma<GEMM_WGRAD, 64>), grid, dim3(256), 0, st, p);
+    launch_variant<GEMM_WGRAD>(p, grid, bnt, (g.Cin & 3) == 0 && aligned16(x), (g.Cout & 3) == 0 && aligned16(dz), st);
     return check_launch("conv_gemm_mfma<wgrad>");
 }
 
