@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the generic conv entry points (the implicit-GEMM MFMA kernel) at the geometries of the U-Net and
+context-encoder stacks: microseconds by HIP events, TFLOP/s of the GEMM view and the fraction of the 157.3 TFLOP/s
+f32 matrix peak.
+
+  python tools/gemmbench.py [--batch 64] [--reps 30] [--only NAME]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spectrum_vae_amd import ops  # noqa: E402
+
+PEAK = 157.3e12
+# name: (kind, H, W, Cin, k, stride, padding, Cout)   conv: input (H, W, Cin);  convT: input (H, W, Cin) -> output Cout
+GEOMS = {
+    "unet.enc2": ("conv", 16, 16, 64, 2, 2, "same", 64), "unet.enc3": ("conv", 8, 8, 64, 2, 2, "same", 64),
+    "unet.dec2": ("convT", 4, 4, 128, 2, 2, "same", 64), "unet.dec3": ("convT", 8, 8, 128, 2, 2, "same", 64),
+    "unet.out": ("convT", 16, 16, 128, 2, 2, "same", 3),
+    "ce.enc2": ("conv", 16, 16, 64, 4, 2, "same", 128), "ce.enc3": ("conv", 8, 8, 128, 4, 2, "same", 256),
+    "ce.enc4": ("conv", 4, 4, 256, 4, 2, "same", 512), "ce.bottleneck": ("conv", 4, 4, 128, 4, 1, "valid", 1000),
+    "ce.dec1": ("convT", 1, 1, 1000, 4, 1, "valid", 512), "ce.dec2": ("convT", 4, 4, 512, 4, 2, "same", 256),
+    "ce.dec3": ("convT", 8, 8, 256, 4, 2, "same", 128), "ce.dec4": ("convT", 16, 16, 128, 4, 2, "same", 64),
+    "ce.out": ("convT", 32, 32, 64, 4, 1, "same", 3),
+    "disc.c2": ("conv", 16, 16, 64, 4, 2, "same", 128), "disc.head": ("conv", 4, 4, 256, 4, 1, "valid", 1),
+}
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    n = a.batch
+    dev = "cuda"
+    print(f"{'layer':14s} {'op':6s} {'us':>9s} {'TFLOP/s':>9s} {'of peak':>8s}")
+    for name, (kind, H, W, cin, k, s, pad, cout) in GEOMS.items():
+        if a.only and a.only not in name:
+            continue
+        if kind == "conv":
+            g = ops.conv_geom(n, H, W, cin, k, k, s, s, pad, cout)
+            x = torch.randn(n, H, W, cin, device=dev)
+            w = torch.randn(k, k, cin, cout, device=dev) * 0.05
+            y = torch.empty(n, g.Ho, g.Wo, cout, device=dev)
+            fl = 2.0 * n * g.Ho * g.Wo * k * k * cin * cout
+            sc = {o: ops.conv2d_scratch(g, o) for o in (ops.OP_FWD, ops.OP_DGRAD)}
+            wsf = torch.empty(max(sc[ops.OP_FWD], 16), dtype=torch.uint8, device=dev) if sc[ops.OP_FWD] else None
+            wsd = torch.empty(max(sc[ops.OP_DGRAD], 16), dtype=torch.uint8, device=dev) if sc[ops.OP_DGRAD] else None
+            wsw = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device=dev)
+            dy, dx, dw = torch.randn_like(y), torch.empty_like(x), torch.empty_like(w)
+            runs = [("fwd", lambda: ops.conv2d_fwd(g, x, w, None, y, "lrelu", 0.2, wsf)),
+                    ("dgrad", lambda: ops.conv2d_dgrad(g, dy, w, dx, wsd)),
+                    ("wgrad", lambda: ops.conv2d_wgrad(g, x, dy, dw, False, wsw))]
+        else:
+            g = ops.deconv_geom(n, H, W, cin, k, k, s, s, pad, cout)
+            x = torch.randn(n, H, W, cin, device=dev)
+            w = torch.randn(k, k, cout, cin, device=dev) * 0.05
+            y = torch.empty(n, g.H, g.W, cout, device=dev)
+            fl = 2.0 * n * H * W * k * k * cin * cout
+            sc = {o: ops.conv2d_scratch(g, o) for o in (ops.OP_TRANSPOSE_FWD, ops.OP_TRANSPOSE_DGRAD)}
+            wsf = torch.empty(sc[ops.OP_TRANSPOSE_FWD], dtype=torch.uint8, device=dev) if sc[ops.OP_TRANSPOSE_FWD] else None
+            wsd = torch.empty(sc[ops.OP_TRANSPOSE_DGRAD], dtype=torch.uint8, device=dev) if sc[ops.OP_TRANSPOSE_DGRAD] else None
+            wsw = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device=dev)
+            dy, dx, dw = torch.randn_like(y), torch.empty_like(x), torch.empty_like(w)
+            runs = [("fwd", lambda: ops.conv2d_transpose_fwd(g, x, w, None, y, "relu", 0.0, wsf)),
+                    ("dgrad", lambda: ops.conv2d_transpose_dgrad(g, dy, w, dx, wsd)),
+                    ("wgrad", lambda: ops.conv2d_transpose_wgrad(g, x, dy, dw, False, wsw))]
+        for op, fn in runs:
+            us = timeit(fn, a.reps)
+            print(f"{name:14s} {op:6s} {us:9.1f} {fl / us / 1e6:9.2f} {fl / us * 1e6 / PEAK:8.3f}")
+
+
+if __name__ == "__main__":
+    main()
