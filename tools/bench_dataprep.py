@@ -79,6 +79,15 @@ def main():
     out["reorder_rows"] = {"images_per_s": round(R / t, 1), "us": round(t * 1e6, 1), "GB_per_s": round(nb / t / 1e9, 1),
                            "hbm_frac": round(nb / t / HBM_PEAK, 3)}
 
+    # what the memory system gives a plain streaming kernel on this box: a device-to-device copy of the genotype buffer
+    # (read + write) and a read-only reduction of it
+    cp = torch.empty_like(x)
+    t = timed(lambda: cp.copy_(x), a.reps)
+    out["reference_copy"] = {"GB_per_s": round(2 * x.numel() * 4 / t / 1e9, 1), "us": round(t * 1e6, 1)}
+    del cp
+    t = timed(lambda: x.max(), a.reps)
+    out["reference_read_only_max"] = {"GB_per_s": round(x.numel() * 4 / t / 1e9, 1), "us": round(t * 1e6, 1)}
+
     # the NumPy path on the host cores (one thread: it is a per-region Python loop in the reference too)
     n_cpu = min(a.cpu_regions, R)
     xs = x.reshape(total, H, M)[: int(off[n_cpu])].cpu().numpy()
