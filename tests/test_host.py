@@ -192,6 +192,29 @@ def test_package_dataprep_matches_reference_golden_vectors():
         assert sorted(np.asarray(perm).tolist()) == list(range(32))
 
 
+def test_pack_regions_lays_ragged_regions_back_to_back():
+    """Host packing for the device data-preparation call: offsets, dtypes, and the errors the reference raises."""
+    from spectrum_vae_amd import data
+    g = np.load(GOLD)
+    regions = [(g[f"X_{ci}"], g[f"pos_{ci}"]) for ci in range(int(g["n_cases"]))]
+    x, pos, off, n_haps, n_mut = data.pack_regions(regions)
+    assert (n_haps, n_mut) == (32, 6) and x.dtype == np.float32 and pos.dtype == np.int64 and off.dtype == np.int64
+    sizes = [r[0].shape[0] for r in regions]
+    assert off.tolist() == np.concatenate(([0], np.cumsum(sizes))).tolist()
+    assert x.size == sum(sizes) * 32 * 6 and pos.size == sum(sizes)
+    k = 3
+    assert np.array_equal(x[off[k] * 192:off[k + 1] * 192].reshape(sizes[k], 32, 6), regions[k][0])
+    assert np.array_equal(pos[off[k]:off[k + 1]], regions[k][1])
+    with pytest.raises(ValueError):
+        data.pack_regions([])
+    with pytest.raises(ValueError):
+        data.pack_regions([(np.zeros((5, 32, 6)), np.arange(4))])
+    with pytest.raises(ValueError):
+        data.pack_regions([(np.zeros((0, 32, 6)), np.arange(0))])
+    with pytest.raises(ValueError):
+        data.pack_regions([(np.zeros((5, 32, 6)), np.arange(5)), (np.zeros((5, 16, 6)), np.arange(5))])
+
+
 def test_process_region_rejects_ragged_input():
     from spectrum_vae_amd import data
     with pytest.raises(ValueError):
