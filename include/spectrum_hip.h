@@ -288,11 +288,13 @@ int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out,
  *      (in double) into the scratch and increments the count, so a captured graph replays the schedule with
  *      no host input.  sv_adam_keras_apply then does, per element,
  *        g *= grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= alpha m/(sqrt(v)+eps)
- *      (grad_scale = 1/world_size after a sum all-reduce).  Buffers must be 16-byte aligned. */
+ *      (grad_scale = 1/world_size after a sum all-reduce).  zero_grad != 0 also clears grad once it has been read, so
+ *      the next backward pass of a training loop (which accumulates) needs no separate fill.  Buffers must be 16-byte
+ *      aligned. */
 int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float beta2, int decay_steps,
                           float decay_rate, int staircase, sv_stream_t stream);
-int sv_adam_keras_apply(float* theta, const float* grad, float* m, float* v, int64_t n, const int64_t* step_state,
-                        float beta1, float beta2, float eps, float grad_scale, sv_stream_t stream);
+int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n, const int64_t* step_state,
+                        float beta1, float beta2, float eps, float grad_scale, int zero_grad, sv_stream_t stream);
 
 /* ---- batching helpers for Model.fit / predict (run_model.py:141-146,283-289,300):
  *      dst[i, :] = src[idx[i], :] with rows of row_elems elements; src may be f64 or f32 (src_is_f64), dst is f32:

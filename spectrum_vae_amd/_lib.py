@@ -107,7 +107,7 @@ SIGNATURES = {
     "sv_loss_mae": (_i, [_p, _p, _p, _i, _p, _f, _i64, _p, _i, _p]),
     "sv_loss_bce": (_i, [_p, _f, _i, _p, _i, _p, _f, _i64, _p, _i, _p]),
     "sv_adam_keras_prepare": (_i, [_p, _f, _f, _f, _i, _f, _i, _p]),
-    "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p]),
+    "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),
     "sv_gather_rows": (_i, [_p, _i, _p, _p, _i64, _i64, _p]),
     "sv_mask_input": (_i, [_p, _p, _p, _i64, _p]),
     "sv_fill_f32": (_i, [_p, _f, _i64, _p]),

@@ -100,9 +100,9 @@ __global__ void adam_prepare_k(int64_t* __restrict__ state, float lr0, float bet
     }
 }
 
-__global__ void adam_apply_k(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+__global__ void adam_apply_k(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m,
                              float* __restrict__ v, int64_t n, const int64_t* __restrict__ state, float beta1,
-                             float beta2, float eps, float grad_scale) {
+                             float beta2, float eps, float grad_scale, int zero_grad) {
     const float alpha = reinterpret_cast<const float*>(state + 1)[0];
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -123,6 +123,7 @@ __global__ void adam_apply_k(float* __restrict__ theta, const float* __restrict_
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
         reinterpret_cast<float4*>(theta)[i] = th;
+        if (zero_grad) reinterpret_cast<float4*>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float gg = grad[i] * grad_scale;
@@ -131,6 +132,7 @@ __global__ void adam_apply_k(float* __restrict__ theta, const float* __restrict_
         m[i] = mi;
         v[i] = vi;
         theta[i] -= alpha * mi / (sqrtf(vi) + eps);
+        if (zero_grad) grad[i] = 0.f;
     }
 }
 
@@ -326,14 +328,14 @@ int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float bet
     return check_launch("sv_adam_keras_prepare");
 }
 
-int sv_adam_keras_apply(float* theta, const float* grad, float* m, float* v, int64_t n, const int64_t* step_state,
-                        float beta1, float beta2, float eps, float grad_scale, sv_stream_t stream) {
+int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n, const int64_t* step_state,
+                        float beta1, float beta2, float eps, float grad_scale, int zero_grad, sv_stream_t stream) {
     SV_REQUIRE(theta && grad && m && v && step_state && n > 0, "sv_adam_keras_apply: bad arguments");
     SV_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                    ((uintptr_t)v % 16 == 0),
                "sv_adam_keras_apply: buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adam_apply_k, dim3(ew_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, to_stream(stream), theta,
-                       grad, m, v, n, step_state, beta1, beta2, eps, grad_scale);
+                       grad, m, v, n, step_state, beta1, beta2, eps, grad_scale, zero_grad);
     return check_launch("sv_adam_keras_apply");
 }
 

@@ -70,6 +70,7 @@ class Model(Layer):
         self._pool = BufferPool()
         self._params: Optional[torch.Tensor] = None
         self._grads: Optional[torch.Tensor] = None
+        self._grads_clean = False  # True only right after an optimizer launch that cleared the gradient buffer
         self._state: Optional[torch.Tensor] = None
         self._calls: List[CallCtx] = []
         self._infer_slot = 0
@@ -320,6 +321,7 @@ class Model(Layer):
     def backward_raw(self, dy: torch.Tensor, call: int = -1, need_dx: bool = False):
         """Backward of the ``call``-th remembered training call; parameter gradients accumulate."""
         ctx = self._calls[call]
+        self._grads_clean = False
         net = getattr(ctx, "net", None)
         if net is not None and self.use_net_fused_bwd and not need_dx and ctx.param_grads:
             (arr, bufs, h, w), x = net
@@ -400,7 +402,10 @@ class Model(Layer):
         side stream and joined before returning."""
         side = self._side_stream()
         if side is None:
-            self.zero_grad_raw()
+            if not self._grads_clean:  # the previous step's optimizer launch left the buffer cleared
+                self.zero_grad_raw()
+            self._grads_clean = False
+            self._calls.clear()
             if prepare_opt:
                 self.optimizer.prepare(self._params.device)
         else:
@@ -435,14 +440,15 @@ class Model(Layer):
     def _train_step_body(self, b: dict, same_xy: bool, weight: float):
         if self._reducer is None:
             self._fwd_bwd(b, same_xy, weight, prepare_opt=True)
-            self.optimizer.apply_model(self, 1.0, prepared=True)
+            self.optimizer.apply_model(self, 1.0, prepared=True, zero_grads=True)
             return
         self._fwd_bwd(b, same_xy, weight)
         scale = self._reducer.all_reduce(self._grads)
-        self.optimizer.apply_model(self, scale)
+        self.optimizer.apply_model(self, scale, zero_grads=True)
 
     def zero_grad_raw(self):
         ops.fill(self._grads, 0.0)
+        self._grads_clean = False  # only the optimizer launch of a training step vouches for a cleared buffer
         self._calls.clear()
 
     def train_on_device_batch(self, b: dict, same_xy: bool, weight: float):
@@ -473,7 +479,7 @@ class Model(Layer):
                 with torch.cuda.graph(g_fb):
                     self._fwd_bwd(b, same_xy, weight)
                 with torch.cuda.graph(g_opt):
-                    self.optimizer.apply_model(self, scale)
+                    self.optimizer.apply_model(self, scale, zero_grads=True)
                 g = (g_fb, g_opt)
             self._graphs[key] = g
         if len(g) == 1:

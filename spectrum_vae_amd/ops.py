@@ -343,11 +343,11 @@ def adam_prepare(state, lr0, beta1, beta2, decay_steps, decay_rate, staircase):
                                     int(staircase), _stream()), "sv_adam_keras_prepare")
 
 
-def adam_apply(theta, grad, m, v, state, beta1, beta2, eps, grad_scale=1.0):
+def adam_apply(theta, grad, m, v, state, beta1, beta2, eps, grad_scale=1.0, zero_grad=False):
     if not (theta.numel() == grad.numel() == m.numel() == v.numel()):
         raise ValueError("adam: buffer sizes differ")
     check(lib.sv_adam_keras_apply(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), _ptr(state, torch.int64),
-                                  beta1, beta2, eps, grad_scale, _stream()), "sv_adam_keras_apply")
+                                  beta1, beta2, eps, grad_scale, int(zero_grad), _stream()), "sv_adam_keras_apply")
 
 
 # --------------------------------------------------------------------------- batching helpers

@@ -81,10 +81,14 @@ class Adam:
         self._prepare(device)
 
     # ---- the fused path: one launch over the model's whole flat parameter buffer
-    def apply_model(self, model, grad_scale: float = 1.0, prepared: bool = False):
+    def apply_model(self, model, grad_scale: float = 1.0, prepared: bool = False, zero_grads: bool = False):
+        """``zero_grads``: the launch also clears the model's gradient buffer (training loops whose next backward
+        accumulates into it), which saves the separate fill of the next step."""
         st = self._ensure_state(model._params.device) if prepared else self._prepare(model._params.device)
         m, v = self._slots_for(model)
-        ops.adam_apply(model._params, model._grads, m, v, st, self.beta_1, self.beta_2, self.epsilon, grad_scale)
+        ops.adam_apply(model._params, model._grads, m, v, st, self.beta_1, self.beta_2, self.epsilon, grad_scale,
+                       zero_grads)
+        model._grads_clean = bool(zero_grads)
 
     # ---- keras surface: optimizer.apply_gradients(zip(grads, variables))
     def apply_gradients(self, grads_and_vars: Iterable):

@@ -491,6 +491,15 @@ def test_adam_keras_and_schedule():
     ops.adam_prepare(st, 1e-3, 0.9, 0.999, 0, 1.0, False)
     ops.adam_apply(th1, dev(g1), torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda"), st, 0.9, 0.999, 1e-7)
     close(th1, -1e-3 * g1 / (np.abs(g1) + 1e-7 / np.sqrt(1 - 0.999)), tol=1e-7, what="adam closed form")
+    # zero_grad: same update, and the gradient buffer is cleared by the launch (1003 elements: vector body + scalar tail)
+    gz = dev(rng.standard_normal(n))
+    th_a, th_b = th.clone(), th.clone()
+    m_a, v_a, m_b, v_b = m.clone(), v.clone(), m.clone(), v.clone()
+    ga, gb = gz.clone(), gz.clone()
+    ops.adam_apply(th_a, ga, m_a, v_a, state, 0.9, 0.999, 1e-7, 0.5)
+    ops.adam_apply(th_b, gb, m_b, v_b, state, 0.9, 0.999, 1e-7, 0.5, zero_grad=True)
+    assert torch.equal(th_a, th_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b)
+    assert torch.equal(ga, gz) and not gb.any()
 
 
 def test_reparam_kl():
