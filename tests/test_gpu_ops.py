@@ -570,8 +570,14 @@ def test_convnet_entry_points_reject_what_they_do_not_cover():
 
 
 def test_conv2d_wgrad_batch_matches_per_layer_calls():
-    """Several layers' kernel gradients from one launch equal the per-layer fused backward, bit for bit."""
+    """Several layers' kernel gradients from one launch equal the per-layer fused backward: bit for bit where both
+    split the samples over workgroups alike, to rounding (2e-6 of the largest entry) where the splits differ; the
+    batched call itself is bit-reproducible, with and without the deferred reduction."""
     from spectrum_vae_amd import ops
+
+    def same(a, b):
+        return torch.equal(a, b) or float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
     rng = np.random.default_rng(5)
     specs = [(16, 16, 8, 16, 1, True, "elu"), (4, 4, 32, 16, 2, False, "elu"), (32, 32, 3, 8, 1, True, "relu"),
              (16, 16, 8, 3, 2, False, "tanh")]
@@ -594,13 +600,14 @@ def test_conv2d_wgrad_batch_matches_per_layer_calls():
                          db=torch.zeros_like(db_ref), ws=torch.empty_like(ws)))
     ops.conv2d_wgrad_batch(jobs, reduce=True)
     for j, (dw_ref, db_ref) in zip(jobs, want):
-        assert torch.equal(j["dw"], dw_ref) and torch.equal(j["db"], db_ref)
+        assert same(j["dw"], dw_ref) and same(j["db"], db_ref)
+    first = [(j["dw"].clone(), j["db"].clone()) for j in jobs]
     for j in jobs:
         j["dw"].zero_(), j["db"].zero_()
     ops.conv2d_wgrad_batch(jobs, reduce=False)
     ops.conv2d_wgrad_finish([(j["g"], j["ws"], j["dw"], j["db"]) for j in jobs])
-    for j, (dw_ref, db_ref) in zip(jobs, want):
-        assert torch.equal(j["dw"], dw_ref) and torch.equal(j["db"], db_ref)
+    for j, (dw1, db1) in zip(jobs, first):
+        assert torch.equal(j["dw"], dw1) and torch.equal(j["db"], db1)
     # fewer, longer-lived workgroups per layer: another summation order, same sums to rounding
     for j in jobs:
         j["dw"].zero_(), j["db"].zero_()
