@@ -149,21 +149,47 @@ class _StepState:
         self.l2, self.lt, self.lf, self.disc_loss, self.total = f(1), f(1), f(1), f(1), f(1)
         self.graph = None
         self.warm = False
+        self.side = torch.cuda.Stream(device=device)  # the context-encoder update runs beside the discriminator's
 
 
 _STEP_CACHE: Dict[tuple, _StepState] = {}
 
 
-def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float):
+def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, overlap: bool = False):
+    """``overlap``: once ``pred`` and the reconstruction gradient exist, the context-encoder backward + update and the
+    discriminator forward / backward / update touch disjoint buffers (each model owns its buffer pool, workspace and
+    optimizer state), so the former is forked onto a second stream; at batch 64 neither fills the chip on its own."""
     mse, bce = MeanSquaredError(), BinaryCrossentropy(from_logits=False)
     ce.zero_grad_raw()
     disc.zero_grad_raw()
+    main = torch.cuda.current_stream()
+    p_real, real_done = None, None
+    if overlap:  # D(real) needs nothing from the context encoder: it runs beside the encoder's forward pass
+        start = torch.cuda.Event()
+        start.record(main)
+        with torch.cuda.stream(st.side):
+            st.side.wait_event(start)
+            p_real = disc.forward_raw(st.X, True)
+            real_done = torch.cuda.Event()
+            real_done.record(st.side)
     ops.mask_input(st.X, st.mask, st.Xm)  # X * (1 - mask)
     pred = ce.forward_raw(st.Xm, True)
     # l2 = MSE(X, pred, sample_weight = mask[..., 0] * 10): channel 0 of the NHWC mask is read with stride C
     mse.value_and_grad(st.X, pred, st.l2, st.dpred, 1.0, sample_weight=st.mask, weight_scale=10.0,
                        weight_stride=st.mask.shape[-1])
-    p_real = disc.forward_raw(st.X, True)
+    joined = None
+    if overlap:
+        main.wait_event(real_done)  # D(fake) follows D(real): BatchNorm's moving statistics are updated in that order
+        forked = torch.cuda.Event()
+        forked.record(main)
+        with torch.cuda.stream(st.side):
+            st.side.wait_event(forked)
+            ce.backward_raw(st.dpred, 0, need_dx=False)
+            ce_opt.apply_model(ce, 1.0)
+            joined = torch.cuda.Event()
+            joined.record(st.side)
+    else:
+        p_real = disc.forward_raw(st.X, True)
     p_fake = disc.forward_raw(pred, True)
     bce.value_and_grad(1.0, p_real, st.lt, st.d_real, 0.5)
     bce.value_and_grad(0.0, p_fake, st.lf, st.d_fake, 0.5)
@@ -179,9 +205,12 @@ def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float):
     s = disc._reducer.all_reduce(disc._grads) if disc._reducer is not None else 1.0
     disc_opt.apply_model(disc, s)
     # context-encoder update: gradient of the masked reconstruction loss only
-    ce.backward_raw(st.dpred, 0, need_dx=False)
-    s = ce._reducer.all_reduce(ce._grads) if ce._reducer is not None else 1.0
-    ce_opt.apply_model(ce, s)
+    if joined is not None:
+        main.wait_event(joined)
+    else:
+        ce.backward_raw(st.dpred, 0, need_dx=False)
+        s = ce._reducer.all_reduce(ce._grads) if ce._reducer is not None else 1.0
+        ce_opt.apply_model(ce, s)
     ce._calls.clear()
     disc._calls.clear()
 
@@ -214,7 +243,7 @@ def train_step(context_encoder, discriminator, ce_opt, disc_opt, X, mask, l2_wei
             torch.cuda.synchronize()
             st.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st.graph):
-                _step_body(ce, disc, ce_opt, disc_opt, st, l2_weight)
+                _step_body(ce, disc, ce_opt, disc_opt, st, l2_weight, overlap=True)
         st.graph.replay()
     return (as_dtensor(st.disc_loss.view(()).clone()), as_dtensor(st.l2.view(()).clone()),
             as_dtensor(st.total.view(()).clone()))

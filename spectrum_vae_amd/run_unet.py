@@ -75,22 +75,40 @@ class _StepState:
         self.disc_loss, self.gen_total = f(1), f(1)
         self.graph = None
         self.warm = False
+        self.side = torch.cuda.Stream(device=device)  # the generator update runs beside the discriminator's
 
 
 _STEP_CACHE: Dict[tuple, _StepState] = {}
 
 
-def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: float):
+def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: float, overlap: bool = False):
+    """``overlap``: once the GAN term's gradient has come back through the discriminator, the generator backward +
+    update and the discriminator backward + update touch disjoint buffers (each model owns its buffer pool, workspace
+    and optimizer state), so the former is forked onto a second stream; at batch 32 neither fills the chip alone."""
     bce, mae = BinaryCrossentropy(from_logits=True), MeanAbsoluteError()
     n, h, w, cx = st.X.shape
     cy = st.y.shape[-1]
     rows = n * h * w
     gen.zero_grad_raw()
     disc.zero_grad_raw()
+    main0 = torch.cuda.current_stream()
+    z_real = None
+    if overlap:  # D([X, y]) needs nothing from the generator: it runs beside the generator's forward pass
+        start = torch.cuda.Event()
+        start.record(main0)
+        with torch.cuda.stream(st.side):
+            st.side.wait_event(start)
+            ops.concat_channels_fwd(st.X, st.y, st.cat_real, rows, cx, cy)
+            z_real = disc.forward_raw(st.cat_real, True)   # call 0
+            real_done = torch.cuda.Event()
+            real_done.record(st.side)
     gen_out = gen.forward_raw(st.X, True)
-    ops.concat_channels_fwd(st.X, st.y, st.cat_real, rows, cx, cy)
+    if overlap:
+        main0.wait_event(real_done)  # D(fake) follows D(real): BatchNorm's moving statistics are updated in that order
+    else:
+        ops.concat_channels_fwd(st.X, st.y, st.cat_real, rows, cx, cy)
+        z_real = disc.forward_raw(st.cat_real, True)   # call 0
     ops.concat_channels_fwd(st.X, gen_out, st.cat_fake, rows, cx, cy)
-    z_real = disc.forward_raw(st.cat_real, True)   # call 0
     z_fake = disc.forward_raw(st.cat_fake, True)   # call 1
     # generator loss: BCE(1, D(fake)) + lambda * MAE(y, gen_out)
     bce.value_and_grad(1.0, z_fake, st.l_gan, st.d_gan, 1.0)
@@ -111,16 +129,31 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
     d_cat = disc.backward(ctx_fake, st.d_gan, need_dx=True)
     ops.concat_channels_bwd(d_cat, st.dX_unused, st.dgen_gan, rows, cx, cy)
     ctx_fake.param_grads = True
+
+    def generator_update():  # (3) dL/dgen = lambda * dMAE + dGAN
+        ops.axpy(st.dgen, st.dgen_gan, 1.0)
+        gen.backward_raw(st.dgen, 0, need_dx=False)
+        s = gen._reducer.all_reduce(gen._grads) if gen._reducer is not None else 1.0
+        gen_opt.apply_model(gen, s)
+
+    main, joined = torch.cuda.current_stream(), None
+    if overlap:
+        forked = torch.cuda.Event()
+        forked.record(main)
+        with torch.cuda.stream(st.side):
+            st.side.wait_event(forked)
+            generator_update()
+            joined = torch.cuda.Event()
+            joined.record(st.side)
     # (2) discriminator update
     disc.backward_raw(st.d_real, 0, need_dx=False)
     disc.backward_raw(st.d_fake, 1, need_dx=False)
     s = disc._reducer.all_reduce(disc._grads) if disc._reducer is not None else 1.0
     disc_opt.apply_model(disc, s)
-    # (3) generator update with dL/dgen = lambda * dMAE + dGAN
-    ops.axpy(st.dgen, st.dgen_gan, 1.0)
-    gen.backward_raw(st.dgen, 0, need_dx=False)
-    s = gen._reducer.all_reduce(gen._grads) if gen._reducer is not None else 1.0
-    gen_opt.apply_model(gen, s)
+    if joined is not None:
+        main.wait_event(joined)
+    else:
+        generator_update()
     gen._calls.clear()
     disc._calls.clear()
 
@@ -151,7 +184,7 @@ def train_step(generator, discriminator, ce_opt, disc_opt, X, y, lambda_weight: 
             torch.cuda.synchronize()
             st.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st.graph):
-                _step_body(gen, disc, ce_opt, disc_opt, st, lambda_weight)
+                _step_body(gen, disc, ce_opt, disc_opt, st, lambda_weight, overlap=True)
         st.graph.replay()
     c = lambda t: as_dtensor(t.view(()).clone())  # noqa: E731
     return c(st.disc_loss), c(st.gen_total), c(st.l_gan), c(st.l_l1)

@@ -487,3 +487,43 @@ def test_whole_network_backward_matches_per_layer_path(n):
         grads[fused] = model._grads.cpu().numpy().copy()
     scale = np.abs(grads[False]).max()
     assert np.abs(grads[True] - grads[False]).max() <= 2e-5 * scale
+
+
+def test_gan_steps_replayed_with_overlapped_updates_equal_the_serial_steps():
+    """The captured steps fork the generator-side work onto a second stream (disjoint buffers); replaying them must
+    give, bit for bit, the losses and weights of the same steps issued serially without a graph."""
+    from spectrum_vae_amd import context_encoder, run_context_encoder, run_unet, unet
+    full = data(48)
+    rng = np.random.default_rng(3)
+    mask = run_context_encoder.batch_random_mask(full, 0.25, rng).astype(np.float32)
+
+    def run_ce(use_graph):
+        ce, disc = context_encoder.ContextEncoder(), context_encoder.Discriminator()
+        ce.build((None, 32, 32, 3)); disc.build((None, 32, 32, 3))
+        ce._materialize(); disc._materialize()
+        o1, o2 = run_context_encoder.build_optimizer(2e-3), run_context_encoder.build_optimizer(2e-4)
+        out = []
+        for step in range(5):
+            sl = slice((step % 3) * 16, (step % 3 + 1) * 16)
+            out.append([float(v) for v in run_context_encoder.train_step(ce, disc, o1, o2, full[sl], mask[sl],
+                                                                         use_graph=use_graph)])
+        return out, [v.numpy() for v in ce.trainable_variables + disc.trainable_variables + disc.non_trainable_variables]
+
+    def run_unet_gan(use_graph):
+        gen, disc = unet.Generator(), unet.Discriminator()
+        gen.build((None, 32, 32, 1)); disc.build((None, 32, 32, 4))
+        gen._materialize(); disc._materialize()
+        o1, o2 = run_unet.build_optimizer(2e-4), run_unet.build_optimizer(2e-4)
+        X = full[..., :1].copy()
+        out = []
+        for step in range(5):
+            sl = slice((step % 3) * 16, (step % 3 + 1) * 16)
+            out.append([float(v) for v in run_unet.train_step(gen, disc, o1, o2, X[sl], full[sl], use_graph=use_graph)])
+        return out, [v.numpy() for v in gen.trainable_variables + disc.trainable_variables + disc.non_trainable_variables]
+
+    for run in (run_ce, run_unet_gan):
+        losses_g, weights_g = run(True)
+        losses_s, weights_s = run(False)
+        assert losses_g == losses_s, run.__name__
+        for a, b in zip(weights_g, weights_s):
+            assert np.array_equal(a, b), run.__name__
