@@ -1144,10 +1144,23 @@ int launch_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, h
     m.n_jobs = rm.n_jobs = n_jobs;
     int blocks = 0, rblocks = 0;
     size_t lds = 0;
-    for (int j = 0; j < n_jobs; ++j) {
-        const sv_wgrad_batch_job& q = jobs[j];
+    // Workgroups are dispatched in block order and a layer's workgroups live longer the larger its images are (staging
+    // dominates), so the layers go into the table longest first: the launch then ends on short workgroups instead of
+    // waiting for a last round of long ones.
+    int ord[kMaxWgradJobs];
+    for (int j = 0; j < n_jobs; ++j) ord[j] = j;
+    for (int a = 1; a < n_jobs; ++a)
+        for (int b = a; b > 0; --b) {
+            const sv_conv_geom &ga = jobs[ord[b]].g, &gb = jobs[ord[b - 1]].g;
+            const int64_t ka = (int64_t)ga.H * ga.W * 64 + ga.Cin + ga.Cout, kb = (int64_t)gb.H * gb.W * 64 + gb.Cin + gb.Cout;
+            if (ka <= kb) break;
+            const int t = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = t;
+        }
+    for (int jj = 0; jj < n_jobs; ++jj) {
+        const int j = jj;  // table slot
+        const sv_wgrad_batch_job& q = jobs[ord[jj]];
         const sv_conv_geom& g = q.g;
-        if (g.KH != 3) return fail(SV_E_UNSUPPORTED, "conv2d_wgrad_batch: job %d: 3x3 kernels only", j);
+        if (g.KH != 3) return fail(SV_E_UNSUPPORTED, "conv2d_wgrad_batch: job %d: 3x3 kernels only", ord[jj]);
         const int Hs = g.H / g.up_h, Ws = g.W / g.up_w;
         WgradPlan p = plan_wgrad(g.N, Hs, Ws, g.Cin, g.Cout, g.KH, g.up_h, q.blocks);
         if (!p.ok) return fail(SV_E_UNSUPPORTED, "conv2d_wgrad_batch: job %d is outside the tiled family", j);
