@@ -10,6 +10,8 @@
 //       in registers, results written to the output arena in the next layer's input layout,
 //   [E] copies the output arena to global memory as NHWC with full-width stores (the backward pass reads it).
 // One launch replaces one launch per layer, and no layer waits for a global-memory round trip of its input.
+#include <cstdlib>
+
 #include "tile_common.h"
 
 namespace sv {
@@ -41,6 +43,7 @@ struct NetLayer {
     int in_plane, in_wp, in_halo;      // planar layout of the input
     int out_plane, out_wp, out_halo;   // planar layout of the output (= the next layer's input layout)
     int co_t, n_cot, ks;
+    int mfma;        // 0: vector path; 1..3: the matrix-core variant compiled for this layer shape (net_layer_fwd_mfma)
     float* y;        // global output [N][Hout][Wout][Cout] (pooled extent when pool)
     uint8_t* idx;    // global argmax slots (pool only, may be null)
 };
@@ -231,6 +234,126 @@ __device__ __forceinline__ void net_layer_fwd(const NetFwdArgs& a, const NetLaye
     }
 }
 
+// ---- one layer on the matrix cores, LDS -> LDS (3x3; CIN in {8, 16, 32} input channels, 16 * NT output channels; conv
+// extent 8 or 16 pixels wide).  y[px][co] = sum_{tap, ci} x[px + tap][ci] * w[tap][ci][co] as v_mfma_f32_16x16x4_f32
+// tiles: 16 pixels x 16 output channels, 4 input channels of one tap per instruction.  Lane l supplies
+// A[pixel l % 16][channel l / 16] from the planar input arena and B[channel l / 16][co l % 16] from the filter arena
+// (the vector path's [co / 8][ci][tap][8] layout), so both are 4-byte LDS reads at a per-lane base plus constants.
+// A wave owns units of 32 pixels (two tiles: 4 rows x 8 or 2 rows x 16), which contain whole 2 x 2 pooling windows.
+typedef float nf_v4f __attribute__((ext_vector_type(4)));
+
+template <int CIN, int NT, int UP, int POOL>
+__device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const NetLayer& L, float* smem, int ns, int nt) {
+    constexpr int K = 3, KK = 9, CO8 = 8;
+    const int Ho = L.Hs * UP, Wo = L.Ws * UP;
+    const bool wide = Wo == 16;  // else Wo == 8
+    const int units_ps = (Ho * Wo) >> 5;
+    const int n_units = ns * units_ps;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const float* in = smem + L.in_off;
+    float* out = smem + L.out_off;
+    const float* w_lds = smem + a.w_off;
+    const int cop = L.n_cot * CO8;
+    const float* b_lds = w_lds + KK * CIN * cop;
+    uint8_t* idx_lds = reinterpret_cast<uint8_t*>(smem + a.idx_off);
+    const int oh = L.out_halo, ih = L.in_halo;
+    int boff[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + li;
+        boff[n] = ((co >> 3) * CIN + lk) * (KK * CO8) + (co & 7);
+    }
+    const FDiv f_ups = fd_make(units_ps);
+    const int T = (Ho >> 1) * (Wo >> 1), tiles_x = Wo >> 1;
+    for (int u = wave; u < n_units; u += nw) {
+        const int s = fd(u, f_ups), uu = u - s * units_ps;
+        // pixel (row, col) of A row li in the two tiles of the unit
+        int pr[2], pc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            pr[t] = wide ? 2 * uu + t : 4 * uu + 2 * t + (li >> 3);
+            pc[t] = wide ? li : (li & 7);
+        }
+        nf_v4f acc[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = nf_v4f{0.f, 0.f, 0.f, 0.f};
+        const float* ins = in + ((size_t)s * CIN + lk) * L.in_plane;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int dr = tap / K - 1, dc = tap % K - 1;
+            int ao[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int sr = UP == 1 ? pr[t] + dr : ((pr[t] + dr) >> 1);  // arithmetic shift: -1 stays -1 (the halo)
+                const int sc = UP == 1 ? pc[t] + dc : ((pc[t] + dc) >> 1);
+                ao[t] = (sr + ih) * L.in_wp + sc + ih;
+            }
+#pragma unroll
+            for (int cg = 0; cg < CIN / 4; ++cg) {
+                float av[2], bv[NT];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) av[t] = ins[cg * 4 * L.in_plane + ao[t]];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bv[n] = w_lds[boff[n] + cg * 4 * (KK * CO8) + tap * CO8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[n], acc[t][n], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: lane holds, per tile and channel co = 16 n + li, the pixels 4 lk .. 4 lk + 3 of the tile
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + li;
+            const float b = b_lds[co];
+            float* oc = out + (size_t)(s * L.Cout + co) * L.out_plane;
+            if (POOL == 0) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int p = 4 * lk + j;
+                        const int row = wide ? 2 * uu + t : 4 * uu + 2 * t + (p >> 3);
+                        const int col = wide ? p : (p & 7);
+                        oc[(row + oh) * L.out_wp + col + oh] = act_apply(acc[t][n][j] + b, L.act, L.alpha);
+                    }
+            } else {
+                // windows: slot 0 (r, c), 1 (r, c + 1), 2 (r + 1, c), 3 (r + 1, c + 1); first maximum wins
+                auto emit = [&](float v0, float v1, float v2, float v3, int ty, int tx) {
+                    float best = v0;
+                    uint32_t bi = 0;
+                    if (v1 > best) { best = v1; bi = 1; }
+                    if (v2 > best) { best = v2; bi = 2; }
+                    if (v3 > best) { best = v3; bi = 3; }
+                    const float v = act_apply(best + b, L.act, L.alpha);
+                    if (L.act == SV_ACT_RELU && v <= 0.f) bi = 0;
+                    oc[(ty + oh) * L.out_wp + tx + oh] = v;
+                    idx_lds[((size_t)s * T + ty * tiles_x + tx) * L.Cout + co] = (uint8_t)bi;
+                };
+                if (wide) {  // tile 0 = row 2 uu, tile 1 = row 2 uu + 1; this lane's columns 4 lk .. 4 lk + 3
+                    emit(acc[0][n][0], acc[0][n][1], acc[1][n][0], acc[1][n][1], uu, 2 * lk);
+                    emit(acc[0][n][2], acc[0][n][3], acc[1][n][2], acc[1][n][3], uu, 2 * lk + 1);
+                } else {     // a tile = rows (r, r + 1) x 8 columns: lanes lk < 2 hold row r, lanes lk >= 2 row r + 1
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(acc[t][n][j], 32, 64);
+                        if (lk < 2) {
+                            emit(acc[t][n][0], acc[t][n][1], o[0], o[1], 2 * uu + t, 2 * lk);
+                            emit(acc[t][n][2], acc[t][n][3], o[2], o[3], 2 * uu + t, 2 * lk + 1);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // output arena (planar) -> global NHWC, argmax bytes -> global
 __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer& L, const float* smem, int n0, int ns,
                                              int nt) {
@@ -310,7 +433,10 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
             // [B]
             if (l + 1 < a.n_layers) net_w_load<K>(a, a.L[l + 1], wpre, bpre, nt);
             // [C]
-            if (L.up == 1) {
+            if (L.mfma == 1) net_layer_fwd_mfma<8, 1, 1, 1>(a, L, smem, ns, nt);
+            else if (L.mfma == 2) net_layer_fwd_mfma<16, 2, 1, 1>(a, L, smem, ns, nt);
+            else if (L.mfma == 3) net_layer_fwd_mfma<32, 1, 2, 0>(a, L, smem, ns, nt);
+            else if (L.up == 1) {
                 if (L.co_t == 8) {
                     if (L.pool) net_layer_fwd<K, 1, 8, 1>(a, L, smem, ns, nt);
                     else net_layer_fwd<K, 1, 8, 0>(a, L, smem, ns, nt);
@@ -382,6 +508,14 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
         int ks = 1;
         while (ks < 8 && s.Cin / (2 * ks) >= 2 && (int64_t)L.n_cot * S * T * ks < nt) ks <<= 1;
         L.ks = ks;
+        // matrix-core variants exist for the shapes whose 16-wide tiles are full: (Cin, Cout, up, pool)
+        L.mfma = 0;
+        if ((Wo == 8 || Wo == 16) && (Ho * Wo) % 32 == 0 && (nt & 63) == 0 && l + 1 < n_layers &&
+            std::getenv("SPECTRUM_NETFWD_VALU") == nullptr) {
+            if (s.Cin == 8 && s.Cout == 16 && s.up == 1 && s.pool) L.mfma = 1;
+            else if (s.Cin == 16 && s.Cout == 32 && s.up == 1 && s.pool) L.mfma = 2;
+            else if (s.Cin == 32 && s.Cout == 16 && s.up == 2 && !s.pool) L.mfma = 3;
+        }
         const size_t wf = (size_t)9 * s.Cin * L.n_cot * L.co_t + L.n_cot * L.co_t;
         if (wf > w_floats) w_floats = wf;
         if (s.pool) {
