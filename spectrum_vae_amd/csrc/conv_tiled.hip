@@ -64,6 +64,7 @@ struct TiledArgs {
     int ks;        // input channels of one output tile are split over ks adjacent lanes (1, 2 or 4) and summed by shuffles
     int epi_lds;   // 1: outputs leave through an LDS tile [sample][pixel][out_cs] as coalesced stores
     int out_cs;    // floats per pixel of that tile
+    int mfma;      // 0: vector path; 1..3: the matrix-core variant compiled for this shape (conv_s1_mfma_pass)
 };
 
 // ---- filter chunk -> w_lds[tap][c][cop] (cop = channel tiles * CO_T; padded channels stay zero from the LDS fill)
@@ -152,6 +153,127 @@ __device__ __forceinline__ void w_pass(const TiledArgs& a, const WJob& j, float*
     }
 }
 
+// ---- one pass on the matrix cores (3x3, no upsampling, CIN in {8, 16, 32} staged channels, 16 * NT output channels,
+// images 8 or 16 pixels wide, the block owns all channels and makes a single pass).  y[px][co] = sum_{tap, ci}
+// x[px + tap][ci] * w[tap][ci][co] as v_mfma_f32_16x16x4_f32 tiles: lane l supplies A[pixel l % 16][channel l / 16]
+// from the planar staged image and B[channel l / 16][co l % 16] from the filter chunk ([co / 8][ci][tap][8]).  A wave
+// owns units of 32 pixels (4 rows x 8 or 2 rows x 16: whole 2 x 2 windows); results wait in registers until every wave
+// is done with the staging buffers, then go to the LDS output tile [sample][pixel][out_cs] the stores read.
+typedef float ct_v4f __attribute__((ext_vector_type(4)));
+
+template <int CIN, int NT, int EPI>
+__device__ __forceinline__ void conv_s1_mfma_pass(const TiledArgs& a, float* smem, int n0, int ns, int nt) {
+    constexpr int K = 3, KK = 9, CO8 = 8;
+    const float* in_lds = smem;
+    const float* w_lds = smem + (size_t)a.S * a.cic * a.plane;
+    const bool wide = a.Wo == 16;
+    const int units_ps = (a.Ho * a.Wo) >> 5;
+    const int nw = nt >> 6;
+    const int upw = (a.S * units_ps + nw - 1) / nw;  // units per wave (compile-time bound below)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int T = (a.Ho >> 1) * (a.Wo >> 1), tiles_x = a.Wo >> 1;
+    const int P = EPI == EPI_STORE ? a.Ho * a.Wo : T;
+    const int cs = a.out_cs;
+    int boff[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + li;
+        boff[n] = ((co >> 3) * a.cic + lk) * (KK * CO8) + (co & 7);
+    }
+    constexpr int MAXU = 4;  // the planner admits at most this many units per wave
+    ct_v4f acc[MAXU][2][NT];
+    const FDiv f_ups = fd_make(units_ps);
+#pragma unroll
+    for (int k = 0; k < MAXU; ++k) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[k][t][n] = ct_v4f{0.f, 0.f, 0.f, 0.f};
+        const int u = wave + k * nw;
+        if (k >= upw || u >= ns * units_ps) continue;  // uniform over the wave
+        const int s = fd(u, f_ups), uu = u - s * units_ps;
+        int pr[2], pc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            pr[t] = wide ? 2 * uu + t : 4 * uu + 2 * t + (li >> 3);
+            pc[t] = wide ? li : (li & 7);
+        }
+        const float* ins = in_lds + ((size_t)s * a.cic + lk) * a.plane;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int dr = tap / K - 1, dc = tap % K - 1;
+            int ao[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) ao[t] = (pr[t] + dr + a.halo) * a.wp + pc[t] + dc + a.halo;
+#pragma unroll
+            for (int cg = 0; cg < CIN / 4; ++cg) {
+                float av[2], bv[NT];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) av[t] = ins[cg * 4 * a.plane + ao[t]];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bv[n] = w_lds[boff[n] + cg * 4 * (KK * CO8) + tap * CO8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[k][t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[n], acc[k][t][n], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // every wave is done reading the staged image and filters: the output tile may overwrite them
+#pragma unroll
+    for (int k = 0; k < MAXU; ++k) {
+        const int u = wave + k * nw;
+        if (k >= upw || u >= ns * units_ps) continue;
+        const int s = fd(u, f_ups), uu = u - s * units_ps;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + li;
+            // lane holds, per tile, the pixels 4 lk .. 4 lk + 3 of channel co
+            if (EPI == EPI_STORE) {
+                const float b = a.bias != nullptr ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int p = 4 * lk + j;
+                        const int row = wide ? 2 * uu + t : 4 * uu + 2 * t + (p >> 3);
+                        const int col = wide ? p : (p & 7);
+                        smem[((size_t)s * P + row * a.Wo + col) * cs + co] = act_apply(acc[k][t][n][j] + b, a.act, a.alpha);
+                    }
+            } else {  // EPI_SUM4: (v00 + v01) + (v10 + v11) per 2 x 2 window
+                if (wide) {
+                    smem[((size_t)s * P + uu * tiles_x + 2 * lk) * cs + co] =
+                        (acc[k][0][n][0] + acc[k][0][n][1]) + (acc[k][1][n][0] + acc[k][1][n][1]);
+                    smem[((size_t)s * P + uu * tiles_x + 2 * lk + 1) * cs + co] =
+                        (acc[k][0][n][2] + acc[k][0][n][3]) + (acc[k][1][n][2] + acc[k][1][n][3]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(acc[k][t][n][j], 32, 64);
+                        if (lk < 2) {
+                            float* q = smem + ((size_t)s * P + (2 * uu + t) * tiles_x + 2 * lk) * cs + co;
+                            q[0] = (acc[k][t][n][0] + acc[k][t][n][1]) + (o[0] + o[1]);
+                            q[cs] = (acc[k][t][n][2] + acc[k][t][n][3]) + (o[2] + o[3]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int c4n = a.Cout >> 2;
+    const FDiv f4 = fd_make(c4n);
+    for (int u = threadIdx.x; u < ns * P * c4n; u += nt) {
+        const int r = fd(u, f4), c4 = u - r * c4n;
+        *reinterpret_cast<float4*>(a.y + ((size_t)n0 * P + r) * a.Cout + 4 * c4) =
+            *reinterpret_cast<const float4*>(smem + (size_t)r * cs + 4 * c4);
+    }
+}
+
 template <int K, int UP, int CO_T, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
     constexpr int PADL = (K - 1) / 2;
@@ -194,6 +316,21 @@ __global__ __launch_bounds__(256, 2) void conv_s1_lds(TiledArgs a) {
     }
     bool prestaged = true;
 
+    if constexpr (K == 3 && UP == 1 && CO_T == 8 && (EPI == EPI_STORE || EPI == EPI_SUM4)) {
+        if (a.mfma) {  // single pass, all channels (the planner's conditions)
+            __syncthreads();
+            SV_MARK(2);
+            const int ns = min(a.S, a.N - n0);
+            if (EPI == EPI_SUM4) {
+                if (a.mfma == 1) conv_s1_mfma_pass<8, 1, EPI_SUM4>(a, smem, n0, ns, nt);
+                else conv_s1_mfma_pass<16, 2, EPI_SUM4>(a, smem, n0, ns, nt);
+            } else {
+                conv_s1_mfma_pass<32, 1, EPI_STORE>(a, smem, n0, ns, nt);
+            }
+            SV_MARK(5);
+            return;
+        }
+    }
     for (; n0 < a.N; n0 += gridDim.x * a.S) {
         const int ns = min(a.S, a.N - n0);
         // A thread owns one work item per pass of nt; its accumulators live across the ci-chunk loop.  When a
@@ -504,6 +641,16 @@ int launch_tiled_s1(const float* x, const float* w, const float* bias, float* y,
                             (int64_t)p.grid.x * p.S >= N;
         a.epi_lds = single && out_bytes <= kLdsBudget;
         a.out_cs = cs;
+        // matrix-core variants: shapes whose 16-wide tiles are full, one pass, all channels in the block, at most 4
+        // 32-pixel units per wave
+        a.mfma = 0;
+        if (K == 3 && UP == 1 && a.epi_lds && p.grid.y == 1 && p.coc == Cout && (a.Wo == 8 || a.Wo == 16) &&
+            (a.Ho * a.Wo) % 32 == 0 && (p.nt & 63) == 0 && (a.bias == nullptr || epi == EPI_STORE) &&
+            (int64_t)p.S * ((a.Ho * a.Wo) >> 5) <= 4 * (p.nt >> 6) && std::getenv("SPECTRUM_DGRAD_VALU") == nullptr) {
+            if (epi == EPI_SUM4 && Cin == 8 && Cout == 16) a.mfma = 1;
+            else if (epi == EPI_SUM4 && Cin == 16 && Cout == 32) a.mfma = 2;
+            else if (epi == EPI_STORE && Cin == 32 && Cout == 16) a.mfma = 3;
+        }
         if (a.epi_lds && out_bytes > p.lds_bytes) p.lds_bytes = out_bytes;
         p.lds_bytes = (p.lds_bytes + 15) & ~(size_t)15;
     }
