@@ -200,25 +200,35 @@ __device__ __forceinline__ void conv_s1_mfma_pass(const TiledArgs& a, float* sme
             pc[t] = wide ? li : (li & 7);
         }
         const float* ins = in_lds + ((size_t)s * a.cic + lk) * a.plane;
-#pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
+        // operands of a whole tap are read into registers one tap ahead of the MFMAs that use them
+        constexpr int CG = CIN / 4;
+        float av[2][CG][2], bv[2][CG][NT];
+        auto load_tap = [&](int tap, float (&a_)[CG][2], float (&b_)[CG][NT]) {
             const int dr = tap / K - 1, dc = tap % K - 1;
             int ao[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) ao[t] = (pr[t] + dr + a.halo) * a.wp + pc[t] + dc + a.halo;
 #pragma unroll
-            for (int cg = 0; cg < CIN / 4; ++cg) {
-                float av[2], bv[NT];
+            for (int cg = 0; cg < CG; ++cg) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) av[t] = ins[cg * 4 * a.plane + ao[t]];
+                for (int t = 0; t < 2; ++t) a_[cg][t] = ins[cg * 4 * a.plane + ao[t]];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bv[n] = w_lds[boff[n] + cg * 4 * (KK * CO8) + tap * CO8];
+                for (int n = 0; n < NT; ++n) b_[cg][n] = w_lds[boff[n] + cg * 4 * (KK * CO8) + tap * CO8];
+            }
+        };
+        load_tap(0, av[0], bv[0]);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            if (tap + 1 < KK) load_tap(tap + 1, av[(tap + 1) & 1], bv[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[k][t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[n], acc[k][t][n], 0, 0, 0);
-            }
+                        acc[k][t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap & 1][cg][t], bv[tap & 1][cg][n], acc[k][t][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();  // every wave is done reading the staged image and filters: the output tile may overwrite them

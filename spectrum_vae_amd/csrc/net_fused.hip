@@ -281,8 +281,11 @@ __device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const Ne
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = nf_v4f{0.f, 0.f, 0.f, 0.f};
         const float* ins = in + ((size_t)s * CIN + lk) * L.in_plane;
-#pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
+        // operands of a whole tap (all channel groups) are read into registers one tap ahead of the MFMAs that use them,
+        // so the matrix pipe never waits on an LDS round trip issued just before it
+        constexpr int CG = CIN / 4;
+        float av[2][CG][2], bv[2][CG][NT];
+        auto load_tap = [&](int tap, float (&a_)[CG][2], float (&b_)[CG][NT]) {
             const int dr = tap / K - 1, dc = tap % K - 1;
             int ao[2];
 #pragma unroll
@@ -292,18 +295,26 @@ __device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const Ne
                 ao[t] = (sr + ih) * L.in_wp + sc + ih;
             }
 #pragma unroll
-            for (int cg = 0; cg < CIN / 4; ++cg) {
-                float av[2], bv[NT];
+            for (int cg = 0; cg < CG; ++cg) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) av[t] = ins[cg * 4 * L.in_plane + ao[t]];
+                for (int t = 0; t < 2; ++t) a_[cg][t] = ins[cg * 4 * L.in_plane + ao[t]];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bv[n] = w_lds[boff[n] + cg * 4 * (KK * CO8) + tap * CO8];
+                for (int n = 0; n < NT; ++n) b_[cg][n] = w_lds[boff[n] + cg * 4 * (KK * CO8) + tap * CO8];
+            }
+        };
+        load_tap(0, av[0], bv[0]);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            if (tap + 1 < KK) load_tap(tap + 1, av[(tap + 1) & 1], bv[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[n], acc[t][n], 0, 0, 0);
-            }
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap & 1][cg][t], bv[tap & 1][cg][n], acc[t][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue: lane holds, per tile and channel co = 16 n + li, the pixels 4 lk .. 4 lk + 3 of the tile
 #pragma unroll
