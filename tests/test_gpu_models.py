@@ -527,3 +527,36 @@ def test_gan_steps_replayed_with_overlapped_updates_equal_the_serial_steps():
         assert losses_g == losses_s, run.__name__
         for a, b in zip(weights_g, weights_s):
             assert np.array_equal(a, b), run.__name__
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 3, 7, 130])
+def test_matrix_core_bodies_agree_with_the_vector_bodies(n, monkeypatch):
+    """The 16/32-channel layers run on MFMA tiles in the fused forward, the input-gradient and the kernel-gradient
+    kernels; the SPECTRUM_*_VALU switches select the vector bodies at plan time.  Both must give the same prediction
+    and gradients to rounding, also for batches that leave a pass or a wave partly empty."""
+    from spectrum_vae_amd import autoencoder, losses
+    from spectrum_vae_amd.losses import to_device_f32
+    x = data(n, seed=23 + n)
+    res = {}
+    for mode in ("mfma", "valu"):
+        for var in ("SPECTRUM_NETFWD_VALU", "SPECTRUM_DGRAD_VALU", "SPECTRUM_WGRAD_VALU"):
+            if mode == "valu":
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
+        model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+        model.build((None, 32, 32, 3))
+        model._materialize()
+        model.compile(optimizer=None, loss=losses.MeanSquaredError())
+        xd = to_device_f32(x)
+        model.zero_grad()
+        pred = model.forward_raw(xd, True)
+        loss = torch.zeros(1, device=xd.device)
+        dpred = torch.empty_like(pred)
+        model.loss.value_and_grad(xd, pred, loss, dpred, 1.0)
+        model.backward_raw(dpred, -1, need_dx=False)
+        res[mode] = (pred.cpu().numpy().copy(), model._grads.cpu().numpy().copy())
+    assert rel(res["mfma"][0], res["valu"][0]) < 1e-5
+    assert rel(res["mfma"][1], res["valu"][1]) < 2e-5
+    assert not np.array_equal(res["mfma"][1], res["valu"][1])  # the switches do select different bodies
