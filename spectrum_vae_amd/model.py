@@ -82,6 +82,8 @@ class Model(Layer):
         # Run the whole forward as ONE launch when the model is a plain chain of fusable 3x3 convs (see
         # ``_conv_chain``); the per-layer buffers are filled exactly as the per-layer path fills them.
         self.use_net_fused = True
+        # measured at batch 1024 (step time in ms for large / small = 256/256: 0.297, 128/256: 0.291, 128/128: 0.292, 64/256: 0.321)
+        self.wgrad_batch_blocks_large = int(os.environ.get("SPECTRUM_WGRAD_BLOCKS_LARGE", "128"))  # layers of >= 256 pixels
         self.wgrad_batch_blocks = int(os.environ.get("SPECTRUM_WGRAD_BLOCKS", "256"))  # workgroups per layer when >= 3 layers share the batched kernel-gradient launch
         self.defer_wgrad_reduce = True  # one reduction launch for the kernel gradients of all fused conv layers
         # The whole backward as one launch (sv_convnet_bwd) is correct but, with one sample in flight per workgroup,
@@ -338,8 +340,10 @@ class Model(Layer):
             ctx.wgrad_jobs, ctx.wgrad_finish = [], []
             dx = self.backward(ctx, dy, need_dx=need_dx)
             nb = self.wgrad_batch_blocks if len(ctx.wgrad_jobs) >= 3 else 0
+            for j in ctx.wgrad_jobs:  # layers with large images: fewer workgroups, each staging more samples
+                j["blocks"] = (self.wgrad_batch_blocks_large if j["g"].H * j["g"].W >= 256 else nb) if nb else 0
             ops.conv2d_wgrad_batch(ctx.wgrad_jobs, reduce=False, blocks=nb)
-            ops.conv2d_wgrad_finish(ctx.wgrad_finish + [(j["g"], j["ws"], j["dw"], j["db"], nb) for j in ctx.wgrad_jobs])
+            ops.conv2d_wgrad_finish(ctx.wgrad_finish + [(j["g"], j["ws"], j["dw"], j["db"], j["blocks"]) for j in ctx.wgrad_jobs])
             ctx.wgrad_jobs = None
             return dx
         return self.backward(ctx, dy, need_dx=need_dx)

@@ -156,7 +156,7 @@ def conv2d_wgrad_batch(jobs, reduce: bool = True, blocks: int = 0):
         a.x, a.dy, a.y, a.idx = _ptr(d["x"]), _ptr(d["dy"]), _ptr(d["y"]), _ptr(d.get("idx"), torch.uint8)
         a.dw, a.db = _ptr(d["dw"]), _ptr(d.get("db"))
         a.workspace, a.workspace_bytes = _ptr(d["ws"], torch.uint8), d["ws"].numel()
-        a.act, a.alpha, a.accumulate, a.blocks = ACT[d["act"]], float(d["alpha"] or 0.0), 1, blocks
+        a.act, a.alpha, a.accumulate, a.blocks = ACT[d["act"]], float(d["alpha"] or 0.0), 1, d.get("blocks", blocks)
     check(lib.sv_conv2d_wgrad_batch(arr, len(jobs), int(reduce), F32, _stream()), "sv_conv2d_wgrad_batch")
 
 
