@@ -267,7 +267,9 @@ int sv_reparam_kl_bwd(const float* mean, const float* logvar, const float* eps, 
 size_t sv_loss_workspace_bytes(void);
 int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int weight_stride, float weight_scale,
                 float* loss_out, int accumulate, void* dpred, float loss_scale, int64_t n_pix, int C, float* partials,
-                int dtype, sv_stream_t stream);
+                float* running, float running_weight, int dtype, sv_stream_t stream);
+/* running (may be NULL): running[0] += running_weight * loss in the same launch - the sample-weighted epoch loss that
+ * model.fit reports (run_model.py:141-148), without a launch of its own. */
 /* per-pixel map, reduction="none" (run_context_encoder.py:493-501; run_model.py:361-362): out[p] = w[p]*mean_c(d^2) */
 int sv_loss_mse_map(const void* y_true, const void* y_pred, const float* weight, int weight_stride,
                     float weight_scale, float* out, int64_t n_pix, int C, int dtype, sv_stream_t stream);

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const
 
 // one block of 256 threads: fixed-order tree over the (<= 1024) block partials
 __global__ __launch_bounds__(256) void loss_fold_k(const float* __restrict__ partials, int nblocks, float inv_count,
-                                                    float* __restrict__ out, int accumulate) {
+                                                    float* __restrict__ out, int accumulate,
+                                                    float* __restrict__ running = nullptr, float running_weight = 0.f) {
     __shared__ double red[256];
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partials[b];
@@ -61,7 +62,9 @@ __global__ __launch_bounds__(256) void loss_fold_k(const float* __restrict__ par
     }
     if (threadIdx.x == 0) {
         const float v = (float)(red[0] * (double)inv_count);
-        out[0] = accumulate ? out[0] + v : v;
+        const float r = accumulate ? out[0] + v : v;
+        out[0] = r;
+        if (running != nullptr) running[0] += running_weight * r;  // an epoch's running sum, in the same launch
     }
 }
 
@@ -259,7 +262,7 @@ size_t sv_loss_workspace_bytes(void) { return (size_t)kLossBlocks * sizeof(float
 
 int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int weight_stride, float weight_scale,
                 float* loss_out, int accumulate, void* dpred, float loss_scale, int64_t n_pix, int C, float* partials,
-                int dtype, sv_stream_t stream) {
+                float* running, float running_weight, int dtype, sv_stream_t stream) {
     SV_F32_ONLY(dtype, "sv_loss_mse");
     SV_REQUIRE(y_true && y_pred && loss_out && partials && n_pix > 0 && C > 0, "sv_loss_mse: bad arguments");
     SV_REQUIRE(weight == nullptr || weight_stride > 0, "sv_loss_mse: weight_stride must be positive");
@@ -271,7 +274,8 @@ int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int
                        loss_scale, n, partials);
     int rc = check_launch("sv_loss_mse");
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate,
+                       running, running_weight);
     return check_launch("sv_loss_mse/fold");
 }
 

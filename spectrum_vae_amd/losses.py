@@ -75,8 +75,11 @@ def _weight_view(sample_weight, y_pred):
 
 
 class MeanSquaredError(Loss):
+    fuses_running_sum = True  # value_and_grad(..., running=, running_weight=) adds the loss to an epoch sum in its launch
+
     def value_and_grad(self, y_true, y_pred, loss_out, dpred=None, scale=1.0, sample_weight=None, accumulate=False,
-                       weight_scale: float = 1.0, weight_stride: Optional[int] = None):
+                       weight_scale: float = 1.0, weight_stride: Optional[int] = None, running=None,
+                       running_weight: float = 0.0):
         if tuple(y_true.shape) != tuple(y_pred.shape):
             raise ValueError(f"MSE: y_true {tuple(y_true.shape)} vs y_pred {tuple(y_pred.shape)}")
         if weight_stride is None:
@@ -84,7 +87,7 @@ class MeanSquaredError(Loss):
         else:  # caller passes a raw device tensor read with a stride (channel 0 of an NHWC mask)
             w, stride = sample_weight, weight_stride
         ops.loss_mse(y_true, y_pred, loss_out, _scratch_for(y_pred.device)["partials"], dpred, scale, w, stride,
-                     weight_scale, accumulate)
+                     weight_scale, accumulate, running, running_weight)
 
     def per_sample(self, y_true, y_pred, sample_weight=None):
         w, stride = _weight_view(sample_weight, y_pred)

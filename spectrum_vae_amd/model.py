@@ -429,8 +429,11 @@ class Model(Layer):
                         sd.wait_event(zeroed)
         pred = self.forward_raw(b["x"], True, side)
         yt = b["x"] if same_xy else b["y"]
-        self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0)
-        ops.axpy(b["acc"], b["loss"], weight)
+        if getattr(self.loss, "fuses_running_sum", False):
+            self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0, running=b["acc"], running_weight=weight)
+        else:
+            self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0)
+            ops.axpy(b["acc"], b["loss"], weight)
         if side is not None:
             main.wait_event(zeroed)
         self.backward_raw(b["dpred"], -1, need_dx=False)

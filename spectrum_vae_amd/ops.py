@@ -309,13 +309,14 @@ def loss_workspace_floats() -> int:
 
 
 def loss_mse(y_true, y_pred, loss_out, partials, dpred=None, loss_scale=1.0, weight=None, weight_stride=1,
-             weight_scale=1.0, accumulate=False):
+             weight_scale=1.0, accumulate=False, running=None, running_weight=0.0):
     c = y_pred.shape[-1]
     n_pix = y_pred.numel() // c
     if y_true.numel() != y_pred.numel():
         raise ValueError(f"MSE: y_true {tuple(y_true.shape)} vs y_pred {tuple(y_pred.shape)}")
     check(lib.sv_loss_mse(_ptr(y_true), _ptr(y_pred), _ptr(weight), weight_stride, weight_scale, _ptr(loss_out),
-                          int(accumulate), _ptr(dpred), loss_scale, n_pix, c, _ptr(partials), F32, _stream()),
+                          int(accumulate), _ptr(dpred), loss_scale, n_pix, c, _ptr(partials), _ptr(running),
+                          float(running_weight), F32, _stream()),
           "sv_loss_mse")
 
 

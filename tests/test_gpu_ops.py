@@ -464,6 +464,10 @@ def test_losses():
     ops.loss_mse(dev(t), dev(p), out, part)
     ops.loss_mse(dev(t), dev(p), out, part, accumulate=True)
     close(out, np.array([2 * np_ops.mse(t, p)]), what="accumulate")
+    # running sum in the same launch: running += weight * loss
+    run = torch.full((1,), 3.0, device="cuda")
+    ops.loss_mse(dev(t), dev(p), out, part, running=run, running_weight=7.0)
+    close(run, np.array([3.0 + 7.0 * np_ops.mse(t, p)]), what="running sum")
 
 
 def test_adam_keras_and_schedule():
