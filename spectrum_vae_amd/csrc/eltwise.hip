@@ -467,6 +467,17 @@ __global__ void gather_rows_k(const SRC* __restrict__ src, const int64_t* __rest
     }
 }
 
+// f32 rows whose length is a multiple of 4 and 16-byte aligned: 16-byte pieces, one 32-bit division per piece
+__global__ void gather_rows_f4_k(const float4* __restrict__ src, const int64_t* __restrict__ idx, float4* __restrict__ dst,
+                                 int n_rows, int row_f4) {
+    const int total = n_rows * row_f4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / row_f4, e = i - r * row_f4;
+        const int64_t sr = idx != nullptr ? idx[r] : r;
+        dst[i] = src[sr * row_f4 + e];
+    }
+}
+
 __global__ void mask_input_k(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y,
                              int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -749,6 +760,13 @@ int sv_reduce_sum_h_bwd(const void* dy, void* dx, int N, int H, int W, int C, in
 int sv_gather_rows(const void* src, int src_is_f64, const int64_t* idx, float* dst, int64_t n_rows,
                    int64_t row_elems, sv_stream_t stream) {
     SV_REQUIRE(src && dst && n_rows > 0 && row_elems > 0, "sv_gather_rows: bad arguments");
+    if (!src_is_f64 && (row_elems & 3) == 0 && n_rows * (row_elems >> 2) < (1ll << 31) &&
+        ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const int row_f4 = (int)(row_elems >> 2);
+        hipLaunchKernelGGL(gather_rows_f4_k, dim3(ew_grid(n_rows * row_f4, 256, 16384)), dim3(256), 0, to_stream(stream),
+                           (const float4*)src, idx, (float4*)dst, (int)n_rows, row_f4);
+        return check_launch("sv_gather_rows");
+    }
     const int grid = ew_grid(n_rows * row_elems, 256, 8192);
     if (src_is_f64)
         hipLaunchKernelGGL(gather_rows_k<double>, dim3(grid), dim3(256), 0, to_stream(stream), (const double*)src,
