@@ -489,12 +489,15 @@ class Model(Layer):
                     self.optimizer.apply_model(self, scale, zero_grads=True)
                 g = (g_fb, g_opt)
             self._graphs[key] = g
-        if len(g) == 1:
-            g[0].replay()
-        else:
-            g[0].replay()
+        if not self._grads_clean:
+            # the recorded step relies on its own optimizer launch having cleared the buffer; a manual backward
+            # (or anything else that touched the gradients) since the last replay means clearing it here first
+            ops.fill(self._grads, 0.0)
+        g[0].replay()
+        if len(g) == 2:
             self._reducer.all_reduce(self._grads)
             g[1].replay()
+        self._grads_clean = True
 
     def graph_safe(self) -> bool:
         """A step can be frozen into a HIP graph when no layer needs fresh host-side arguments per call."""

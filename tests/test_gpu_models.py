@@ -241,6 +241,38 @@ def test_trajectory_100_steps_run_model_config():
         assert rel(v.numpy(), p.detach().numpy()) <= 1e-3, v.name
 
 
+def test_replayed_steps_survive_a_manual_backward_in_between():
+    """The recorded step leaves out the gradient clear (its optimizer launch does it).  A manual backward between
+    two replays leaves gradients in the buffer; the next replayed step must not add to them."""
+    from spectrum_vae_amd import autoencoder, losses, ops
+    from spectrum_vae_amd.run_model import build_optimizer
+    X = torch.from_numpy(data(32 * 4)).cuda()
+
+    def run(disturb):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+        model.build((None, 32, 32, 3))
+        model._materialize()
+        model.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
+        b = model._step_buffers(32, (32, 32, 3))
+        out = []
+        for step in range(8):
+            ops.gather_rows(X[(step % 4) * 32:(step % 4 + 1) * 32], None, b["x"])
+            model.train_on_device_batch(b, True, 32.0)
+            out.append(float(b["loss"].item()))
+            if disturb and step in (3, 5):
+                pred = model.forward_raw(X[:7], True)
+                model.backward_raw(torch.ones_like(pred), -1, need_dx=False)
+                model._calls.clear()
+        return out, [v.numpy().copy() for v in model.trainable_variables]
+
+    (l0, w0), (l1, w1) = run(False), run(True)
+    assert l0 == l1
+    for a, c in zip(w0, w1):
+        assert np.array_equal(a, c)
+
+
 def test_fit_predict_history_and_early_stopping():
     from spectrum_vae_amd import EarlyStopping, losses
     from spectrum_vae_amd.run_model import build_optimizer, default_model, pad_height
