@@ -483,9 +483,10 @@ class Model(Layer):
             else:
                 scale = 1.0 / self._reducer.world
                 g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fb):
+                # thread-local capture: the process group's watchdog thread polls events while this thread records
+                with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
                     self._fwd_bwd(b, same_xy, weight)
-                with torch.cuda.graph(g_opt):
+                with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
                     self.optimizer.apply_model(self, scale, zero_grads=True)
                 g = (g_fb, g_opt)
             self._graphs[key] = g

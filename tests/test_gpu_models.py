@@ -273,6 +273,42 @@ def test_replayed_steps_survive_a_manual_backward_in_between():
         assert np.array_equal(a, c)
 
 
+def test_data_parallel_step_with_one_rank_equals_the_plain_step():
+    """With a gradient reducer attached the step is two recorded graphs with the all-reduce issued between them.  A
+    reducer over one rank (no process group) sums nothing and scales by 1, so losses and weights must equal the
+    single-graph step bit for bit."""
+    from spectrum_vae_amd import autoencoder, losses, ops, parallel
+    from spectrum_vae_amd.run_model import build_optimizer
+    X = torch.from_numpy(data(32 * 4)).cuda()
+
+    def run(reduced):
+        model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+        model.build((None, 32, 32, 3))
+        model._materialize()
+        model.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
+        red = None
+        if reduced:
+            red = parallel.GradReducer()
+            assert red.world == 1
+            model.distribute(red)
+        b = model._step_buffers(32, (32, 32, 3))
+        out = []
+        for step in range(8):
+            ops.gather_rows(X[(step % 4) * 32:(step % 4 + 1) * 32], None, b["x"])
+            model.train_on_device_batch(b, True, 32.0)
+            out.append(float(b["loss"].item()))
+        g = next(iter(model._graphs.values()))
+        assert len(g) == (2 if reduced else 1)
+        if reduced:
+            assert red.calls == 8 and red.bytes == 8 * 4 * model._grads.numel()
+        return out, [v.numpy().copy() for v in model.trainable_variables]
+
+    (l0, w0), (l1, w1) = run(False), run(True)
+    assert l0 == l1
+    for a, c in zip(w0, w1):
+        assert np.array_equal(a, c)
+
+
 def test_fit_predict_history_and_early_stopping():
     from spectrum_vae_amd import EarlyStopping, losses
     from spectrum_vae_amd.run_model import build_optimizer, default_model, pad_height
