@@ -328,6 +328,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0 is the last to arrive (per-kernel timing above); tear the group down together
         dist.destroy_process_group()
 
 
