@@ -148,29 +148,40 @@ def kernel_of_call(name: str, g):
     return None
 
 
-def run_cpu_baseline(budget_s: float = 20.0, batch: int = PER_GPU_BATCH) -> dict:
-    """The torch-CPU restatement of the same training step (oracle/torch_ref.py), timed on the host cores."""
+def run_cpu_baseline(budget_s: float = 14.0, batch: int = PER_GPU_BATCH) -> dict:
+    """The torch-CPU restatement of the same training step (oracle/torch_ref.py), timed on the host cores: at the
+    bench's batch (the reported value) and at the reference loop's own batch of 32 (run_model.py:234,289)."""
     from oracle import models as omodels
     from oracle import torch_ref
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    host_cpus = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(host_cpus, 16)
     torch.set_num_threads(threads)
-    cfg = {k: v for k, v in RUN_MODEL_CFG.items()}
-    enc, dec = omodels.caepadded(**cfg)
-    ref = torch_ref.RefSequential(enc + dec, (32, 32, 3))
-    opt = torch_ref.KerasAdam(ref.params, 5e-4, decay_steps=10, decay_rate=0.96)
-    x = torch.from_numpy(synth_data(batch, 1833))
-    torch_ref.train_step_mse(ref, opt, x, x)  # warm-up
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        torch_ref.train_step_mse(ref, opt, x, x)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 200:
-            break
+
+    def timed(bsz: int, budget: float):
+        cfg = {k: v for k, v in RUN_MODEL_CFG.items()}
+        enc, dec = omodels.caepadded(**cfg)
+        ref = torch_ref.RefSequential(enc + dec, (32, 32, 3))
+        opt = torch_ref.KerasAdam(ref.params, 5e-4, decay_steps=10, decay_rate=0.96)
+        x = torch.from_numpy(synth_data(bsz, 1833))
+        torch_ref.train_step_mse(ref, opt, x, x)  # warm-up
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            torch_ref.train_step_mse(ref, opt, x, x)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or steps >= 2000:
+                break
+        return steps, el
+
+    steps, el = timed(batch, budget_s)
+    steps32, el32 = timed(32, 6.0)
     return {"value": round(steps * batch / el, 1), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} training steps at batch {batch} of the torch-CPU restatement of the reference step "
-                      f"(TensorFlow is not installable here) in {el:.1f} s"}
+            "host_cpu_count": host_cpus,
+            "value_batch32": round(steps32 * 32 / el32, 1),
+            "sample": f"{steps} training steps at batch {batch} in {el:.1f} s (value) and {steps32} steps at the "
+                      f"reference loop's batch 32 in {el32:.1f} s (value_batch32) of the torch-CPU restatement of the "
+                      f"reference step (TensorFlow is not installable here), {threads} threads of {host_cpus} host CPUs"}
 
 
 def main():

@@ -176,9 +176,11 @@ class Model(Layer):
         for v in ntv:
             v.data = self._state[v.offset:v.offset + v.size].view(v.shape)
             v.owner = self
-        for l in self._all_layers():
+        for i, l in enumerate(self._all_layers()):
             if isinstance(l, Sequential):
                 l._owner_model = self
+            if hasattr(l, "stream_id"):
+                l.stream_id = i
 
     def _all_layers(self) -> List[Layer]:
         out, stack = [], [self]

@@ -131,6 +131,10 @@ class BufferPool:
         """Shared scratch for reductions; grows, never shrinks.  Kernels using it run on one stream."""
         nbytes = max(int(nbytes), 256)
         if self._ws is None or self._ws.numel() < nbytes:
+            if self._ws is not None:
+                # recorded HIP graphs hold the old buffer's raw address: it must stay allocated (and unused by anyone
+                # else) for as long as they can be replayed, i.e. for the life of the pool
+                self._retired.append(self._ws)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
@@ -693,6 +697,9 @@ class Dropout(Layer):
         self.rate = float(rate)
         self.seed = DEFAULT_SEED if seed is None else int(seed)
         self.calls = 0
+        # position of this layer in its model (set when the model lays out its parameters): the per-layer random
+        # stream is derived from it, so two builds of the same model draw the same masks
+        self.stream_id = 0
 
     def forward(self, ctx, x):
         if not ctx.training or self.rate <= 0.0:
@@ -700,7 +707,7 @@ class Dropout(Layer):
         y = ctx.buf(self, "y", tuple(x.shape))
         offset = self.calls * x.numel()
         self.calls += 1
-        ops.dropout_fwd(x, y, self.rate, self.seed + (id(self) % 65521), offset)
+        ops.dropout_fwd(x, y, self.rate, self.seed + 7919 * self.stream_id, offset)
         ctx.saved[id(self)] = {"offset": offset}
         return y
 
@@ -710,7 +717,7 @@ class Dropout(Layer):
         if self.rate <= 0.0:
             return dy
         dx = ctx.buf(self, "dx", tuple(dy.shape))
-        ops.dropout_bwd(dy, dx, self.rate, self.seed + (id(self) % 65521), ctx.saved[id(self)]["offset"])
+        ops.dropout_bwd(dy, dx, self.rate, self.seed + 7919 * self.stream_id, ctx.saved[id(self)]["offset"])
         return dx
 
 

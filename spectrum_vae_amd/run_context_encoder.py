@@ -9,7 +9,7 @@ computed and returned but, as in the reference, never differentiated.
 from __future__ import annotations
 
 import argparse
-from typing import Dict, Tuple
+from typing import Tuple
 
 import numpy as np
 import torch
@@ -152,7 +152,17 @@ class _StepState:
         self.side = torch.cuda.Stream(device=device)  # the context-encoder update runs beside the discriminator's
 
 
-_STEP_CACHE: Dict[tuple, _StepState] = {}
+def _step_state(ce, disc, ce_opt, disc_opt, bs: int, weight: float, device) -> _StepState:
+    """The step state of (ce, disc, optimizers, batch size, weight).  It lives ON the context encoder and holds
+    references to the other three participants, so a recorded graph can never outlive - or be looked up for
+    look-alikes of - the objects whose buffers it is bound to."""
+    cache = ce.__dict__.setdefault("_gan_steps", {})
+    key = (id(disc), id(ce_opt), id(disc_opt), int(bs), float(weight))
+    st = cache.get(key)
+    if st is None:
+        st = cache[key] = _StepState(ce, disc, bs, device)
+        st.partners = (disc, ce_opt, disc_opt)  # keeps the ids in the key from being reused while the entry exists
+    return st
 
 
 def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, overlap: bool = False):
@@ -228,10 +238,7 @@ def train_step(context_encoder, discriminator, ce_opt, disc_opt, X, mask, l2_wei
         disc.build(tuple(Xd.shape))
     ce._materialize(device)
     disc._materialize(device)
-    key = (id(ce), id(disc), id(ce_opt), id(disc_opt), Xd.shape[0], float(l2_weight))
-    st = _STEP_CACHE.get(key)
-    if st is None:
-        st = _STEP_CACHE[key] = _StepState(ce, disc, Xd.shape[0], device)
+    st = _step_state(ce, disc, ce_opt, disc_opt, Xd.shape[0], l2_weight, device)
     st.X.copy_(Xd)
     st.mask.copy_(Md)
     graphable = use_graph and ce._reducer is None and disc._reducer is None

@@ -10,7 +10,7 @@ training tensor as the 1-channel input and the full tensor as the 3-channel targ
 from __future__ import annotations
 
 import argparse
-from typing import Dict, Tuple
+from typing import Tuple
 
 import numpy as np
 import torch
@@ -78,7 +78,17 @@ class _StepState:
         self.side = torch.cuda.Stream(device=device)  # the generator update runs beside the discriminator's
 
 
-_STEP_CACHE: Dict[tuple, _StepState] = {}
+def _step_state(gen, disc, gen_opt, disc_opt, bs: int, weight: float, device) -> _StepState:
+    """The step state of (generator, discriminator, optimizers, batch size, lambda).  It lives ON the generator and
+    holds references to the other three participants, so a recorded graph can never outlive - or be looked up for
+    look-alikes of - the objects whose buffers it is bound to."""
+    cache = gen.__dict__.setdefault("_gan_steps", {})
+    key = (id(disc), id(gen_opt), id(disc_opt), int(bs), float(weight))
+    st = cache.get(key)
+    if st is None:
+        st = cache[key] = _StepState(gen, disc, bs, device)
+        st.partners = (disc, gen_opt, disc_opt)  # keeps the ids in the key from being reused while the entry exists
+    return st
 
 
 def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: float, overlap: bool = False):
@@ -169,10 +179,7 @@ def train_step(generator, discriminator, ce_opt, disc_opt, X, y, lambda_weight: 
         disc.build((Xd.shape[0], Xd.shape[1], Xd.shape[2], Xd.shape[3] + yd.shape[3]))
     gen._materialize(device)
     disc._materialize(device)
-    key = (id(gen), id(disc), id(ce_opt), id(disc_opt), Xd.shape[0], float(lambda_weight))
-    st = _STEP_CACHE.get(key)
-    if st is None:
-        st = _STEP_CACHE[key] = _StepState(gen, disc, Xd.shape[0], device)
+    st = _step_state(gen, disc, ce_opt, disc_opt, Xd.shape[0], lambda_weight, device)
     st.X.copy_(Xd)
     st.y.copy_(yd)
     graphable = use_graph and gen._reducer is None and disc._reducer is None

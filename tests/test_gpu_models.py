@@ -628,3 +628,113 @@ def test_matrix_core_bodies_agree_with_the_vector_bodies(n, monkeypatch):
     assert rel(res["mfma"][0], res["valu"][0]) < 1e-5
     assert rel(res["mfma"][1], res["valu"][1]) < 2e-5
     assert not np.array_equal(res["mfma"][1], res["valu"][1])  # the switches do select different bodies
+
+
+def test_bench_shape_step_matches_oracle():
+    """The headline configuration itself: run_model.py defaults at batch 1024 through ``train_on_device_batch``'s
+    replayed graphs (fused forward, matrix-core bodies, 128 / 256 kernel-gradient workgroups per layer).  Loss and
+    every gradient within 1e-4 of the CPU restatement, then 20 optimizer steps with the loss trajectory within 1e-3."""
+    from spectrum_vae_amd import autoencoder, losses, ops, parallel
+    from spectrum_vae_amd.run_model import build_optimizer
+    n = 1024
+    X = data(2 * n, seed=41)
+    model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+    model.build((None, 32, 32, 3))
+    model._materialize()
+    assert model.wgrad_batch_blocks_large == 128 and model.wgrad_batch_blocks == 256
+    enc, dec = omodels.caepadded(**RUN_MODEL_DEFAULTS)
+    ref = RefSequential(enc + dec, (32, 32, 3))
+    load_into_ref(ref, model)
+    w_start = [v.numpy() for v in model.trainable_variables]
+
+    class Snoop(parallel.GradReducer):
+        """A one-rank reducer that keeps a copy of what it is handed: the gradient buffer exactly as the replayed
+        forward/backward graph left it (the optimizer graph that follows clears it)."""
+        snaps = []
+
+        def all_reduce(self, flat):
+            self.snaps.append(flat.clone())
+            return super().all_reduce(flat)
+
+    # ---- (1) gradients out of the replayed step.  lr = 0 keeps the weights where the oracle's are.
+    from spectrum_vae_amd.optimizers import Adam
+    model.compile(optimizer=Adam(0.0), loss=losses.MeanSquaredError())
+    red = Snoop()
+    model.distribute(red)
+    Xd = torch.from_numpy(X).cuda()
+    b = model._step_buffers(n, (32, 32, 3))
+    ops.gather_rows(Xd[:n], None, b["x"])
+    for _ in range(4):  # eager, capture, replay, replay
+        model.train_on_device_batch(b, True, float(n))
+    g = next(iter(model._graphs.values()))
+    assert not isinstance(g, str) and len(g) == 2
+    flat = red.snaps[-1].cpu().numpy()
+    hip_loss = float(b["loss"].item())
+    _, loss, g32 = _ref_pass(ref, X[:n], X[:n], torch.float32)
+    assert abs(hip_loss - loss) <= 1e-4 * abs(loss)
+    for v, want in zip(model.trainable_variables, g32):
+        got = flat[v.offset:v.offset + v.size].reshape(v.shape)
+        assert rel(got, want, floor=1e-6 + 1e-3 * float(np.abs(want).max())) <= 1e-4, v.name
+    for v, w0 in zip(model.trainable_variables, w_start):
+        assert np.array_equal(v.numpy(), w0)  # lr = 0
+
+    # ---- (2) trajectory through the single-graph step
+    model.distribute(None)
+    model.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
+    opt_ref = KerasAdam(ref.params, 5e-4, decay_steps=10, decay_rate=0.96, staircase=True)
+    hip, cpu = [], []
+    for step in range(20):
+        sl = slice((step % 2) * n, (step % 2 + 1) * n)
+        ops.gather_rows(Xd[sl], None, b["x"])
+        model.train_on_device_batch(b, True, float(n))
+        hip.append(float(b["loss"].item()))
+        xb = torch.from_numpy(X[sl])
+        cpu.append(torch_ref.train_step_mse(ref, opt_ref, xb, xb))
+    hip, cpu = np.array(hip), np.array(cpu)
+    g = next(iter(model._graphs.values()))
+    assert not isinstance(g, str) and len(g) == 1, "the trajectory steps were not replayed from one graph"
+    assert np.max(np.abs(hip - cpu) / np.abs(cpu)) <= 1e-3, (hip, cpu)
+    for v, p in zip(model.trainable_variables, ref.params):
+        assert rel(v.numpy(), p.detach().numpy()) <= 1e-3, v.name
+
+
+def test_recorded_step_survives_a_larger_scratch_request():
+    """A recorded step holds the raw address of the pool's scratch buffer.  A later call that needs more scratch (a
+    training-mode forward at a much larger batch) replaces the buffer; the old one must stay alive, or replays would
+    write partial sums into memory the allocator has handed to someone else."""
+    from spectrum_vae_amd import autoencoder, losses, ops
+    from spectrum_vae_amd.losses import to_device_f32
+    from spectrum_vae_amd.run_model import build_optimizer
+    cfg = dict(RUN_MODEL_DEFAULTS, batch_norm=True)  # BatchNorm reductions go through the shared scratch
+    X = data(8 * 4)
+    big = to_device_f32(data(600, seed=9))
+
+    def run(disturb):
+        model = autoencoder.CAEPadded(**cfg)
+        model.build((None, 32, 32, 3))
+        model._materialize()
+        model.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
+        Xd = torch.from_numpy(X).cuda()
+        b = model._step_buffers(8, (32, 32, 3))
+        out, hog = [], []
+        for step in range(8):
+            ops.gather_rows(Xd[(step % 4) * 8:(step % 4 + 1) * 8], None, b["x"])
+            model.train_on_device_batch(b, True, 8.0)
+            out.append(float(b["loss"].item()))
+            if disturb and step == 3:
+                ws0 = model._pool._ws
+                state = model._state.clone()
+                model.forward_raw(big, True)      # asks for far more scratch than the batch-8 step did
+                model._calls.clear()
+                model._state.copy_(state)         # undo the moving-statistics update of the extra call
+                assert model._pool._ws is not ws0 and any(t is ws0 for t in model._pool._retired)
+                # whatever the allocator hands out next must not be the retired scratch
+                hog = [torch.full((ws0.numel() // 4,), 7.0, device="cuda") for _ in range(4)]
+        for h in hog:
+            assert bool((h == 7.0).all())
+        return out, [v.numpy().copy() for v in model.trainable_variables]
+
+    (l0, w0), (l1, w1) = run(False), run(True)
+    assert l0 == l1
+    for a, c in zip(w0, w1):
+        assert np.array_equal(a, c)
