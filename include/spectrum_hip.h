@@ -61,6 +61,18 @@ size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g);
 int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate,
                     void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
 
+/* ---- sv_conv2d_wgrad without a workspace argument and without any allocation.  No counterpart in the reference (its
+ *      kernel gradients come out of TensorFlow's GradientTape, which allocates freely): this is for callers that cannot
+ *      allocate - code under HIP graph capture, tight serving / fine-tuning loops, harnesses that forbid hipMalloc.
+ *      The partial sums go through a 16 MiB device array inside the library (one copy per GPU, held until the process
+ *      ends; sv_static_scratch_bytes() returns its size); the call uses the CURRENT device's copy.  Geometries whose
+ *      sv_conv2d_wgrad_workspace_bytes exceeds that size are refused with SV_E_WORKSPACE.  Results are bit-identical to
+ *      sv_conv2d_wgrad.  All calls on one GPU share the array: calls that overlap in time on one GPU (different
+ *      streams, different threads) race - serialise them. */
+size_t sv_static_scratch_bytes(void);
+int sv_conv2d_wgrad_static(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate, int dtype,
+                           sv_stream_t stream);
+
 /* ---- fused forms for stride-1 SAME convs with a 3x3 or 5x5 kernel (every conv of CAEPadded,
  *      autoencoder.py:438-459,496-526).  sv_conv2d_fused_supported tells whether a geometry is in the family
  *      (pooled != 0: also that the output extent is even).

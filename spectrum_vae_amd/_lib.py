@@ -61,6 +61,8 @@ SIGNATURES = {
     "sv_conv2d_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
     "sv_conv2d_wgrad_workspace_bytes": (_sz, [_g]),
     "sv_conv2d_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),
+    "sv_static_scratch_bytes": (_sz, []),
+    "sv_conv2d_wgrad_static": (_i, [_g, _p, _p, _p, _i, _i, _p]),
     "sv_conv2d_fused_supported": (_i, [_g, _i]),
     "sv_conv2d_pool_fwd": (_i, [_g, _p, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_bwd": (_i, [_g, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _sz, _i, _p]),

@@ -1,0 +1,67 @@
+// An entry point that allocates nothing: the kernel gradient of a convolution with its partial-sum slabs in a
+// device array that is part of the library's code object.  For callers that cannot call hipMalloc (code under HIP
+// graph capture, tight serving / fine-tuning loops, harnesses that forbid allocation) and have no workspace to pass.
+#include <mutex>
+
+#include "common.h"
+
+namespace sv {
+
+constexpr size_t kStaticScratchBytes = (size_t)16 << 20;  // 16 MiB per GPU, held from library load to process end
+
+// The partial-sum slabs of sv_conv2d_wgrad_static.  Every GPU the library's code object is loaded on has its own copy
+// at its own address.  In host code this name is only a handle for hipGetSymbolAddress: it is never passed to a
+// kernel or to a memory routine.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, looked up once per GPU
+
+// Device address of this GPU's copy of `scratch` (the current device's), or nullptr with the error text set.
+static void* static_scratch_for_current_device() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        fail(SV_E_LAUNCH, "sv_conv2d_wgrad_static: no usable current device (%s, device %d)", hipGetErrorString(e), dev);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // resolves against the current device's code object
+        if (e != hipSuccess || p == nullptr) {
+            fail(SV_E_LAUNCH, "sv_conv2d_wgrad_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                 hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    return g_scratch_ptr[dev];
+}
+
+}  // namespace sv
+
+using namespace sv;
+
+extern "C" {
+
+size_t sv_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+int sv_conv2d_wgrad_static(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate, int dtype,
+                           sv_stream_t stream) {
+    const size_t need = sv_conv2d_wgrad_workspace_bytes(g);  // validates the geometry (0: invalid)
+    if (need == 0) return fail(SV_E_INVALID, "sv_conv2d_wgrad_static: invalid geometry");
+    if (need > kStaticScratchBytes)
+        return fail(SV_E_WORKSPACE,
+                    "sv_conv2d_wgrad_static: this geometry needs %zu bytes of partial sums, the built-in scratch holds "
+                    "%zu: use sv_conv2d_wgrad with a caller workspace",
+                    need, kStaticScratchBytes);
+    void* ptr = static_scratch_for_current_device();
+    if (ptr == nullptr) return SV_E_LAUNCH;
+    // Nothing in the slabs has to start at zero: every partial sum that the reduction uses is written by this call's
+    // producer kernel first (padding slots are read and dropped), so the previous call's contents never show.
+    return sv_conv2d_wgrad(g, x, dz, dw, accumulate, ptr, kStaticScratchBytes, dtype, stream);
+}
+
+}  // extern "C"

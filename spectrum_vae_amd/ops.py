@@ -100,6 +100,16 @@ def conv2d_wgrad(g: ConvGeom, x, dz, dw, accumulate: bool, ws: torch.Tensor):
                               ws.numel(), F32, _stream()), "sv_conv2d_wgrad")
 
 
+def static_scratch_bytes() -> int:
+    return int(lib.sv_static_scratch_bytes())
+
+
+def conv2d_wgrad_static(g: ConvGeom, x, dz, dw, accumulate: bool):
+    """``conv2d_wgrad`` with the partial sums in the library's built-in device array: no workspace, no allocation."""
+    check(lib.sv_conv2d_wgrad_static(C.byref(g), _ptr(x), _ptr(dz), _ptr(dw), int(accumulate), F32, _stream()),
+          "sv_conv2d_wgrad_static")
+
+
 def conv2d_fused_supported(g: ConvGeom, pooled: bool) -> bool:
     return bool(lib.sv_conv2d_fused_supported(C.byref(g), int(pooled)))
 
