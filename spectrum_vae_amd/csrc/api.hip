@@ -17,6 +17,13 @@ int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, 
 size_t wgrad_direct_workspace(const sv_conv_geom& g);
 int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, float* dw, int accumulate, void* ws,
                         size_t ws_bytes, hipStream_t st);
+// bf16 storage: activations / filters / activation gradients bf16, bias and kernel gradients f32
+int launch_fwd_bf16(const sv_conv_geom& g, const void* x, const void* w, const float* bias, void* y, int act, float alpha,
+                    hipStream_t st, void* ws, size_t ws_bytes);
+int launch_dgrad_bf16(const sv_conv_geom& g, const void* dz, const void* w, const float* bias, void* dx, int act,
+                      float alpha, hipStream_t st, void* ws, size_t ws_bytes);
+int launch_wgrad_bf16(const sv_conv_geom& g, const void* x, const void* dz, float* dw, int accumulate, void* ws,
+                      size_t ws_bytes, hipStream_t st);
 
 // conv_tiled.hip
 bool tiled_s1_supported(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP);
@@ -63,10 +70,14 @@ size_t sv_conv2d_scratch_bytes(const sv_conv_geom* g, int op) {
 
 int sv_conv2d_fwd_ws(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
                      float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_conv2d_fwd");
+    SV_F32_OR_BF16(dtype, "sv_conv2d_fwd");
     int rc = validate_geom(g, "sv_conv2d_fwd");
     if (rc) return rc;
     SV_REQUIRE(x && w && y, "sv_conv2d_fwd: null tensor");
+    if (dtype == SV_BF16) {
+        SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_fwd: folded upsampling is f32 only");
+        return launch_fwd_bf16(*g, x, w, (const float*)bias, y, act, alpha, to_stream(stream), workspace, workspace_bytes);
+    }
     if (tiled_shape(*g)) {
         rc = launch_tiled_s1((const float*)x, (const float*)w, (const float*)bias, (float*)y, nullptr, g->N,
                              g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, 0, 0, act, alpha,
@@ -83,10 +94,14 @@ int sv_conv2d_dgrad(const sv_conv_geom* g, const void* dz, const void* w, void* 
 
 int sv_conv2d_dgrad_ws(const sv_conv_geom* g, const void* dz, const void* w, void* dx, void* workspace,
                        size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_conv2d_dgrad");
+    SV_F32_OR_BF16(dtype, "sv_conv2d_dgrad");
     int rc = validate_geom(g, "sv_conv2d_dgrad");
     if (rc) return rc;
     SV_REQUIRE(dz && w && dx, "sv_conv2d_dgrad: null tensor");
+    if (dtype == SV_BF16) {
+        SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_dgrad: folded upsampling is f32 only");
+        return launch_dgrad_bf16(*g, dz, w, nullptr, dx, SV_ACT_NONE, 0.f, to_stream(stream), workspace, workspace_bytes);
+    }
     if (tiled_shape(*g)) {
         // a conv of dz (Cout channels, logical resolution) with mirrored taps and swapped channel roles; a folded
         // upsampling turns into a 2x2 sum of the result
@@ -110,10 +125,14 @@ size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g) {
 
 int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate, void* workspace,
                     size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_conv2d_wgrad");
+    SV_F32_OR_BF16(dtype, "sv_conv2d_wgrad");
     int rc = validate_geom(g, "sv_conv2d_wgrad");
     if (rc) return rc;
     SV_REQUIRE(x && dz && dw, "sv_conv2d_wgrad: null tensor");
+    if (dtype == SV_BF16) {
+        SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_wgrad: folded upsampling is f32 only");
+        return launch_wgrad_bf16(*g, x, dz, (float*)dw, accumulate, workspace, workspace_bytes, to_stream(stream));
+    }
     if (tiled_shape(*g)) {
         rc = launch_tiled_wgrad((const float*)x, (const float*)dz, (float*)dw, nullptr, accumulate, workspace,
                                 workspace_bytes, g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h,
@@ -232,11 +251,13 @@ int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w,
 
 int sv_conv2d_transpose_fwd_ws(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
                                float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_conv2d_transpose_fwd");
+    SV_F32_OR_BF16(dtype, "sv_conv2d_transpose_fwd");
     int rc = validate_geom(g, "sv_conv2d_transpose_fwd");
     if (rc) return rc;
     SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_transpose_fwd: folded upsampling is not defined here");
     SV_REQUIRE(x && w && y, "sv_conv2d_transpose_fwd: null tensor");
+    if (dtype == SV_BF16)
+        return launch_dgrad_bf16(*g, x, w, (const float*)bias, y, act, alpha, to_stream(stream), workspace, workspace_bytes);
     return launch_dgrad_direct(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, act, alpha,
                                to_stream(stream), workspace, workspace_bytes);
 }
@@ -249,11 +270,13 @@ int sv_conv2d_transpose_dgrad(const sv_conv_geom* g, const void* dz, const void*
 
 int sv_conv2d_transpose_dgrad_ws(const sv_conv_geom* g, const void* dz, const void* w, void* dx, void* workspace,
                                  size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_conv2d_transpose_dgrad");
+    SV_F32_OR_BF16(dtype, "sv_conv2d_transpose_dgrad");
     int rc = validate_geom(g, "sv_conv2d_transpose_dgrad");
     if (rc) return rc;
     SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_transpose_dgrad: folded upsampling is not defined here");
     SV_REQUIRE(dz && w && dx, "sv_conv2d_transpose_dgrad: null tensor");
+    if (dtype == SV_BF16)
+        return launch_fwd_bf16(*g, dz, w, nullptr, dx, SV_ACT_NONE, 0.f, to_stream(stream), workspace, workspace_bytes);
     return launch_fwd_direct(*g, (const float*)dz, (const float*)w, nullptr, (float*)dx, SV_ACT_NONE, 0.f,
                              to_stream(stream), workspace, workspace_bytes);
 }
@@ -262,11 +285,13 @@ int sv_conv2d_transpose_dgrad_ws(const sv_conv_geom* g, const void* dz, const vo
 // layer's output gradient in the role of the conv input and the layer's input in the role of the conv's dz.
 int sv_conv2d_transpose_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate,
                               void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_conv2d_transpose_wgrad");
+    SV_F32_OR_BF16(dtype, "sv_conv2d_transpose_wgrad");
     int rc = validate_geom(g, "sv_conv2d_transpose_wgrad");
     if (rc) return rc;
     SV_REQUIRE(g->up_h == 1 && g->up_w == 1, "sv_conv2d_transpose_wgrad: folded upsampling is not defined here");
     SV_REQUIRE(x && dz && dw, "sv_conv2d_transpose_wgrad: null tensor");
+    if (dtype == SV_BF16)
+        return launch_wgrad_bf16(*g, dz, x, (float*)dw, accumulate, workspace, workspace_bytes, to_stream(stream));
     return launch_wgrad_direct(*g, (const float*)dz, (const float*)x, (float*)dw, accumulate, workspace,
                                workspace_bytes, to_stream(stream));
 }

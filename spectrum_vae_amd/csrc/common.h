@@ -39,6 +39,12 @@ inline int check_launch(const char* what) {
         if ((dtype) != SV_F32) return sv::fail(SV_E_UNSUPPORTED, name ": dtype %d unsupported", (int)(dtype)); \
     } while (0)
 
+#define SV_F32_OR_BF16(dtype, name)                                                          \
+    do {                                                                                     \
+        if ((dtype) != SV_F32 && (dtype) != SV_BF16)                                         \
+            return sv::fail(SV_E_UNSUPPORTED, name ": dtype %d unsupported", (int)(dtype));  \
+    } while (0)
+
 inline hipStream_t to_stream(sv_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -20,13 +20,22 @@ int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* 
                            float alpha, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st,
                            int accumulate);
+// conv_gemm_bf16.hip: the same three products with bf16 operands
+bool conv_gemm_bf16_ok(const sv_conv_geom& g, int mode);
+int conv_gemm_bf16_wgrad_splits(const sv_conv_geom& g);
+int launch_conv_gemm_bf16_fwd(const sv_conv_geom& g, const void* x, const void* w, const float* bias, void* y, int act,
+                              float alpha, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_conv_gemm_bf16_dgrad(const sv_conv_geom& g, const void* dz, const void* w, const float* bias, void* dx, int act,
+                                float alpha, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_conv_gemm_bf16_wgrad(const sv_conv_geom& g, const void* x, const void* dz, float* slabs, int splits,
+                                hipStream_t st, int accumulate);
 
 // ------------------------------------------------------------------------------------------------ forward
 // y[n,oh,ow,co] = act(bias[co] + sum_{kh,kw,ci} x[n, (oh*SH+kh-pt)/up_h, (ow*SW+kw-pl)/up_w, ci] * w[kh,kw,ci,co])
-template <int CO_T>
-__global__ __launch_bounds__(256) void conv2d_fwd_direct(sv_conv_geom g, const float* __restrict__ x,
-                                                         const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ y,
+template <int CO_T, typename T>
+__global__ __launch_bounds__(256) void conv2d_fwd_direct(sv_conv_geom g, const T* __restrict__ x,
+                                                         const T* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ y,
                                                          int act, float alpha) {
     const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
     const int co0 = blockIdx.y * CO_T;
@@ -46,22 +55,22 @@ __global__ __launch_bounds__(256) void conv2d_fwd_direct(sv_conv_geom g, const f
                 const int iwl = ow * g.SW + kw - g.pad_l;
                 const bool ok = okh && iwl >= 0 && iwl < g.W;
                 const int iw = ok ? iwl / g.up_w : 0;
-                const float* xp = x + (((int64_t)n * Hp + ih) * Wp + iw) * g.Cin;
-                const float* wp = w + (int64_t)(kh * g.KW + kw) * g.Cin * g.Cout + co0;
+                const T* xp = x + (((int64_t)n * Hp + ih) * Wp + iw) * g.Cin;
+                const T* wp = w + (int64_t)(kh * g.KW + kw) * g.Cin * g.Cout + co0;
                 if (ok) {
                     for (int ci = 0; ci < g.Cin; ++ci) {
-                        const float xv = xp[ci];
+                        const float xv = (float)xp[ci];
 #pragma unroll
                         for (int c = 0; c < CO_T; ++c)
-                            if (co0 + c < g.Cout) acc[c] = fmaf(xv, wp[(int64_t)ci * g.Cout + c], acc[c]);
+                            if (co0 + c < g.Cout) acc[c] = fmaf(xv, (float)wp[(int64_t)ci * g.Cout + c], acc[c]);
                     }
                 }
             }
         }
-        float* yp = y + p * g.Cout + co0;
+        T* yp = y + p * g.Cout + co0;
 #pragma unroll
         for (int c = 0; c < CO_T; ++c)
-            if (co0 + c < g.Cout) yp[c] = act_apply(acc[c], act, alpha);
+            if (co0 + c < g.Cout) yp[c] = (T)act_apply(acc[c], act, alpha);
     }
 }
 
@@ -69,10 +78,10 @@ __global__ __launch_bounds__(256) void conv2d_fwd_direct(sv_conv_geom g, const f
 // out[n,ihp,iwp,ci] = epi( sum over logical (ih,iw) mapped to this stored pixel, kh, kw, co with
 //                         (ih+pt-kh) % SH == 0:  dz[n,(ih+pt-kh)/SH,(iw+pl-kw)/SW,co] * w[kh,kw,ci,co] )
 // epi = optional bias[ci] + activation: that is the forward of Conv2DTranspose.
-template <int CI_T>
-__global__ __launch_bounds__(256) void conv2d_dgrad_direct(sv_conv_geom g, const float* __restrict__ dz,
-                                                           const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ dx,
+template <int CI_T, typename T>
+__global__ __launch_bounds__(256) void conv2d_dgrad_direct(sv_conv_geom g, const T* __restrict__ dz,
+                                                           const T* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ dx,
                                                            int act, float alpha) {
     const int Hp = g.H / g.up_h, Wp = g.W / g.up_w;
     const int64_t npix = (int64_t)g.N * Hp * Wp;
@@ -96,26 +105,26 @@ __global__ __launch_bounds__(256) void conv2d_dgrad_direct(sv_conv_geom g, const
                         const int u = iw + g.pad_l - kw;
                         const bool ok = okh && u >= 0 && (u % g.SW) == 0 && (u / g.SW) < g.Wo;
                         const int ow = ok ? u / g.SW : 0;
-                        const float* zp = dz + (((int64_t)n * g.Ho + oh) * g.Wo + ow) * g.Cout;
-                        const float* wp = w + ((int64_t)(kh * g.KW + kw) * g.Cin + ci0) * g.Cout;
+                        const T* zp = dz + (((int64_t)n * g.Ho + oh) * g.Wo + ow) * g.Cout;
+                        const T* wp = w + ((int64_t)(kh * g.KW + kw) * g.Cin + ci0) * g.Cout;
                         if (ok) {
                             for (int co = 0; co < g.Cout; ++co) {
-                                const float zv = zp[co];
+                                const float zv = (float)zp[co];
 #pragma unroll
                                 for (int c = 0; c < CI_T; ++c)
-                                    if (ci0 + c < g.Cin) acc[c] = fmaf(zv, wp[(int64_t)c * g.Cout + co], acc[c]);
+                                    if (ci0 + c < g.Cin) acc[c] = fmaf(zv, (float)wp[(int64_t)c * g.Cout + co], acc[c]);
                             }
                         }
                     }
                 }
             }
         }
-        float* op = dx + p * g.Cin + ci0;
+        T* op = dx + p * g.Cin + ci0;
 #pragma unroll
         for (int c = 0; c < CI_T; ++c)
             if (ci0 + c < g.Cin) {
                 float v = acc[c] + (bias != nullptr ? bias[ci0 + c] : 0.f);
-                op[c] = act_apply(v, act, alpha);
+                op[c] = (T)act_apply(v, act, alpha);
             }
     }
 }
@@ -126,9 +135,9 @@ __global__ __launch_bounds__(256) void conv2d_dgrad_direct(sv_conv_geom g, const
 // the result does not depend on scheduling.  SWAP exchanges the roles of the two tensors' channels in the
 // OUTPUT layout (dw[kh,kw,ci,co] vs the Conv2DTranspose layout, which is the same memory order) - unused here,
 // the transposed wrapper swaps its operands instead.
-template <int CO_T>
-__global__ __launch_bounds__(256) void conv2d_wgrad_direct(sv_conv_geom g, const float* __restrict__ x,
-                                                           const float* __restrict__ dz, float* __restrict__ part,
+template <int CO_T, typename T>
+__global__ __launch_bounds__(256) void conv2d_wgrad_direct(sv_conv_geom g, const T* __restrict__ x,
+                                                           const T* __restrict__ dz, float* __restrict__ part,
                                                            int64_t pix_per_split) {
     __shared__ float red[4 * CO_T];
     const int k = blockIdx.x;
@@ -151,11 +160,11 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct(sv_conv_geom g, const
         const int ihl = oh * g.SH + kh - g.pad_t;
         const int iwl = ow * g.SW + kw - g.pad_l;
         if (ihl < 0 || ihl >= g.H || iwl < 0 || iwl >= g.W) continue;
-        const float xv = x[(((int64_t)n * Hp + ihl / g.up_h) * Wp + iwl / g.up_w) * g.Cin + ci];
-        const float* zp = dz + p * g.Cout + co0;
+        const float xv = (float)x[(((int64_t)n * Hp + ihl / g.up_h) * Wp + iwl / g.up_w) * g.Cin + ci];
+        const T* zp = dz + p * g.Cout + co0;
 #pragma unroll
         for (int c = 0; c < CO_T; ++c)
-            if (co0 + c < g.Cout) acc[c] = fmaf(xv, zp[c], acc[c]);
+            if (co0 + c < g.Cout) acc[c] = fmaf(xv, (float)zp[c], acc[c]);
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -222,18 +231,44 @@ int validate_geom(const sv_conv_geom* g, const char* who) {
 // reduction over more workgroups.  0 when the geometry gains nothing from it.
 size_t conv_direct_scratch(const sv_conv_geom& g, int mode) { return conv_gemm_splitk_workspace(g, mode); }
 
+template <typename T>
+static void fwd_direct_any(const sv_conv_geom& g, const T* x, const T* w, const float* bias, T* y, int act, float alpha,
+                           dim3 grid, int cot, hipStream_t st) {
+    if (cot == 16)
+        hipLaunchKernelGGL((conv2d_fwd_direct<16, T>), grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
+    else if (cot == 8)
+        hipLaunchKernelGGL((conv2d_fwd_direct<8, T>), grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
+    else
+        hipLaunchKernelGGL((conv2d_fwd_direct<4, T>), grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
+}
+template <typename T>
+static void dgrad_direct_any(const sv_conv_geom& g, const T* dz, const T* w, const float* bias, T* dx, int act,
+                             float alpha, dim3 grid, int cit, hipStream_t st) {
+    if (cit == 16)
+        hipLaunchKernelGGL((conv2d_dgrad_direct<16, T>), grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
+    else if (cit == 8)
+        hipLaunchKernelGGL((conv2d_dgrad_direct<8, T>), grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
+    else
+        hipLaunchKernelGGL((conv2d_dgrad_direct<4, T>), grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
+}
+template <typename T>
+static void wgrad_direct_any(const sv_conv_geom& g, const T* x, const T* dz, float* part, int64_t pps, dim3 grid, int cot,
+                             hipStream_t st) {
+    if (cot == 16)
+        hipLaunchKernelGGL((conv2d_wgrad_direct<16, T>), grid, dim3(256), 0, st, g, x, dz, part, pps);
+    else if (cot == 8)
+        hipLaunchKernelGGL((conv2d_wgrad_direct<8, T>), grid, dim3(256), 0, st, g, x, dz, part, pps);
+    else
+        hipLaunchKernelGGL((conv2d_wgrad_direct<4, T>), grid, dim3(256), 0, st, g, x, dz, part, pps);
+}
+
 int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
                       float alpha, hipStream_t st, void* ws, size_t ws_bytes) {
     if (conv_gemm_worthwhile(g, 0)) return launch_conv_gemm_fwd(g, x, w, bias, y, act, alpha, ws, ws_bytes, st);
     const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
     const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
     dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cout, cot));
-    if (cot == 16)
-        hipLaunchKernelGGL(conv2d_fwd_direct<16>, grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
-    else if (cot == 8)
-        hipLaunchKernelGGL(conv2d_fwd_direct<8>, grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
-    else
-        hipLaunchKernelGGL(conv2d_fwd_direct<4>, grid, dim3(256), 0, st, g, x, w, bias, y, act, alpha);
+    fwd_direct_any<float>(g, x, w, bias, y, act, alpha, grid, cot, st);
     return check_launch("conv2d_fwd_direct");
 }
 
@@ -243,12 +278,7 @@ int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, 
     const int64_t npix = (int64_t)g.N * (g.H / g.up_h) * (g.W / g.up_w);
     const int cit = g.Cin >= 16 ? 16 : (g.Cin > 4 ? 8 : 4);
     dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cin, cit));
-    if (cit == 16)
-        hipLaunchKernelGGL(conv2d_dgrad_direct<16>, grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
-    else if (cit == 8)
-        hipLaunchKernelGGL(conv2d_dgrad_direct<8>, grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
-    else
-        hipLaunchKernelGGL(conv2d_dgrad_direct<4>, grid, dim3(256), 0, st, g, dz, w, bias, dx, act, alpha);
+    dgrad_direct_any<float>(g, dz, w, bias, dx, act, alpha, grid, cit, st);
     return check_launch("conv2d_dgrad_direct");
 }
 
@@ -292,13 +322,61 @@ int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, 
     const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
     dim3 grid((unsigned)(g.KH * g.KW * g.Cin), (unsigned)ceil_div(g.Cout, cot), (unsigned)ns);
     float* part = (float*)ws;
-    if (cot == 16)
-        hipLaunchKernelGGL(conv2d_wgrad_direct<16>, grid, dim3(256), 0, st, g, x, dz, part, pps);
-    else if (cot == 8)
-        hipLaunchKernelGGL(conv2d_wgrad_direct<8>, grid, dim3(256), 0, st, g, x, dz, part, pps);
-    else
-        hipLaunchKernelGGL(conv2d_wgrad_direct<4>, grid, dim3(256), 0, st, g, x, dz, part, pps);
+    wgrad_direct_any<float>(g, x, dz, part, pps, grid, cot, st);
     int rc = check_launch("conv2d_wgrad_direct");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, part, dw, kc, ns, accumulate);
+    return check_launch("wgrad_reduce");
+}
+
+// ---- bf16 storage (activations, filters, activation gradients as bf16; sums, bias and kernel gradients in f32):
+// the matrix-core kernel of conv_gemm_bf16.hip where the shape is GEMM-like, the direct kernels above otherwise.
+typedef __bf16 bf16_t;
+
+int launch_fwd_bf16(const sv_conv_geom& g, const void* x, const void* w, const float* bias, void* y, int act, float alpha,
+                    hipStream_t st, void* ws, size_t ws_bytes) {
+    if (conv_gemm_bf16_ok(g, 0)) return launch_conv_gemm_bf16_fwd(g, x, w, bias, y, act, alpha, ws, ws_bytes, st);
+    const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
+    const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
+    dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cout, cot));
+    fwd_direct_any<bf16_t>(g, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, act, alpha, grid, cot, st);
+    return check_launch("conv2d_fwd_direct<bf16>");
+}
+
+int launch_dgrad_bf16(const sv_conv_geom& g, const void* dz, const void* w, const float* bias, void* dx, int act,
+                      float alpha, hipStream_t st, void* ws, size_t ws_bytes) {
+    if (conv_gemm_bf16_ok(g, 1) && ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(w)) & 15) == 0)
+        return launch_conv_gemm_bf16_dgrad(g, dz, w, bias, dx, act, alpha, ws, ws_bytes, st);
+    const int64_t npix = (int64_t)g.N * (g.H / g.up_h) * (g.W / g.up_w);
+    const int cit = g.Cin >= 16 ? 16 : (g.Cin > 4 ? 8 : 4);
+    dim3 grid((unsigned)ew_grid(npix, 256, 1 << 16), (unsigned)ceil_div(g.Cin, cit));
+    dgrad_direct_any<bf16_t>(g, (const bf16_t*)dz, (const bf16_t*)w, bias, (bf16_t*)dx, act, alpha, grid, cit, st);
+    return check_launch("conv2d_dgrad_direct<bf16>");
+}
+
+int launch_wgrad_bf16(const sv_conv_geom& g, const void* x, const void* dz, float* dw, int accumulate, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+    const int64_t kc = (int64_t)g.KH * g.KW * g.Cin * g.Cout;
+    if (ws == nullptr || ws_bytes < wgrad_direct_workspace(g))
+        return fail(SV_E_WORKSPACE, "conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes,
+                    wgrad_direct_workspace(g));
+    if (conv_gemm_bf16_ok(g, 2)) {
+        const int splits = conv_gemm_bf16_wgrad_splits(g);
+        if (splits == 1) return launch_conv_gemm_bf16_wgrad(g, x, dz, dw, 1, st, accumulate);
+        int rc = launch_conv_gemm_bf16_wgrad(g, x, dz, (float*)ws, splits, st, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, (const float*)ws, dw, kc, splits,
+                           accumulate);
+        return check_launch("wgrad_reduce");
+    }
+    const int ns = wgrad_direct_splits(g);
+    const int64_t npix = (int64_t)g.N * g.Ho * g.Wo;
+    const int64_t pps = ceil_div(npix, ns);
+    const int cot = g.Cout >= 16 ? 16 : (g.Cout > 4 ? 8 : 4);
+    dim3 grid((unsigned)(g.KH * g.KW * g.Cin), (unsigned)ceil_div(g.Cout, cot), (unsigned)ns);
+    float* part = (float*)ws;
+    wgrad_direct_any<bf16_t>(g, (const bf16_t*)x, (const bf16_t*)dz, part, pps, grid, cot, st);
+    int rc = check_launch("conv2d_wgrad_direct<bf16>");
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, part, dw, kc, ns, accumulate);
     return check_launch("wgrad_reduce");

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT, F32, ConvGeom, NetLayer, WgradBatchJob, WgradJob, check, lib
+from ._lib import ACT, BF16, F32, ConvGeom, NetLayer, WgradBatchJob, WgradJob, check, lib
 
 
 def _stream() -> int:
@@ -29,6 +29,24 @@ def _ptr(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") -
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
     return t.data_ptr()
+
+
+def _dt(t: torch.Tensor) -> int:
+    """Storage-type code of an activation tensor: the kernels take float32 or bfloat16 activations / filters."""
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _aptr(t: Optional[torch.Tensor], like: Optional[torch.Tensor] = None, name: str = "tensor") -> Optional[int]:
+    """Pointer of an activation-typed tensor (float32 or bfloat16); ``like``: the tensor whose type it must share."""
+    if t is None:
+        return None
+    if like is not None and t.dtype != like.dtype:
+        raise TypeError(f"{name}: expected {like.dtype}, got {t.dtype}")
+    return _ptr(t, t.dtype, name)
 
 
 # --------------------------------------------------------------------------- geometry (host logic, GPU-free)
@@ -82,13 +100,14 @@ def _ws_args(ws):
 
 
 def conv2d_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float, ws=None):
-    check(lib.sv_conv2d_fwd_ws(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha, *_ws_args(ws), F32,
-                               _stream()), "sv_conv2d_fwd_ws")
+    """x, w, y float32 or all bfloat16 (bias stays float32)."""
+    check(lib.sv_conv2d_fwd_ws(C.byref(g), _aptr(x), _aptr(w, x, "w"), _ptr(bias), _aptr(y, x, "y"), ACT[act], alpha,
+                               *_ws_args(ws), _dt(x), _stream()), "sv_conv2d_fwd_ws")
 
 
 def conv2d_dgrad(g: ConvGeom, dz, w, dx, ws=None):
-    check(lib.sv_conv2d_dgrad_ws(C.byref(g), _ptr(dz), _ptr(w), _ptr(dx), *_ws_args(ws), F32, _stream()),
-          "sv_conv2d_dgrad_ws")
+    check(lib.sv_conv2d_dgrad_ws(C.byref(g), _aptr(dz), _aptr(w, dz, "w"), _aptr(dx, dz, "dx"), *_ws_args(ws), _dt(dz),
+                                 _stream()), "sv_conv2d_dgrad_ws")
 
 
 def conv2d_wgrad_workspace(g: ConvGeom) -> int:
@@ -96,8 +115,9 @@ def conv2d_wgrad_workspace(g: ConvGeom) -> int:
 
 
 def conv2d_wgrad(g: ConvGeom, x, dz, dw, accumulate: bool, ws: torch.Tensor):
-    check(lib.sv_conv2d_wgrad(C.byref(g), _ptr(x), _ptr(dz), _ptr(dw), int(accumulate), _ptr(ws, torch.uint8),
-                              ws.numel(), F32, _stream()), "sv_conv2d_wgrad")
+    """x, dz float32 or both bfloat16; dw is always float32."""
+    check(lib.sv_conv2d_wgrad(C.byref(g), _aptr(x), _aptr(dz, x, "dz"), _ptr(dw), int(accumulate), _ptr(ws, torch.uint8),
+                              ws.numel(), _dt(x), _stream()), "sv_conv2d_wgrad")
 
 
 def static_scratch_bytes() -> int:
@@ -190,18 +210,18 @@ def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float
 
 
 def conv2d_transpose_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float, ws=None):
-    check(lib.sv_conv2d_transpose_fwd_ws(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha,
-                                         *_ws_args(ws), F32, _stream()), "sv_conv2d_transpose_fwd_ws")
+    check(lib.sv_conv2d_transpose_fwd_ws(C.byref(g), _aptr(x), _aptr(w, x, "w"), _ptr(bias), _aptr(y, x, "y"), ACT[act],
+                                         alpha, *_ws_args(ws), _dt(x), _stream()), "sv_conv2d_transpose_fwd_ws")
 
 
 def conv2d_transpose_dgrad(g: ConvGeom, dz, w, dx, ws=None):
-    check(lib.sv_conv2d_transpose_dgrad_ws(C.byref(g), _ptr(dz), _ptr(w), _ptr(dx), *_ws_args(ws), F32, _stream()),
-          "sv_conv2d_transpose_dgrad_ws")
+    check(lib.sv_conv2d_transpose_dgrad_ws(C.byref(g), _aptr(dz), _aptr(w, dz, "w"), _aptr(dx, dz, "dx"), *_ws_args(ws),
+                                           _dt(dz), _stream()), "sv_conv2d_transpose_dgrad_ws")
 
 
 def conv2d_transpose_wgrad(g: ConvGeom, x, dz, dw, accumulate: bool, ws: torch.Tensor):
-    check(lib.sv_conv2d_transpose_wgrad(C.byref(g), _ptr(x), _ptr(dz), _ptr(dw), int(accumulate),
-                                        _ptr(ws, torch.uint8), ws.numel(), F32, _stream()),
+    check(lib.sv_conv2d_transpose_wgrad(C.byref(g), _aptr(x), _aptr(dz, x, "dz"), _ptr(dw), int(accumulate),
+                                        _ptr(ws, torch.uint8), ws.numel(), _dt(x), _stream()),
           "sv_conv2d_transpose_wgrad")
 
 
