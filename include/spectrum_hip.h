@@ -15,8 +15,12 @@
  *    calling thread's last failure;
  *  - activations are NHWC, Conv2D kernels HWIO (kh,kw,Cin,Cout), Conv2DTranspose kernels
  *    (kh,kw,Cout,Cin), Dense kernels (in,out): the tf.keras layouts;
- *  - `dtype` selects the storage type of activations/weights (SV_F32; SV_BF16 where the
- *    declaration says so); accumulation is always f32.
+ *  - `dtype` selects the storage type of activations, filters and activation gradients: SV_F32 everywhere, SV_BF16 in
+ *    the strided / transposed conv family (sv_conv2d_{fwd,dgrad,wgrad}[_ws], sv_conv2d_transpose_*, sv_conv2d_wgrad_static),
+ *    sv_act_*, sv_bias_grad, sv_batchnorm_*, sv_concat_channels_*, sv_axpy, sv_mask_input_dt and the losses (prediction
+ *    and its gradient; targets, masks and weights stay f32).  Sums are always f32; biases, BatchNorm parameters and
+ *    statistics, loss values and every kernel / bias gradient (dw, db, dgamma, dbeta) are f32 in both modes: the master
+ *    weights and the Adam step stay f32, a bf16 model keeps a bf16 copy of its filters (sv_cast_f32_bf16).
  */
 #ifndef SPECTRUM_HIP_H
 #define SPECTRUM_HIP_H
@@ -317,8 +321,13 @@ int sv_gather_rows(const void* src, int src_is_f64, const int64_t* idx, float* d
                    int64_t row_elems, sv_stream_t stream);
 /* y = x * (1 - mask) (run_context_encoder.py:242) */
 int sv_mask_input(const float* x, const float* mask, float* y, int64_t n, sv_stream_t stream);
+/* the same with y in the storage type `dtype` (the masked input of a bf16 model) */
+int sv_mask_input_dt(const float* x, const float* mask, void* y, int64_t n, int dtype, sv_stream_t stream);
 int sv_fill_f32(float* p, float value, int64_t n, sv_stream_t stream);
 int sv_axpy_f32(float* y, const float* x, float a, int64_t n, sv_stream_t stream); /* y += a*x */
+/* y += a*x on activation-typed tensors (the sum of the gradients arriving over a skip connection, unet.py:144, and of the
+ * two loss terms' gradients in run_unet.py:164-203) */
+int sv_axpy(void* y, const void* x, float a, int64_t n, int dtype, sv_stream_t stream);
 int sv_cast_f32_bf16(const float* x, void* y, int64_t n, sv_stream_t stream);
 int sv_cast_bf16_f32(const void* x, float* y, int64_t n, sv_stream_t stream);
 

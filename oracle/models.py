@@ -272,23 +272,24 @@ class RefUNet:
     final Conv2DTranspose to OUTPUT_CHANNELS with tanh and bias (built once here;
     the reference rebuilds it on every call, which re-initialises it)."""
 
-    def __init__(self, input_shape=(32, 32, 1), kernel=(2, 2), stride=(2, 2), seed=1833, dtype=torch.float32):
+    def __init__(self, input_shape=(32, 32, 1), kernel=(2, 2), stride=(2, 2), seed=1833, dtype=torch.float32,
+                 lowp: bool = False):
         self.blocks: List[RefSequential] = []
         shape = tuple(input_shape)
         down_shapes = []
         for i in range(4):
-            blk = RefSequential(unet_down_block(64, kernel, stride), shape, dtype, seed + i)
+            blk = RefSequential(unet_down_block(64, kernel, stride), shape, dtype, seed + i, lowp=lowp)
             self.blocks.append(blk)
             shape = blk.output_shape
             down_shapes.append(shape)
         skips = down_shapes[:-1][::-1]
         for i in range(3):
-            blk = RefSequential(unet_up_block(64, kernel, stride), shape, dtype, seed + 10 + i)
+            blk = RefSequential(unet_up_block(64, kernel, stride), shape, dtype, seed + 10 + i, lowp=lowp)
             self.blocks.append(blk)
             shape = blk.output_shape
             shape = (shape[0], shape[1], shape[2] + skips[i][2])
         final = [_convT(OUTPUT_CHANNELS, kernel, "tanh", "same", strides=stride, init="normal0.02")]
-        self.final = RefSequential(final, shape, dtype, seed + 20)
+        self.final = RefSequential(final, shape, dtype, seed + 20, lowp=lowp)
         self.blocks.append(self.final)
         self.output_shape = self.final.output_shape
 

@@ -88,6 +88,37 @@ def upsample_nchw(x, size):
     return x.repeat_interleave(size[0], dim=2).repeat_interleave(size[1], dim=3)
 
 
+# --------------------------------------------------------------------------- bf16 storage emulation
+class _RoundBoth(torch.autograd.Function):
+    """A tensor that the bf16 engine writes to memory: the value is rounded to bfloat16 on the way forward and its
+    gradient is rounded to bfloat16 on the way back (both are stored as bf16 there)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """A float32 master weight read through its bf16 copy: rounded forward, gradient passed through unrounded (kernel
+    gradients are accumulated and stored as float32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_act(x):
+    return _RoundBoth.apply(x)
+
+
 # --------------------------------------------------------------------------- losses (R12)
 def mse(y_true, y_pred):
     return torch.mean((y_pred - y_true) ** 2)
@@ -123,7 +154,11 @@ class RefSequential:
     are flat lists of tensors."""
 
     def __init__(self, layers: Sequence[dict], input_shape: Sequence[int], dtype=torch.float32,
-                 seed: int = 1833, bn_unbiased_moving_var: bool = True):
+                 seed: int = 1833, bn_unbiased_moving_var: bool = True, lowp: bool = False):
+        # lowp: restate the bf16 policy of the engine - every tensor it stores as bfloat16 (the input, each layer's
+        # output, each gradient flowing between layers, the filters the convs read) is rounded at that point, while
+        # the arithmetic in between stays in ``dtype`` (pass float64: the engine's float32 sums are exact by comparison)
+        self.lowp = bool(lowp)
         self.layers = [dict(l) for l in layers]
         self.input_shape = tuple(int(v) for v in input_shape)
         self.dtype = dtype
@@ -222,16 +257,20 @@ class RefSequential:
         spatial = x.dim() == 4
         if spatial:
             x = x.permute(0, 3, 1, 2)  # NCHW internally
+        lowp = self.lowp
+        wq = (lambda w: _RoundFwd.apply(w)) if lowp else (lambda w: w)
+        if lowp:
+            x = round_act(x)
         for li, l in enumerate(self.layers):
             t = l["type"]
             p = l["_p"]
             if t == "conv2d":
                 b = self.params[p + 1] if l.get("use_bias", True) else None
-                x = conv2d_nchw(x, self.params[p], b, l.get("strides", (1, 1)), l["padding"])
+                x = conv2d_nchw(x, wq(self.params[p]), b, l.get("strides", (1, 1)), l["padding"])
                 x = _act(x, l.get("activation"), l.get("alpha", 0.2))
             elif t == "conv2d_transpose":
                 b = self.params[p + 1] if l.get("use_bias", True) else None
-                x = conv2d_transpose_nchw(x, self.params[p], b, l.get("strides", (1, 1)), l["padding"])
+                x = conv2d_transpose_nchw(x, wq(self.params[p]), b, l.get("strides", (1, 1)), l["padding"])
                 x = _act(x, l.get("activation"), l.get("alpha", 0.2))
             elif t == "maxpool":
                 x = maxpool_nchw(x, l["pool"], l.get("padding", "valid"))
@@ -267,6 +306,8 @@ class RefSequential:
                 spatial = False
             else:
                 raise ValueError(t)
+            if lowp and t in ("conv2d", "conv2d_transpose", "batchnorm", "leakyrelu", "activation"):
+                x = round_act(x)
             if taps is not None:
                 taps[li] = x.permute(0, 2, 3, 1) if (spatial and x.dim() == 4) else x
         if spatial and x.dim() == 4:

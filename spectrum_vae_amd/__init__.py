@@ -6,7 +6,7 @@ C ABI in ``include/spectrum_hip.h``).  Importing the package loads that library 
 missing: there is no fallback backend.
 """
 from . import _lib  # noqa: F401  (loads libspectrum_hip.so or raises)
-from . import autoencoder, context_encoder, global_vars, losses, nn, optimizers, unet  # noqa: F401
+from . import autoencoder, context_encoder, global_vars, losses, mixed_precision, nn, optimizers, unet  # noqa: F401
 from .model import EarlyStopping, History, Model  # noqa: F401
 
 __all__ = ["autoencoder", "context_encoder", "unet", "global_vars", "losses", "optimizers", "nn", "Model",

@@ -112,6 +112,8 @@ SIGNATURES = {
     "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),
     "sv_gather_rows": (_i, [_p, _i, _p, _p, _i64, _i64, _p]),
     "sv_mask_input": (_i, [_p, _p, _p, _i64, _p]),
+    "sv_mask_input_dt": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "sv_axpy": (_i, [_p, _p, _f, _i64, _i, _p]),
     "sv_fill_f32": (_i, [_p, _f, _i64, _p]),
     "sv_process_regions": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _i64, _p, _p, _p, _p]),
     "sv_sort_min_diff": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p]),

@@ -435,9 +435,14 @@ int conv_gemm_wgrad_splits(const sv_conv_geom& g) {
     return (int)s;
 }
 
+size_t conv_gemm_bf16_wgrad_workspace(const sv_conv_geom& g);  // conv_gemm_bf16.hip
+
+// One query serves both storage types (the entry point does not know the dtype): the larger of the two kernels' needs.
 size_t conv_gemm_wgrad_workspace(const sv_conv_geom& g) {
     if (!conv_gemm_worthwhile(g, GEMM_WGRAD)) return 0;
-    return (size_t)conv_gemm_wgrad_splits(g) * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
+    const size_t f32 = (size_t)conv_gemm_wgrad_splits(g) * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
+    const size_t b16 = conv_gemm_bf16_wgrad_workspace(g);
+    return f32 > b16 ? f32 : b16;
 }
 
 static void fill_common(ConvGemmArgs& p, const sv_conv_geom& g, int mode) {

@@ -6,7 +6,9 @@
 //   input gradient  dX[(n,ih,iw)][ci]  = sum_k dZ(n, (ih+pt-kh)/SH, (iw+pl-kw)/SW, co) * W[kh][kw][ci][co], k = (kh,kw,co)
 //   kernel gradient dW[(kh,kw,ci)][co] = sum_r X(...) * dZ[r][co],   r = (n,oh,ow), split over workgroups (f32 slabs)
 //
-// A workgroup (4 waves) owns a 64 x 64 (or 64 x 16) tile of the result and walks the reduction in steps of 64.  Both
+// A workgroup (4 waves) owns a BM x BNT tile of the result (128 x 128, 128 x 64, 64 x 64 or 64 x 16: at these channel
+// counts the kernel is bound by the operand traffic between L2 and the CUs, which falls with the tile edge) and walks the
+// reduction in steps of 64.  Both
 // operands are gathered from the NHWC / HWIO tensors in 16-byte pieces (8 channels) into registers one step ahead, then
 // dropped into one of two kinds of LDS image:
 //   ROW image [row][64 k]   - the operand's reduction index is contiguous in memory (x in the forward, dz and w in the
@@ -46,7 +48,7 @@ struct ConvGemmBf16Args {
     int va, vb;         // the A / B operand can be gathered in 16-byte pieces (channel count % 8 == 0, 16-byte aligned base)
 };
 
-constexpr int BBM = 64, BBK = 64;
+constexpr int BBK = 64;
 
 // ---- LDS images (byte offsets) -----------------------------------------------------------------------------------------
 // ROW image: 128-byte rows of 64 k; 16-byte chunk c of row r sits at chunk c ^ (r & 7).
@@ -84,16 +86,20 @@ __device__ __forceinline__ void put_elem(uint4& v, int e, unsigned short bits) {
     w[e >> 1] |= (uint32_t)bits << ((e & 1) * 16);
 }
 
-// BNT: columns of the result tile (64: waves 2 x 2, each 32 x 32;  16: waves 4 x 1, each 16 x 16).
-template <int MODE, int BNT>
+// BBM x BNT: the result tile.  BNT >= 64: the waves sit 2 x 2, each on (BBM / 2) x (BNT / 2);  BNT == 16: 4 x 1, each on
+// (BBM / 4) x 16.  Images wider than 64 columns are kept as side-by-side 64-column images.
+template <int MODE, int BBM, int BNT>
 __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
-    constexpr int WAVES_N = BNT == 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    constexpr int WAVES_N = BNT >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int TI = BBM / WAVES_M / 16, TJ = BNT / WAVES_N / 16;
-    constexpr int NBQ = BNT == 64 ? 2 : 1;  // 16-byte B pieces per thread and step (BNT == 16: threads 0..127 only)
-    // A image 8 KiB; B image 8 KiB (BNT 64) or 2 KiB; the epilogue's bf16 output tile (pitch 72 columns) reuses both
-    __shared__ __attribute__((aligned(16))) unsigned char smem[BNT == 64 ? 16384 : 10240];
+    constexpr int NAQ = BBM / 32;                   // 16-byte A pieces per thread and step
+    constexpr int NBQ = BNT >= 64 ? BNT / 32 : 1;   // 16-byte B pieces per thread and step (BNT == 16: threads 0..127 only)
+    constexpr int A_BYTES = BBM * 128, B_BYTES = BNT >= 64 ? BNT * 128 : 2048;
+    constexpr int CP = BNT + 8;                     // pitch (columns) of the epilogue's bf16 output tile, which reuses the images
+    constexpr int C_BYTES = BBM * CP * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES > C_BYTES ? A_BYTES + B_BYTES : C_BYTES];
     unsigned char* As = smem;
-    unsigned char* Bs = smem + 8192;
+    unsigned char* Bs = smem + A_BYTES;
     const sv_conv_geom& g = p.g;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -157,11 +163,12 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
     // ---- per-thread bookkeeping of the gathers.  Piece q = t + 256 i (i = 0, 1): image row q >> 3, 16-byte chunk q & 7.
     // ROW images (FWD / DGRAD A): image row = result row;  TR images (WGRAD A, B; FWD B): image row = reduction index.
     const int qc = t & 7;  // chunk of every piece of this thread
-    int r_img[2], r_h[2], r_w[2];
-    bool r_ok[2];
+    constexpr int NRW = MODE == BGEMM_WGRAD ? 1 : NAQ;  // result rows this thread gathers A for
+    int r_img[NRW], r_h[NRW], r_w[NRW];
+    bool r_ok[NRW];
     if (MODE == BGEMM_FWD) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NAQ; ++i) {
             const int m = m0 + (t >> 3) + 32 * i;
             r_ok[i] = m < p.M;
             const int mm = r_ok[i] ? m : 0;
@@ -172,22 +179,27 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
         }
     } else if (MODE == BGEMM_DGRAD) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NAQ; ++i) {
             const int rl = (t >> 3) + 32 * i;
             r_img[i] = row_img[rl]; r_h[i] = row_h[rl]; r_w[i] = row_w[rl];
             r_ok[i] = r_img[i] >= 0;
         }
     }
-    // WGRAD: this thread's 8 result rows m = m0 + 8 qc .. + 7 share a tap when the A operand is vectorised
-    int a_kh = 0, a_kw = 0, a_ci = 0;
-    bool a_ok = true;
+    // WGRAD: piece i of this thread covers reduction row (t >> 3) + 32 (i & 1) and the 8 result rows
+    // m = m0 + 64 (i >> 1) + 8 qc .. + 7, which share a tap when the A operand is vectorised
+    constexpr int NAM = MODE == BGEMM_WGRAD ? BBM / 64 : 1;
+    int a_kh[NAM], a_kw[NAM], a_ci[NAM];
+    bool a_ok[NAM];
     if (MODE == BGEMM_WGRAD) {
-        const int m = m0 + 8 * qc;
-        a_ok = m < p.M;
-        const int tap = a_ok ? fd(m, p.f_ck) : 0;
-        a_ci = a_ok ? m - tap * g.Cin : 0;
-        a_kh = fd(tap, p.f_kw);
-        a_kw = tap - a_kh * g.KW;
+#pragma unroll
+        for (int s = 0; s < NAM; ++s) {
+            const int m = m0 + 64 * s + 8 * qc;
+            a_ok[s] = m < p.M;
+            const int tap = a_ok[s] ? fd(m, p.f_ck) : 0;
+            a_ci[s] = a_ok[s] ? m - tap * g.Cin : 0;
+            a_kh[s] = fd(tap, p.f_kw);
+            a_kw[s] = tap - a_kh[s] * g.KW;
+        }
     }
 
     v4f_b acc[TI][TJ];
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
     };
 
     // global -> registers for one reduction step (issued one step ahead of its use)
-    auto gather = [&](int k0, uint4 (&av)[2], uint4 (&bv)[NBQ]) {
+    auto gather = [&](int k0, uint4 (&av)[NAQ], uint4 (&bv)[NBQ]) {
         // ------------------------------------------------------------------ A
         if (MODE == BGEMM_FWD) {
             const int kt = k0 + 8 * qc;
@@ -221,14 +233,14 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
                 int kh, kw, ci;
                 fwd_tap(kok ? kt : 0, kh, kw, ci);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NAQ; ++i) {
                     const int ih = r_h[i] * g.SH - g.pad_t + kh, iw = r_w[i] * g.SW - g.pad_l + kw;
                     const bool ok = kok && r_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
                     av[i] = ld16(p.a + (((int64_t)r_img[i] * g.H + ih) * g.W + iw) * g.Cin + ci, ok);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) av[i] = make_uint4(0u, 0u, 0u, 0u);
+                for (int i = 0; i < NAQ; ++i) av[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int k = kt + e;
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
                     int kh, kw, ci;
                     fwd_tap(kok ? k : 0, kh, kw, ci);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < NAQ; ++i) {
                         const int ih = r_h[i] * g.SH - g.pad_t + kh, iw = r_w[i] * g.SW - g.pad_l + kw;
                         const bool ok = kok && r_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
                         if (ok) put_elem(av[i], e, bf_bits(p.a[(((int64_t)r_img[i] * g.H + ih) * g.W + iw) * g.Cin + ci]));
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
             int kh, kw, co;
             dgrad_tap(kok ? kt : 0, kh, kw, co);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NAQ; ++i) {
                 const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
                 const int oh = th / g.SH, ow = tw / g.SW;  // exact by construction of the class
                 const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo;
@@ -257,22 +269,23 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = k0 + (t >> 3) + 32 * i;
+            for (int i = 0; i < NAQ; ++i) {
+                const int r = k0 + (t >> 3) + 32 * (i & 1);
+                const int sm = i >> 1;  // which 64-row group of the tile
                 const bool rok = r < kend;
                 const int rr = rok ? r : 0;
                 const int img = fd(rr, p.f_howo);
                 const int rem = rr - img * p.f_howo.d;
                 const int oh = fd(rem, p.f_wo), ow = rem - oh * p.f_wo.d;
                 if (p.va) {
-                    const int ih = oh * g.SH - g.pad_t + a_kh, iw = ow * g.SW - g.pad_l + a_kw;
-                    const bool ok = rok && a_ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                    av[i] = ld16(p.a + (((int64_t)img * g.H + ih) * g.W + iw) * g.Cin + a_ci, ok);
+                    const int ih = oh * g.SH - g.pad_t + a_kh[sm], iw = ow * g.SW - g.pad_l + a_kw[sm];
+                    const bool ok = rok && a_ok[sm] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+                    av[i] = ld16(p.a + (((int64_t)img * g.H + ih) * g.W + iw) * g.Cin + a_ci[sm], ok);
                 } else {
                     av[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int m = m0 + 8 * qc + e;
+                        const int m = m0 + 64 * sm + 8 * qc + e;
                         const bool mok = m < p.M;
                         const int tap = fd(mok ? m : 0, p.f_ck);
                         const int ci = (mok ? m : 0) - tap * g.Cin;
@@ -300,11 +313,11 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
         } else {  // TR image [k][n]: FWD w[k][n], WGRAD dz[r][n]; n contiguous in memory
 #pragma unroll
             for (int i = 0; i < NBQ; ++i) {
-                const int kr = BNT == 64 ? (t >> 3) + 32 * i : (t >> 1);
-                const int c8 = BNT == 64 ? qc : (t & 1);
+                const int kr = BNT >= 64 ? (t >> 3) + 32 * (i & 1) : (t >> 1);
+                const int c8 = BNT >= 64 ? 8 * (i >> 1) + qc : (t & 1);
                 const int k = k0 + kr;
                 const int n = n0 + 8 * c8;
-                const bool live = (BNT == 64 || t < 128) && k < kend;
+                const bool live = (BNT >= 64 || t < 128) && k < kend;
                 if (p.vb) {
                     bv[i] = ld16(p.b + (int64_t)k * p.N + n, live && n + 8 <= p.N);
                 } else {
@@ -317,14 +330,14 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
         }
     };
 
-    uint4 av[2], bv[NBQ];
+    uint4 av[NAQ], bv[NBQ];
     if (kbeg < kend) gather(kbeg, av, bv);
     for (int k0 = kbeg; k0 < kend; k0 += BBK) {
         __syncthreads();  // the previous step's fragment reads are done
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ir = (t >> 3) + 32 * i;
-            const int off = MODE == BGEMM_WGRAD ? tr64_off(ir, 8 * qc) : row_off(ir, qc);
+        for (int i = 0; i < NAQ; ++i) {
+            const int off = MODE == BGEMM_WGRAD ? 8192 * (i >> 1) + tr64_off((t >> 3) + 32 * (i & 1), 8 * qc)
+                                                : row_off((t >> 3) + 32 * i, qc);
             *reinterpret_cast<uint4*>(As + off) = av[i];
         }
 #pragma unroll
@@ -332,8 +345,8 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
             if (MODE == BGEMM_DGRAD) {
                 const int nl = (t >> 3) + 32 * i;
                 if (nl < BNT) *reinterpret_cast<uint4*>(Bs + row_off(nl, qc)) = bv[i];
-            } else if (BNT == 64) {
-                *reinterpret_cast<uint4*>(Bs + tr64_off((t >> 3) + 32 * i, 8 * qc)) = bv[i];
+            } else if (BNT >= 64) {
+                *reinterpret_cast<uint4*>(Bs + 8192 * (i >> 1) + tr64_off((t >> 3) + 32 * (i & 1), 8 * qc)) = bv[i];
             } else if (t < 128) {
                 *reinterpret_cast<uint4*>(Bs + tr16_off(t >> 1, 8 * (t & 1))) = bv[i];
             }
@@ -345,13 +358,16 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
             v8bf a[TI], b[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                if (MODE == BGEMM_WGRAD) a[i] = tr_frag<64>(As, kk, lk, li, wm + 16 * i);
-                else a[i] = *reinterpret_cast<const v8bf*>(As + row_off(wm + 16 * i + li, 4 * kk + lk));
+                const int c0 = wm + 16 * i;
+                if (MODE == BGEMM_WGRAD) a[i] = tr_frag<64>(As + 8192 * (c0 >> 6), kk, lk, li, c0 & 63);
+                else a[i] = *reinterpret_cast<const v8bf*>(As + row_off(c0 + li, 4 * kk + lk));
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                if (MODE == BGEMM_DGRAD) b[j] = *reinterpret_cast<const v8bf*>(Bs + row_off(wn + 16 * j + li, 4 * kk + lk));
-                else b[j] = tr_frag<BNT>(Bs, kk, lk, li, wn + 16 * j);
+                const int c0 = wn + 16 * j;
+                if (MODE == BGEMM_DGRAD) b[j] = *reinterpret_cast<const v8bf*>(Bs + row_off(c0 + li, 4 * kk + lk));
+                else if (BNT >= 64) b[j] = tr_frag<64>(Bs + 8192 * (c0 >> 6), kk, lk, li, c0 & 63);
+                else b[j] = tr_frag<16>(Bs, kk, lk, li, c0);
             }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -387,9 +403,8 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
             }
         return;
     }
-    // bias + activation, rounded to bf16 into an LDS tile [row][BNT] (pitch 72 columns), then 16-byte stores of whole
-    // channel runs
-    constexpr int CP = 72;
+    // bias + activation, rounded to bf16 into an LDS tile [row][BNT] (pitch BNT + 8 columns), then 16-byte stores of
+    // whole channel runs
     __syncthreads();  // all fragment reads of the last step are done: the tile may overwrite the images
     bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
 #pragma unroll
@@ -448,14 +463,13 @@ __global__ __launch_bounds__(256) void splitk_finish_bf16_k(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
-// conv_gemm.hip: shape test and split counts of the f32 kernel.  The bf16 kernel never cuts a reduction finer than the
-// f32 one does, so the workspace sizes that sv_conv2d_scratch_bytes / sv_conv2d_wgrad_workspace_bytes report cover both.
+// conv_gemm.hip: shape test and split counts of the f32 kernel.  Cut reductions (few result tiles) always run on 64-row
+// tiles here, as there, and never finer than the f32 kernel cuts them, so sv_conv2d_scratch_bytes covers both kernels;
+// the kernel-gradient workspace query takes the larger of the two kernels' needs (conv_gemm_bf16_wgrad_workspace).
 bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode);
 int conv_gemm_splits(const sv_conv_geom& g, int mode);
-int conv_gemm_wgrad_splits(const sv_conv_geom& g);
 size_t conv_gemm_splitk_workspace(const sv_conv_geom& g, int mode);
 
-static int tile_cols_b(int ncols) { return ncols <= 16 ? 16 : 64; }
 static bool aligned16b(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // The input-gradient product gathers both operands along Cout in 16-byte pieces: it needs Cout % 8 == 0.
@@ -463,6 +477,18 @@ bool conv_gemm_bf16_ok(const sv_conv_geom& g, int mode) {
     if (!conv_gemm_worthwhile(g, mode)) return false;
     if (mode == BGEMM_DGRAD && (g.Cout & 7) != 0) return false;
     return true;
+}
+
+// Result tile for `rows` x `ncols` results in `zmult` independent groups (row classes, reduction splits): the largest
+// tile that still leaves every CU more than one workgroup.
+struct TileSel {
+    int bm, bnt;
+};
+static TileSel pick_tile(int64_t rows, int ncols, int64_t zmult) {
+    if (ncols <= 16) return {64, 16};
+    if (ncols > 64 && ceil_div(rows, 128) * ceil_div(ncols, 128) * zmult >= 384) return {128, 128};
+    if (ceil_div(rows, 128) * ceil_div(ncols, 64) * zmult >= 384) return {128, 64};
+    return {64, 64};
 }
 
 static int bf16_splits(const sv_conv_geom& g, int mode, int64_t kdim) {
@@ -483,9 +509,12 @@ static void fill_common_b(ConvGemmBf16Args& p, const sv_conv_geom& g, int mode) 
 }
 
 template <int MODE>
-static void launch_b(const ConvGemmBf16Args& p, dim3 grid, int bnt, hipStream_t st) {
-    if (bnt == 64) hipLaunchKernelGGL((conv_gemm_bf16<MODE, 64>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_gemm_bf16<MODE, 16>), grid, dim3(256), 0, st, p);
+static void launch_b(const ConvGemmBf16Args& p, int64_t rows, int64_t zdim, TileSel ts, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(rows, ts.bm), (unsigned)ceil_div(p.N, ts.bnt), (unsigned)zdim);
+    if (ts.bm == 128 && ts.bnt == 128) hipLaunchKernelGGL((conv_gemm_bf16<MODE, 128, 128>), grid, dim3(256), 0, st, p);
+    else if (ts.bm == 128) hipLaunchKernelGGL((conv_gemm_bf16<MODE, 128, 64>), grid, dim3(256), 0, st, p);
+    else if (ts.bnt == 64) hipLaunchKernelGGL((conv_gemm_bf16<MODE, 64, 64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_gemm_bf16<MODE, 64, 16>), grid, dim3(256), 0, st, p);
 }
 
 static int finish_b(const ConvGemmBf16Args& p, hipStream_t st) {
@@ -509,9 +538,8 @@ int launch_conv_gemm_bf16_fwd(const sv_conv_geom& g, const void* x, const void* 
         p.splits = bf16_splits(g, BGEMM_FWD, p.K);
         p.cf = (float*)ws;
     }
-    const int bnt = tile_cols_b(p.N);
-    dim3 grid((unsigned)ceil_div(p.M, BBM), (unsigned)ceil_div(p.N, bnt), (unsigned)p.splits);
-    launch_b<BGEMM_FWD>(p, grid, bnt, st);
+    const TileSel ts = p.splits > 1 ? TileSel{64, p.N <= 16 ? 16 : 64} : pick_tile(p.M, p.N, 1);
+    launch_b<BGEMM_FWD>(p, p.M, p.splits, ts, st);
     int rc = check_launch("conv_gemm_bf16<fwd>");
     if (rc || p.splits == 1) return rc;
     return finish_b(p, st);
@@ -542,21 +570,52 @@ int launch_conv_gemm_bf16_dgrad(const sv_conv_geom& g, const void* dz, const voi
         p.splits = bf16_splits(g, BGEMM_DGRAD, kclass);
         p.cf = (float*)ws;
     }
-    const int bnt = tile_cols_b(p.N);
-    dim3 grid((unsigned)ceil_div(rows, BBM), (unsigned)ceil_div(p.N, bnt), (unsigned)(classes * p.splits));
-    launch_b<BGEMM_DGRAD>(p, grid, bnt, st);
+    const TileSel ts = p.splits > 1 ? TileSel{64, p.N <= 16 ? 16 : 64} : pick_tile(rows, p.N, classes);
+    launch_b<BGEMM_DGRAD>(p, rows, (int64_t)classes * p.splits, ts, st);
     int rc = check_launch("conv_gemm_bf16<dgrad>");
     if (rc || p.splits == 1) return rc;
     return finish_b(p, st);
 }
 
-// Reduction splits of the bf16 kernel gradient: never more than the f32 kernel's (the workspace query is shared).
-int conv_gemm_bf16_wgrad_splits(const sv_conv_geom& g) {
-    int s = conv_gemm_wgrad_splits(g);
-    const int64_t R = (int64_t)g.N * g.Ho * g.Wo;
+// Kernel gradient: result (kh, kw, ci) x co, reduction over the pixels, cut into `splits` ranges so that the launch has
+// about 512 workgroups; each range leaves a float32 slab.
+struct WgradSel {
+    TileSel ts;
+    int splits;
+};
+static WgradSel bf16_wgrad_plan(const sv_conv_geom& g) {
+    const int64_t M = (int64_t)g.KH * g.KW * g.Cin, R = (int64_t)g.N * g.Ho * g.Wo;
+    const int N = g.Cout;
+    WgradSel w;
+    // A result with many tiles is not cut at all (each tile goes straight into dw): then the largest tile that still gives
+    // every CU a workgroup.  Otherwise the largest tile whose cut reduction keeps at least four steps per workgroup at
+    // about 512 workgroups.
+    const TileSel cands[3] = {{128, 128}, {128, 64}, {64, 64}};
+    w.ts = TileSel{64, N <= 16 ? 16 : 64};
+    if (N > 16) {
+        const bool uncut = ceil_div(M, 64) * ceil_div(N, 64) >= 384;
+        for (const TileSel& c : cands) {
+            if (c.bnt == 128 && N <= 64) continue;
+            if (c.bm == 128 && M <= 64) continue;
+            const int64_t tiles = ceil_div(M, c.bm) * ceil_div(N, c.bnt);
+            if (uncut ? tiles >= 256 : ceil_div(512, tiles) * 4 * BBK <= R) { w.ts = c; break; }
+        }
+    }
+    const int64_t tiles = ceil_div(M, w.ts.bm) * ceil_div(N, w.ts.bnt);
+    int64_t s = ceil_div(512, tiles);
     const int64_t maxs = ceil_div(R, 2 * BBK);
-    if (s > maxs) s = (int)maxs;
-    return s < 1 ? 1 : s;
+    if (s > maxs) s = maxs;
+    if (s < 1 || (N > 16 && ceil_div(M, 64) * ceil_div(N, 64) >= 384)) s = 1;
+    if (s > 1024) s = 1024;
+    w.splits = (int)s;
+    return w;
+}
+
+int conv_gemm_bf16_wgrad_splits(const sv_conv_geom& g) { return bf16_wgrad_plan(g).splits; }
+
+size_t conv_gemm_bf16_wgrad_workspace(const sv_conv_geom& g) {
+    if (!conv_gemm_worthwhile(g, BGEMM_WGRAD)) return 0;
+    return (size_t)bf16_wgrad_plan(g).splits * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
 }
 
 // splits > 1: slabs only, the caller sums them (wgrad_reduce); splits == 1: `slabs` is dw itself (accumulate applies)
@@ -571,9 +630,7 @@ int launch_conv_gemm_bf16_wgrad(const sv_conv_geom& g, const void* x, const void
     p.vb = (g.Cout & 7) == 0 && aligned16b(dz);
     p.k_per_split = (int)(ceil_div(ceil_div(p.K, splits), BBK) * BBK);
     p.splits = 1;
-    const int bnt = tile_cols_b(p.N);
-    dim3 grid((unsigned)ceil_div(p.M, BBM), (unsigned)ceil_div(p.N, bnt), (unsigned)splits);
-    launch_b<BGEMM_WGRAD>(p, grid, bnt, st);
+    launch_b<BGEMM_WGRAD>(p, p.M, splits, bf16_wgrad_plan(g).ts, st);
     return check_launch("conv_gemm_bf16<wgrad>");
 }
 

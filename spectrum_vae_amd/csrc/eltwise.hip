@@ -7,25 +7,33 @@
 namespace sv {
 
 // ------------------------------------------------------------------------------------------------ activations
-__global__ void act_fwd_k(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act, float alpha) {
-    const int64_t n4 = n >> 2;
+// 16 bytes of activations: 4 floats or 8 bf16
+template <typename T>
+struct Pack16 {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+
+template <typename T>
+__global__ void act_fwd_k(const T* __restrict__ x, T* __restrict__ y, int64_t n, int act, float alpha) {
+    constexpr int VN = Pack16<T>::N;
+    const int64_t nv = n / VN;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 v = reinterpret_cast<const float4*>(x)[i];
-        v.x = act_apply(v.x, act, alpha);
-        v.y = act_apply(v.y, act, alpha);
-        v.z = act_apply(v.z, act, alpha);
-        v.w = act_apply(v.w, act, alpha);
-        reinterpret_cast<float4*>(y)[i] = v;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        Pack16<T> v = reinterpret_cast<const Pack16<T>*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v.v[e] = (T)act_apply((float)v.v[e], act, alpha);
+        reinterpret_cast<Pack16<T>*>(y)[i] = v;
     }
-    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        y[i] = act_apply(x[i], act, alpha);
+    for (int64_t i = nv * VN + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = (T)act_apply((float)x[i], act, alpha);
 }
 
 // dz = dy * act'(y); optional per-channel column sums of dz into part[block][C] (C <= 1024).
 // Rows are dealt to blocks in contiguous chunks; thread t of a block owns channel (t % C) of rows t/C, ...
-__global__ __launch_bounds__(256) void act_bwd_k(const float* __restrict__ dy, const float* __restrict__ y,
-                                                  float* __restrict__ dz, float* __restrict__ part, int64_t rows,
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_k(const T* __restrict__ dy, const T* __restrict__ y,
+                                                  T* __restrict__ dz, float* __restrict__ part, int64_t rows,
                                                   int C, int act, float alpha, int64_t rows_per_block) {
     extern __shared__ float sm[];  // [rows_in_flight][C] partial sums when part != nullptr
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -40,9 +48,9 @@ __global__ __launch_bounds__(256) void act_bwd_k(const float* __restrict__ dy, c
 #pragma unroll 4
             for (int64_t r = r0 + rr; r < r1; r += rif) {
                 const int64_t i = r * C + c;
-                const float g = dy[i] * act_grad_from_y(y[i], act, alpha);
-                dz[i] = g;
-                acc += g;
+                const T gt = (T)((float)dy[i] * act_grad_from_y((float)y[i], act, alpha));
+                dz[i] = gt;
+                acc += (float)gt;  // the bias gradient sums what the next kernel will read
             }
         }
         if (part != nullptr) {
@@ -60,9 +68,9 @@ __global__ __launch_bounds__(256) void act_bwd_k(const float* __restrict__ dy, c
 #pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) {
                 const int64_t i = r * C + c;
-                const float g = dy[i] * act_grad_from_y(y[i], act, alpha);
-                dz[i] = g;
-                acc += g;
+                const T gt = (T)((float)dy[i] * act_grad_from_y((float)y[i], act, alpha));
+                dz[i] = gt;
+                acc += (float)gt;
             }
             if (part != nullptr) part[(int64_t)blockIdx.x * C + c] = acc;
         }
@@ -70,7 +78,8 @@ __global__ __launch_bounds__(256) void act_bwd_k(const float* __restrict__ dy, c
 }
 
 // column sums only
-__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ z, float* __restrict__ part, int64_t rows,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ z, float* __restrict__ part, int64_t rows,
                                                  int C, int64_t rows_per_block) {
     extern __shared__ float sm[];
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ z, flo
         float acc = 0.f;
         if (rr < rif)
 #pragma unroll 4
-            for (int64_t r = r0 + rr; r < r1; r += rif) acc += z[r * C + c];
+            for (int64_t r = r0 + rr; r < r1; r += rif) acc += (float)z[r * C + c];
         sm[threadIdx.x] = (rr < rif) ? acc : 0.f;
         __syncthreads();
         if (threadIdx.x < C) {
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ z, flo
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float acc = 0.f;
 #pragma unroll 4
-            for (int64_t r = r0; r < r1; ++r) acc += z[r * C + c];
+            for (int64_t r = r0; r < r1; ++r) acc += (float)z[r * C + c];
             part[(int64_t)blockIdx.x * C + c] = acc;
         }
     }
@@ -238,7 +247,8 @@ __global__ void upsample_bwd_k(const float* __restrict__ dy, float* __restrict__
 // ------------------------------------------------------------------------------------------------ batch norm
 // pass 1: per-block partial (sum, sum of squares about a per-channel pivot) -> part[block][2][C].
 // The pivot (first row of the tensor) keeps the one-pass variance well conditioned.
-__global__ __launch_bounds__(256) void bn_stats_k(const float* __restrict__ x, float* __restrict__ part,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_k(const T* __restrict__ x, float* __restrict__ part,
                                                    int64_t rows, int C, int64_t rows_per_block) {
     extern __shared__ float sm[];  // 2 * blockDim.x
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -249,10 +259,10 @@ __global__ __launch_bounds__(256) void bn_stats_k(const float* __restrict__ x, f
         const int c = threadIdx.x % C, rr = threadIdx.x / C;
         float s = 0.f, q = 0.f;
         if (rr < rif) {
-            const float piv = x[c];
+            const float piv = (float)x[c];
 #pragma unroll 4
             for (int64_t r = r0 + rr; r < r1; r += rif) {
-                const float d = x[r * C + c] - piv;
+                const float d = (float)x[r * C + c] - piv;
                 s += d;
                 q = fmaf(d, d, q);
             }
@@ -271,11 +281,11 @@ __global__ __launch_bounds__(256) void bn_stats_k(const float* __restrict__ x, f
         }
     } else {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            const float piv = x[c];
+            const float piv = (float)x[c];
             float s = 0.f, q = 0.f;
 #pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) {
-                const float d = x[r * C + c] - piv;
+                const float d = (float)x[r * C + c] - piv;
                 s += d;
                 q = fmaf(d, d, q);
             }
@@ -286,7 +296,8 @@ __global__ __launch_bounds__(256) void bn_stats_k(const float* __restrict__ x, f
 }
 
 // pass 2: fold partials -> mean, invstd; update the moving statistics.
-__global__ void bn_finalize_k(const float* __restrict__ x, const float* __restrict__ part, int nblocks,
+template <typename T>
+__global__ void bn_finalize_k(const T* __restrict__ x, const float* __restrict__ part, int nblocks,
                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
                               float* __restrict__ moving_mean, float* __restrict__ moving_var, int64_t rows, int C,
                               float eps, float momentum, int unbiased) {
@@ -299,7 +310,7 @@ __global__ void bn_finalize_k(const float* __restrict__ x, const float* __restri
         const double dmean = s / m;
         double var = q / m - dmean * dmean;
         if (var < 0.0) var = 0.0;
-        const float mean = (float)((double)x[c] + dmean);
+        const float mean = (float)((double)(float)x[c] + dmean);
         save_mean[c] = mean;
         save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
         if (moving_mean != nullptr) {
@@ -311,19 +322,21 @@ __global__ void bn_finalize_k(const float* __restrict__ x, const float* __restri
 }
 
 // y = (x - mean) * invstd * gamma + beta   (mean/invstd either saved batch stats or derived from moving stats)
-__global__ void bn_apply_k(const float* __restrict__ x, const float* __restrict__ gamma,
+template <typename T>
+__global__ void bn_apply_k(const T* __restrict__ x, const float* __restrict__ gamma,
                            const float* __restrict__ beta, const float* __restrict__ mean,
-                           const float* __restrict__ var_or_invstd, int is_var, float eps, float* __restrict__ y,
+                           const float* __restrict__ var_or_invstd, int is_var, float eps, T* __restrict__ y,
                            int64_t total, int C) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const float inv = is_var ? rsqrtf(var_or_invstd[c] + eps) : var_or_invstd[c];
-        y[i] = (x[i] - mean[c]) * inv * gamma[c] + beta[c];
+        y[i] = (T)(((float)x[i] - mean[c]) * inv * gamma[c] + beta[c]);
     }
 }
 
 // backward pass 1: per-block partial (sum dy, sum dy*xhat) -> part[block][2][C]
-__global__ __launch_bounds__(256) void bn_bwd_stats_k(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_k(const T* __restrict__ x, const T* __restrict__ dy,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float* __restrict__ part,
                                                        int64_t rows, int C, int64_t rows_per_block) {
@@ -339,9 +352,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const float* __restrict__ 
             const float mu = mean[c], inv = invstd[c];
 #pragma unroll 4
             for (int64_t r = r0 + rr; r < r1; r += rif) {
-                const float g = dy[r * C + c];
+                const float g = (float)dy[r * C + c];
                 s += g;
-                q = fmaf(g, (x[r * C + c] - mu) * inv, q);
+                q = fmaf(g, ((float)x[r * C + c] - mu) * inv, q);
             }
         }
         sm[threadIdx.x] = (rr < rif) ? s : 0.f;
@@ -362,9 +375,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const float* __restrict__ 
             float s = 0.f, q = 0.f;
 #pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) {
-                const float g = dy[r * C + c];
+                const float g = (float)dy[r * C + c];
                 s += g;
-                q = fmaf(g, (x[r * C + c] - mu) * inv, q);
+                q = fmaf(g, ((float)x[r * C + c] - mu) * inv, q);
             }
             part[((int64_t)blockIdx.x * 2 + 0) * C + c] = s;
             part[((int64_t)blockIdx.x * 2 + 1) * C + c] = q;
@@ -388,22 +401,24 @@ __global__ void bn_bwd_fold_k(const float* __restrict__ part, int nblocks, float
 }
 
 // dx = gamma*invstd/m * (m*dy - sum_dy - xhat*sum_dy_xhat)
-__global__ void bn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ void bn_bwd_apply_k(const T* __restrict__ x, const T* __restrict__ dy,
                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ stats2,
-                               float* __restrict__ dx, int64_t rows, int C) {
+                               T* __restrict__ dx, int64_t rows, int C) {
     const int64_t total = rows * C;
     const float invm = 1.f / (float)rows;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const float inv = invstd[c];
-        const float xh = (x[i] - mean[c]) * inv;
-        dx[i] = gamma[c] * inv * (dy[i] - invm * (stats2[c] + xh * stats2[C + c]));
+        const float xh = ((float)x[i] - mean[c]) * inv;
+        dx[i] = (T)(gamma[c] * inv * ((float)dy[i] - invm * (stats2[c] + xh * stats2[C + c])));
     }
 }
 
 // ------------------------------------------------------------------------------------------------ concat / misc
-__global__ void concat_fwd_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+template <typename T>
+__global__ void concat_fwd_k(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
                              int64_t rows, int Ca, int Cb) {
     const int Cy = Ca + Cb;
     const int64_t total = rows * Cy;
@@ -414,7 +429,8 @@ __global__ void concat_fwd_k(const float* __restrict__ a, const float* __restric
     }
 }
 
-__global__ void concat_bwd_k(const float* __restrict__ dy, float* __restrict__ da, float* __restrict__ db,
+template <typename T>
+__global__ void concat_bwd_k(const T* __restrict__ dy, T* __restrict__ da, T* __restrict__ db,
                              int64_t rows, int Ca, int Cb) {
     const int Cy = Ca + Cb;
     const int64_t total = rows * Cy;
@@ -493,6 +509,19 @@ __global__ void axpy_k(float* __restrict__ y, const float* __restrict__ x, float
         y[i] = fmaf(a, x[i], y[i]);
 }
 
+template <typename T>
+__global__ void axpy_t_k(T* __restrict__ y, const T* __restrict__ x, float a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (T)fmaf(a, (float)x[i], (float)y[i]);
+}
+
+// y = x * (1 - mask), x and mask float32, y in the model's storage type
+template <typename T>
+__global__ void mask_input_t_k(const float* __restrict__ x, const float* __restrict__ m, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (T)(x[i] * (1.f - m[i]));
+}
+
 __global__ void cast_f32_bf16_k(const float* __restrict__ x, __hip_bfloat16* __restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = __float2bfloat16(x[i]);
@@ -546,14 +575,26 @@ int col_ws(void* ws, size_t ws_bytes, int64_t rows, int C, float** part, float**
 }
 }  // namespace
 
+// Runs BODY with T = the storage type `dtype` names (float or bf16).
+#define SV_WITH_T(dtype, BODY)        \
+    do {                              \
+        if ((dtype) == SV_F32) {      \
+            typedef float T;          \
+            BODY                      \
+        } else {                      \
+            typedef __bf16 T;         \
+            BODY                      \
+        }                             \
+    } while (0)
+
 extern "C" {
 
 int sv_act_fwd(const void* x, void* y, int64_t n, int act, float alpha, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_act_fwd");
+    SV_F32_OR_BF16(dtype, "sv_act_fwd");
     SV_REQUIRE(x && y && n >= 0, "sv_act_fwd: bad arguments");
     if (n == 0) return SV_OK;
-    hipLaunchKernelGGL(act_fwd_k, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, to_stream(stream), (const float*)x,
-                       (float*)y, n, act, alpha);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(act_fwd_k<T>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, to_stream(stream),
+                                        (const T*)x, (T*)y, n, act, alpha););
     return check_launch("sv_act_fwd");
 }
 
@@ -564,7 +605,7 @@ size_t sv_colreduce_workspace_bytes(int64_t rows, int C) {
 
 int sv_act_bwd(const void* dy, const void* y, void* dz, void* db, int db_accumulate, int64_t rows, int C, int act,
                float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_act_bwd");
+    SV_F32_OR_BF16(dtype, "sv_act_bwd");
     SV_REQUIRE(dy && y && dz && rows > 0 && C > 0 && C <= kMaxC, "sv_act_bwd: bad arguments (C=%d)", C);
     ColPlan p = col_plan(rows, C);
     float *part = nullptr, *folded = nullptr;
@@ -572,8 +613,8 @@ int sv_act_bwd(const void* dy, const void* y, void* dz, void* db, int db_accumul
         int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_act_bwd");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(act_bwd_k, dim3(p.nblocks), dim3(256), 256 * sizeof(float), to_stream(stream),
-                       (const float*)dy, (const float*)y, (float*)dz, part, rows, C, act, alpha, p.rows_per_block);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(act_bwd_k<T>, dim3(p.nblocks), dim3(256), 256 * sizeof(float), to_stream(stream),
+                                        (const T*)dy, (const T*)y, (T*)dz, part, rows, C, act, alpha, p.rows_per_block););
     int rc = check_launch("sv_act_bwd");
     if (rc || db == nullptr) return rc;
     hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, to_stream(stream), part, (float*)db,
@@ -583,14 +624,14 @@ int sv_act_bwd(const void* dy, const void* y, void* dz, void* db, int db_accumul
 
 int sv_bias_grad(const void* dz, void* db, int accumulate, int64_t rows, int C, void* workspace,
                  size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_bias_grad");
+    SV_F32_OR_BF16(dtype, "sv_bias_grad");
     SV_REQUIRE(dz && db && rows > 0 && C > 0 && C <= kMaxC, "sv_bias_grad: bad arguments (C=%d)", C);
     ColPlan p = col_plan(rows, C);
     float *part = nullptr, *folded = nullptr;
     int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_bias_grad");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_k, dim3(p.nblocks), dim3(256), 256 * sizeof(float), to_stream(stream),
-                       (const float*)dz, part, rows, C, p.rows_per_block);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(colsum_k<T>, dim3(p.nblocks), dim3(256), 256 * sizeof(float), to_stream(stream),
+                                        (const T*)dz, part, rows, C, p.rows_per_block););
     rc = check_launch("sv_bias_grad");
     if (rc) return rc;
     hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, to_stream(stream), part, (float*)db,
@@ -648,7 +689,7 @@ int sv_batchnorm_fwd_train(const void* x, const float* gamma, const float* beta,
                            float* save_invstd, float* moving_mean, float* moving_var, int64_t rows, int C, float eps,
                            float momentum, int unbiased_moving_var, void* workspace, size_t workspace_bytes,
                            int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_batchnorm_fwd_train");
+    SV_F32_OR_BF16(dtype, "sv_batchnorm_fwd_train");
     SV_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && rows > 0 && C > 0 && C <= kMaxC,
                "sv_batchnorm_fwd_train: bad arguments (C=%d)", C);
     SV_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr),
@@ -658,36 +699,37 @@ int sv_batchnorm_fwd_train(const void* x, const float* gamma, const float* beta,
     int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_batchnorm_fwd_train");
     if (rc) return rc;
     hipStream_t st = to_stream(stream);
-    hipLaunchKernelGGL(bn_stats_k, dim3(p.nblocks), dim3(256), 512 * sizeof(float), st, (const float*)x, part, rows,
-                       C, p.rows_per_block);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_stats_k<T>, dim3(p.nblocks), dim3(256), 512 * sizeof(float), st, (const T*)x, part,
+                                        rows, C, p.rows_per_block););
     rc = check_launch("bn_stats");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, st, (const float*)x, part, p.nblocks,
-                       save_mean, save_invstd, moving_mean, moving_var, rows, C, eps, momentum, unbiased_moving_var);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_finalize_k<T>, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, st, (const T*)x, part,
+                                        p.nblocks, save_mean, save_invstd, moving_mean, moving_var, rows, C, eps, momentum,
+                                        unbiased_moving_var););
     rc = check_launch("bn_finalize");
     if (rc) return rc;
     const int64_t total = rows * C;
-    hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, st, (const float*)x, gamma, beta,
-                       save_mean, save_invstd, 0, eps, (float*)y, total, C);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, st, (const T*)x, gamma,
+                                        beta, save_mean, save_invstd, 0, eps, (T*)y, total, C););
     return check_launch("bn_apply");
 }
 
 int sv_batchnorm_fwd_infer(const void* x, const float* gamma, const float* beta, const float* moving_mean,
                            const float* moving_var, void* y, int64_t rows, int C, float eps, int dtype,
                            sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_batchnorm_fwd_infer");
+    SV_F32_OR_BF16(dtype, "sv_batchnorm_fwd_infer");
     SV_REQUIRE(x && gamma && beta && moving_mean && moving_var && y && rows > 0 && C > 0,
                "sv_batchnorm_fwd_infer: bad arguments");
     const int64_t total = rows * C;
-    hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
-                       (const float*)x, gamma, beta, moving_mean, moving_var, 1, eps, (float*)y, total, C);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
+                                        (const T*)x, gamma, beta, moving_mean, moving_var, 1, eps, (T*)y, total, C););
     return check_launch("sv_batchnorm_fwd_infer");
 }
 
 int sv_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const float* save_mean,
                      const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t rows,
                      int C, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_batchnorm_bwd");
+    SV_F32_OR_BF16(dtype, "sv_batchnorm_bwd");
     SV_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && rows > 0 && C > 0 &&
                    C <= kMaxC,
                "sv_batchnorm_bwd: bad arguments (C=%d)", C);
@@ -696,34 +738,34 @@ int sv_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const fl
     int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &stats2, "sv_batchnorm_bwd");
     if (rc) return rc;
     hipStream_t st = to_stream(stream);
-    hipLaunchKernelGGL(bn_bwd_stats_k, dim3(p.nblocks), dim3(256), 512 * sizeof(float), st, (const float*)x,
-                       (const float*)dy, save_mean, save_invstd, part, rows, C, p.rows_per_block);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_stats_k<T>, dim3(p.nblocks), dim3(256), 512 * sizeof(float), st, (const T*)x,
+                                        (const T*)dy, save_mean, save_invstd, part, rows, C, p.rows_per_block););
     rc = check_launch("bn_bwd_stats");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_fold_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
                        accumulate, C);
     rc = check_launch("bn_bwd_fold");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(rows * C, 256, 8192)), dim3(256), 0, st, (const float*)x,
-                       (const float*)dy, gamma, save_mean, save_invstd, stats2, (float*)dx, rows, C);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_grid(rows * C, 256, 8192)), dim3(256), 0, st, (const T*)x,
+                                        (const T*)dy, gamma, save_mean, save_invstd, stats2, (T*)dx, rows, C););
     return check_launch("bn_bwd_apply");
 }
 
 int sv_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int Ca, int Cb, int dtype,
                            sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_concat_channels_fwd");
+    SV_F32_OR_BF16(dtype, "sv_concat_channels_fwd");
     SV_REQUIRE(a && b && y && rows > 0 && Ca > 0 && Cb > 0, "sv_concat_channels_fwd: bad arguments");
-    hipLaunchKernelGGL(concat_fwd_k, dim3(ew_grid(rows * (Ca + Cb), 256, 8192)), dim3(256), 0, to_stream(stream),
-                       (const float*)a, (const float*)b, (float*)y, rows, Ca, Cb);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(concat_fwd_k<T>, dim3(ew_grid(rows * (Ca + Cb), 256, 8192)), dim3(256), 0,
+                                        to_stream(stream), (const T*)a, (const T*)b, (T*)y, rows, Ca, Cb););
     return check_launch("sv_concat_channels_fwd");
 }
 
 int sv_concat_channels_bwd(const void* dy, void* da, void* db, int64_t rows, int Ca, int Cb, int dtype,
                            sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_concat_channels_bwd");
+    SV_F32_OR_BF16(dtype, "sv_concat_channels_bwd");
     SV_REQUIRE(dy && da && db && rows > 0 && Ca > 0 && Cb > 0, "sv_concat_channels_bwd: bad arguments");
-    hipLaunchKernelGGL(concat_bwd_k, dim3(ew_grid(rows * (Ca + Cb), 256, 8192)), dim3(256), 0, to_stream(stream),
-                       (const float*)dy, (float*)da, (float*)db, rows, Ca, Cb);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(concat_bwd_k<T>, dim3(ew_grid(rows * (Ca + Cb), 256, 8192)), dim3(256), 0,
+                                        to_stream(stream), (const T*)dy, (T*)da, (T*)db, rows, Ca, Cb););
     return check_launch("sv_concat_channels_bwd");
 }
 
@@ -793,6 +835,22 @@ int sv_axpy_f32(float* y, const float* x, float a, int64_t n, sv_stream_t stream
     SV_REQUIRE(x && y && n > 0, "sv_axpy_f32: bad arguments");
     hipLaunchKernelGGL(axpy_k, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream), y, x, a, n);
     return check_launch("sv_axpy_f32");
+}
+
+int sv_axpy(void* y, const void* x, float a, int64_t n, int dtype, sv_stream_t stream) {
+    SV_F32_OR_BF16(dtype, "sv_axpy");
+    SV_REQUIRE(x && y && n > 0, "sv_axpy: bad arguments");
+    SV_WITH_T(dtype, hipLaunchKernelGGL(axpy_t_k<T>, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream), (T*)y,
+                                        (const T*)x, a, n););
+    return check_launch("sv_axpy");
+}
+
+int sv_mask_input_dt(const float* x, const float* mask, void* y, int64_t n, int dtype, sv_stream_t stream) {
+    SV_F32_OR_BF16(dtype, "sv_mask_input_dt");
+    SV_REQUIRE(x && mask && y && n > 0, "sv_mask_input_dt: bad arguments");
+    SV_WITH_T(dtype, hipLaunchKernelGGL(mask_input_t_k<T>, dim3(ew_grid(n, 256, 8192)), dim3(256), 0, to_stream(stream), x,
+                                        mask, (T*)y, n););
+    return check_launch("sv_mask_input_dt");
 }
 
 int sv_cast_f32_bf16(const float* x, void* y, int64_t n, sv_stream_t stream) {

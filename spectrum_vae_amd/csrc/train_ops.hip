@@ -11,37 +11,37 @@ constexpr int kLossBlocks = 1024;
 // mode 0: squared error, weight per pixel optional;  mode 1: absolute error;
 // mode 2: BCE on probabilities against constant label; mode 3: BCE on logits against constant label.
 // value_i is summed and scaled by inv_count; dpred_i = loss_scale * d(value_i)/dpred * inv_count.
-template <int MODE>
-__global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const float* __restrict__ p,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const T* __restrict__ p,
                                                const float* __restrict__ weight, int wstride, float wscale, int C,
-                                               float label, float inv_count, float* __restrict__ dpred,
+                                               float label, float inv_count, T* __restrict__ dpred,
                                                float loss_scale, int64_t n, float* __restrict__ partials) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float v, g;
         if (MODE == 0) {
-            const float d = p[i] - t[i];
+            const float d = (float)p[i] - t[i];
             const float w = weight != nullptr ? weight[(i / C) * wstride] * wscale : 1.f;
             v = w * d * d;
             g = 2.f * w * d;
         } else if (MODE == 1) {
-            const float d = p[i] - t[i];
+            const float d = (float)p[i] - t[i];
             v = fabsf(d);
             g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         } else if (MODE == 2) {
             const float eps = 1e-7f;
-            const float q0 = p[i];
+            const float q0 = (float)p[i];
             const float q = fminf(fmaxf(q0, eps), 1.f - eps);
             v = -(label * logf(q + eps) + (1.f - label) * logf(1.f - q + eps));
             g = (q0 >= eps && q0 <= 1.f - eps) ? -(label / (q + eps) - (1.f - label) / (1.f - q + eps)) : 0.f;
         } else {
-            const float z = p[i];
+            const float z = (float)p[i];
             v = fmaxf(z, 0.f) - z * label + log1pf(expf(-fabsf(z)));
             g = 1.f / (1.f + expf(-z)) - label;
         }
         acc += v;
-        if (dpred != nullptr) dpred[i] = loss_scale * g * inv_count;
+        if (dpred != nullptr) dpred[i] = (T)(loss_scale * g * inv_count);
     }
     const float s = block_sum_256(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -68,12 +68,13 @@ __global__ __launch_bounds__(256) void loss_fold_k(const float* __restrict__ par
     }
 }
 
-__global__ void mse_map_k(const float* __restrict__ t, const float* __restrict__ p, const float* __restrict__ weight,
+template <typename T>
+__global__ void mse_map_k(const float* __restrict__ t, const T* __restrict__ p, const float* __restrict__ weight,
                           int wstride, float wscale, float* __restrict__ out, int64_t n_pix, int C) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int c = 0; c < C; ++c) {
-            const float d = p[i * C + c] - t[i * C + c];
+            const float d = (float)p[i * C + c] - t[i * C + c];
             s = fmaf(d, d, s);
         }
         s /= (float)C;
@@ -256,6 +257,17 @@ __global__ void reparam_bwd_k(const float* __restrict__ mean, const float* __res
 
 using namespace sv;
 
+#define SV_WITH_T(dtype, BODY)        \
+    do {                              \
+        if ((dtype) == SV_F32) {      \
+            typedef float T;          \
+            BODY                      \
+        } else {                      \
+            typedef __bf16 T;         \
+            BODY                      \
+        }                             \
+    } while (0)
+
 extern "C" {
 
 size_t sv_loss_workspace_bytes(void) { return (size_t)kLossBlocks * sizeof(float); }
@@ -263,15 +275,15 @@ size_t sv_loss_workspace_bytes(void) { return (size_t)kLossBlocks * sizeof(float
 int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int weight_stride, float weight_scale,
                 float* loss_out, int accumulate, void* dpred, float loss_scale, int64_t n_pix, int C, float* partials,
                 float* running, float running_weight, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_loss_mse");
+    SV_F32_OR_BF16(dtype, "sv_loss_mse");
     SV_REQUIRE(y_true && y_pred && loss_out && partials && n_pix > 0 && C > 0, "sv_loss_mse: bad arguments");
     SV_REQUIRE(weight == nullptr || weight_stride > 0, "sv_loss_mse: weight_stride must be positive");
     const int64_t n = n_pix * C;
     const int nb = ew_grid(n, 256, kLossBlocks);
     const float inv = 1.f / (float)n;
-    hipLaunchKernelGGL(loss_k<0>, dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
-                       (const float*)y_pred, weight, weight_stride, weight_scale, C, 0.f, inv, (float*)dpred,
-                       loss_scale, n, partials);
+    SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<0, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
+                                        (const T*)y_pred, weight, weight_stride, weight_scale, C, 0.f, inv, (T*)dpred,
+                                        loss_scale, n, partials););
     int rc = check_launch("sv_loss_mse");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate,
@@ -281,22 +293,23 @@ int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int
 
 int sv_loss_mse_map(const void* y_true, const void* y_pred, const float* weight, int weight_stride,
                     float weight_scale, float* out, int64_t n_pix, int C, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_loss_mse_map");
+    SV_F32_OR_BF16(dtype, "sv_loss_mse_map");
     SV_REQUIRE(y_true && y_pred && out && n_pix > 0 && C > 0, "sv_loss_mse_map: bad arguments");
-    hipLaunchKernelGGL(mse_map_k, dim3(ew_grid(n_pix, 256, 8192)), dim3(256), 0, to_stream(stream),
-                       (const float*)y_true, (const float*)y_pred, weight, weight_stride, weight_scale, out, n_pix, C);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(mse_map_k<T>, dim3(ew_grid(n_pix, 256, 8192)), dim3(256), 0, to_stream(stream),
+                                        (const float*)y_true, (const T*)y_pred, weight, weight_stride, weight_scale, out,
+                                        n_pix, C););
     return check_launch("sv_loss_mse_map");
 }
 
 int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int accumulate, void* dpred,
                 float loss_scale, int64_t n, float* partials, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_loss_mae");
+    SV_F32_OR_BF16(dtype, "sv_loss_mae");
     SV_REQUIRE(y_true && y_pred && loss_out && partials && n > 0, "sv_loss_mae: bad arguments");
     const int nb = ew_grid(n, 256, kLossBlocks);
     const float inv = 1.f / (float)n;
-    hipLaunchKernelGGL(loss_k<1>, dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
-                       (const float*)y_pred, (const float*)nullptr, 1, 1.f, 1, 0.f, inv, (float*)dpred, loss_scale, n,
-                       partials);
+    SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<1, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
+                                        (const T*)y_pred, (const float*)nullptr, 1, 1.f, 1, 0.f, inv, (T*)dpred, loss_scale,
+                                        n, partials););
     int rc = check_launch("sv_loss_mae");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
@@ -305,18 +318,18 @@ int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int acc
 
 int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out, int accumulate, void* dpred,
                 float loss_scale, int64_t n, float* partials, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_loss_bce");
+    SV_F32_OR_BF16(dtype, "sv_loss_bce");
     SV_REQUIRE(pred && loss_out && partials && n > 0, "sv_loss_bce: bad arguments");
     const int nb = ew_grid(n, 256, kLossBlocks);
     const float inv = 1.f / (float)n;
     if (from_logits)
-        hipLaunchKernelGGL(loss_k<3>, dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
-                           (const float*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (float*)dpred,
-                           loss_scale, n, partials);
+        SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<3, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
+                                            (const T*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (T*)dpred,
+                                            loss_scale, n, partials););
     else
-        hipLaunchKernelGGL(loss_k<2>, dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
-                           (const float*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (float*)dpred,
-                           loss_scale, n, partials);
+        SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<2, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
+                                            (const T*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (T*)dpred,
+                                            loss_scale, n, partials););
     int rc = check_launch("sv_loss_bce");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);

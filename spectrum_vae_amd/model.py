@@ -20,7 +20,7 @@ from . import ops
 from .losses import to_device_f32
 from .nn import DEFAULT_SEED, BufferPool, CallCtx, DTensor, Layer, Sequential, Variable, as_dtensor, default_device
 
-ALIGN = 4  # floats; every variable starts on a 16-byte boundary of the flat buffer
+ALIGN = 8  # floats; every variable starts on a 16-byte boundary of the flat buffer AND of its bf16 copy
 
 
 class History:
@@ -68,6 +68,12 @@ class Model(Layer):
         super().__init__(name)
         self._seed = seed
         self._pool = BufferPool()
+        from . import mixed_precision
+        # storage type of activations / activation gradients / the filter copy the convs read (the policy in force
+        # when the model is constructed); weights, gradients and optimizer state are float32 either way
+        self._act_dtype: torch.dtype = mixed_precision.global_policy().torch_dtype
+        self._params_lp: Optional[torch.Tensor] = None
+        self._lp_dirty = True
         self._params: Optional[torch.Tensor] = None
         self._grads: Optional[torch.Tensor] = None
         self._grads_clean = False  # True only right after an optimizer launch that cleared the gradient buffer
@@ -169,10 +175,15 @@ class Model(Layer):
         self._params = torch.from_numpy(host_p).to(device)
         self._grads = torch.zeros(n_t, dtype=torch.float32, device=device)
         self._state = torch.from_numpy(host_s).to(device)
+        if self._act_dtype != torch.float32:
+            self._params_lp = torch.empty(n_t, dtype=self._act_dtype, device=device)
         for v in tv:
             v.data = self._params[v.offset:v.offset + v.size].view(v.shape)
             v.grad = self._grads[v.offset:v.offset + v.size].view(v.shape)
+            if self._params_lp is not None:
+                v.data_lp = self._params_lp[v.offset:v.offset + v.size].view(v.shape)
             v.owner = self
+        self._lp_dirty = True
         for v in ntv:
             v.data = self._state[v.offset:v.offset + v.size].view(v.shape)
             v.owner = self
@@ -181,6 +192,24 @@ class Model(Layer):
                 l._owner_model = self
             if hasattr(l, "stream_id"):
                 l.stream_id = i
+
+    @property
+    def compute_dtype(self) -> str:
+        return "bfloat16" if self._act_dtype == torch.bfloat16 else "float32"
+
+    def _refresh_lp(self):
+        """Re-derive the bf16 copy of the weights from the float32 masters (one launch over the flat buffer)."""
+        if self._params_lp is not None:
+            ops.cast(self._params, self._params_lp)
+        self._lp_dirty = False
+
+    def _to_act(self, t: torch.Tensor, key) -> torch.Tensor:
+        """A float32 tensor in this model's activation type (a pooled buffer holds the converted copy)."""
+        if t.dtype == self._act_dtype:
+            return t
+        out = self._pool.get(("act_in", key), tuple(t.shape), self._act_dtype)
+        ops.cast(t, out)
+        return out
 
     def _all_layers(self) -> List[Layer]:
         out, stack = [], [self]
@@ -220,6 +249,7 @@ class Model(Layer):
         self._materialize()
         self._params.copy_(sd["params"].to(self._params.device))
         self._state.copy_(sd["state"].to(self._state.device))
+        self._lp_dirty = True
 
     # ------------------------------------------------------------------ execution
     def _prep_input(self, x) -> torch.Tensor:
@@ -238,6 +268,10 @@ class Model(Layer):
         A training-mode call is remembered until ``zero_grad``/the optimizer step so ``backward`` can run."""
         t = self._prep_input(x)
         y = self.forward_raw(t, training)
+        if y.dtype != torch.float32:  # callers get float32, as a Keras mixed-precision model's float32 output layer gives
+            out = torch.empty(tuple(y.shape), dtype=torch.float32, device=y.device)
+            ops.cast(y, out)
+            return as_dtensor(out)
         return as_dtensor(y.clone())
 
     def call(self, x, training: bool = False):
@@ -311,12 +345,16 @@ class Model(Layer):
         """Forward on a prepared device tensor; the result aliases the model's buffer pool.  ``side``: stream
         the backward pass of this call may use for its weight-gradient kernels (the caller joins it)."""
         if training:
-            ctx = CallCtx(self._pool, len(self._calls), True)
+            ctx = CallCtx(self._pool, len(self._calls), True, self._act_dtype)
             ctx.side = side
             self._calls.append(ctx)
         else:
-            ctx = CallCtx(self._pool, "infer", False)
-        if self.use_net_fused:
+            ctx = CallCtx(self._pool, "infer", False, self._act_dtype)
+        if self._act_dtype != torch.float32:
+            if self._lp_dirty:
+                self._refresh_lp()
+            x = self._to_act(x, ctx.slot)
+        if self.use_net_fused and not ctx.lp:
             y = self._net_forward(ctx, x)
             if y is not None:
                 return y
@@ -359,10 +397,19 @@ class Model(Layer):
         """``model.encoder(x)`` / ``model.decoder(z)``: run one sub-stack on its own."""
         t = to_device_f32(x, self._pool.device or default_device())
         self._materialize(t.device)
-        ctx = CallCtx(self._pool, ("sub", id(seq)), False)
+        ctx = CallCtx(self._pool, ("sub", id(seq)), False, self._act_dtype)
         if training:
             raise NotImplementedError("sub-model calls are inference-only; train through the owning model")
-        return as_dtensor(seq.forward(ctx, t).clone())
+        if ctx.lp:
+            if self._lp_dirty:
+                self._refresh_lp()
+            t = self._to_act(t, ctx.slot)
+        y = seq.forward(ctx, t)
+        if y.dtype != torch.float32:
+            out = torch.empty(tuple(y.shape), dtype=torch.float32, device=y.device)
+            ops.cast(y, out)
+            return as_dtensor(out)
+        return as_dtensor(y.clone())
 
     # default forward/backward for models that are one stack of layers
     def forward(self, ctx, x):
@@ -390,7 +437,7 @@ class Model(Layer):
         return {
             "x": p.get(("fit", "x"), (bs,) + self.input_shape_),
             "y": p.get(("fit", "y"), (bs,) + tuple(y_shape)),
-            "dpred": p.get(("fit", "dpred"), (bs,) + self.output_shape_),
+            "dpred": p.get(("fit", "dpred"), (bs,) + self.output_shape_, self._act_dtype),
             "loss": p.get(("fit", "loss"), (1,)),
             "acc": p.get(("fit", "acc"), (1,)),
         }
@@ -613,7 +660,11 @@ class Model(Layer):
             cur = min(bs, n - start)
             xb = self._pool.get(("predict", "x"), (cur,) + self.input_shape_)
             ops.gather_rows(X[start:start + cur], None, xb)
-            out[start:start + cur].copy_(self.forward_raw(xb, False))
+            yb = self.forward_raw(xb, False)
+            if yb.dtype != torch.float32:
+                ops.cast(yb, out[start:start + cur])
+            else:
+                out[start:start + cur].copy_(yb)
         return out.cpu().numpy()
 
 

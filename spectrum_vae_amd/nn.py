@@ -79,6 +79,7 @@ class Variable:
         self.offset = -1
         self.data: Optional[torch.Tensor] = None  # view, set by Model._materialize
         self.grad: Optional[torch.Tensor] = None
+        self.data_lp: Optional[torch.Tensor] = None  # bfloat16 copy (models whose compute dtype is bfloat16)
         self.owner = None
 
     def initial_value(self, rng: np.random.Generator) -> np.ndarray:
@@ -104,6 +105,8 @@ class Variable:
     def assign(self, value):
         v = torch.as_tensor(np.asarray(value, dtype=np.float32)).reshape(self.shape)
         self.data.copy_(v.to(self.data.device))
+        if self.owner is not None:
+            self.owner._lp_dirty = True  # the bf16 copy of the weights is refreshed before the next forward pass
 
     def __repr__(self):
         return f"<Variable {self.name} {self.shape}>"
@@ -155,10 +158,11 @@ class BufferPool:
 class CallCtx:
     """State of one forward call: what each layer saved for its backward."""
 
-    def __init__(self, pool: BufferPool, slot: int, training: bool):
+    def __init__(self, pool: BufferPool, slot: int, training: bool, dtype: torch.dtype = torch.float32):
         self.pool = pool
         self.slot = slot
         self.training = training
+        self.dtype = dtype  # storage type of activations and their gradients in this call
         self.saved: Dict[int, dict] = {}
         # False: backward only propagates to the inputs (a generator's gradient THROUGH a discriminator);
         # weight/bias gradients are skipped, BatchNorm's go to scratch.
@@ -173,8 +177,17 @@ class CallCtx:
         self.wgrad_jobs: Optional[list] = None
         self.wgrad_finish: list = []
 
-    def buf(self, layer, role, shape, dtype=torch.float32):
-        return self.pool.get((id(layer), role, self.slot), shape, dtype)
+    def buf(self, layer, role, shape, dtype=None):
+        return self.pool.get((id(layer), role, self.slot), shape, self.dtype if dtype is None else dtype)
+
+    @property
+    def lp(self) -> bool:
+        return self.dtype != torch.float32
+
+    def need_f32(self, layer):
+        if self.lp:
+            raise NotImplementedError(f"{type(layer).__name__} ({layer.name}) has no bfloat16 kernels: build the model "
+                                      "with the float32 policy")
 
 
 # --------------------------------------------------------------------------- base layer
@@ -340,10 +353,16 @@ class _ConvBase(Layer):
             nbytes = cache[key] = ops.conv2d_scratch(g, op)
         return ctx.pool.workspace(nbytes) if nbytes else None
 
+    def _w(self, ctx):
+        """The filter tensor in the storage type of this call."""
+        return self.kernel.data_lp if ctx.lp else self.kernel.data
+
     def forward(self, ctx, x):
         n = x.shape[0]
         g = self.geom(n)
         b = self.bias.data if self.bias is not None else None
+        if ctx.lp and (self.pool is not None or self.up != (1, 1)):
+            raise NotImplementedError(f"{self.name}: the fused 3x3 / 5x5 stride-1 family is float32 only")
         if self.pool is not None:
             ho, wo, cout = self.output_shape_
             y = ctx.buf(self, "y", (n, ho // 2, wo // 2, cout))
@@ -354,10 +373,10 @@ class _ConvBase(Layer):
             return y
         y = ctx.buf(self, "y", (n,) + self.output_shape_)
         if self.transposed:
-            ops.conv2d_transpose_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha,
+            ops.conv2d_transpose_fwd(g, x, self._w(ctx), b, y, self.act, self.alpha,
                                      self._scratch(ctx, g, ops.OP_TRANSPOSE_FWD))
         else:
-            ops.conv2d_fwd(g, x, self.kernel.data, b, y, self.act, self.alpha, self._scratch(ctx, g, ops.OP_FWD))
+            ops.conv2d_fwd(g, x, self._w(ctx), b, y, self.act, self.alpha, self._scratch(ctx, g, ops.OP_FWD))
         if ctx.training:
             ctx.saved[id(self)] = {"x": x, "y": y}
         return y
@@ -368,7 +387,7 @@ class _ConvBase(Layer):
         n = x.shape[0]
         g = self.geom(n)
         ho, wo, cout = self.output_shape_
-        if self.fused_bwd and ctx.param_grads:
+        if self.fused_bwd and ctx.param_grads and not ctx.lp:
             dx = ctx.buf(self, "dx", tuple(x.shape)) if need_dx else None
             db = self.bias.grad if self.bias is not None else None
             if ctx.wgrad_jobs is not None and not ctx.side:
@@ -428,9 +447,9 @@ class _ConvBase(Layer):
             return None
         dx = ctx.buf(self, "dx", tuple(x.shape))
         if self.transposed:
-            ops.conv2d_transpose_dgrad(g, dz, self.kernel.data, dx, self._scratch(ctx, g, ops.OP_TRANSPOSE_DGRAD))
+            ops.conv2d_transpose_dgrad(g, dz, self._w(ctx), dx, self._scratch(ctx, g, ops.OP_TRANSPOSE_DGRAD))
         else:
-            ops.conv2d_dgrad(g, dz, self.kernel.data, dx, self._scratch(ctx, g, ops.OP_DGRAD))
+            ops.conv2d_dgrad(g, dz, self._w(ctx), dx, self._scratch(ctx, g, ops.OP_DGRAD))
         return dx
 
 
@@ -470,6 +489,7 @@ class MaxPooling2D(Layer):
     def forward(self, ctx, x):
         if self.folded:
             return x
+        ctx.need_f32(self)
         n = x.shape[0]
         h, w, c = self.input_shape_
         ho, wo, _ = self.output_shape_
@@ -509,6 +529,7 @@ class UpSampling2D(Layer):
     def forward(self, ctx, x):
         if self.folded:
             return x
+        ctx.need_f32(self)
         n = x.shape[0]
         h, w, c = self.input_shape_
         y = ctx.buf(self, "y", (n,) + self.output_shape_)
@@ -554,8 +575,8 @@ class BatchNormalization(Layer):
         rows = x.numel() // c
         y = ctx.buf(self, "y", tuple(x.shape))
         if ctx.training:
-            mean = ctx.buf(self, "mean", (c,))
-            invstd = ctx.buf(self, "invstd", (c,))
+            mean = ctx.buf(self, "mean", (c,), torch.float32)
+            invstd = ctx.buf(self, "invstd", (c,), torch.float32)
             ws = ctx.pool.workspace(ops.colreduce_workspace(rows, c))
             ops.batchnorm_fwd_train(x, self.gamma.data, self.beta.data, y, mean, invstd, self.moving_mean.data,
                                     self.moving_variance.data, rows, c, self.epsilon, self.momentum, self.unbiased,
@@ -576,7 +597,8 @@ class BatchNormalization(Layer):
         if ctx.param_grads:
             dg, db, acc = self.gamma.grad, self.beta.grad, True
         else:
-            dg, db, acc = ctx.buf(self, "dg_scratch", (c,)), ctx.buf(self, "db_scratch", (c,)), False
+            dg, db, acc = (ctx.buf(self, "dg_scratch", (c,), torch.float32),
+                           ctx.buf(self, "db_scratch", (c,), torch.float32), False)
         ops.batchnorm_bwd(x, dy, self.gamma.data, s["mean"], s["invstd"], dx, dg, db, acc, rows, c, ws)
         return dx
 
@@ -661,6 +683,7 @@ class Dense(Layer):
         return self.input_shape_[0] * self.units
 
     def forward(self, ctx, x):
+        ctx.need_f32(self)
         m, k = x.shape
         y = ctx.buf(self, "y", (m, self.units))
         ops.dense_fwd(x, self.kernel.data, self.bias.data, y, m, k, self.units, self.act, self.alpha)
@@ -704,6 +727,7 @@ class Dropout(Layer):
     def forward(self, ctx, x):
         if not ctx.training or self.rate <= 0.0:
             return x
+        ctx.need_f32(self)
         y = ctx.buf(self, "y", tuple(x.shape))
         offset = self.calls * x.numel()
         self.calls += 1
@@ -728,6 +752,7 @@ class ReduceSumH(Layer):
         return (in_shape[1], in_shape[2])
 
     def forward(self, ctx, x):
+        ctx.need_f32(self)
         n = x.shape[0]
         h, w, c = self.input_shape_
         y = ctx.buf(self, "y", (n, w, c))

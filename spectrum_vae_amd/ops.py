@@ -227,7 +227,7 @@ def conv2d_transpose_wgrad(g: ConvGeom, x, dz, dw, accumulate: bool, ws: torch.T
 
 # --------------------------------------------------------------------------- elementwise / reductions
 def act_fwd(x, y, act: str, alpha: float):
-    check(lib.sv_act_fwd(_ptr(x), _ptr(y), x.numel(), ACT[act], alpha, F32, _stream()), "sv_act_fwd")
+    check(lib.sv_act_fwd(_aptr(x), _aptr(y, x, "y"), x.numel(), ACT[act], alpha, _dt(x), _stream()), "sv_act_fwd")
 
 
 def colreduce_workspace(rows: int, c: int) -> int:
@@ -235,13 +235,13 @@ def colreduce_workspace(rows: int, c: int) -> int:
 
 
 def act_bwd(dy, y, dz, db, db_accumulate: bool, rows: int, c: int, act: str, alpha: float, ws):
-    check(lib.sv_act_bwd(_ptr(dy), _ptr(y), _ptr(dz), _ptr(db), int(db_accumulate), rows, c, ACT[act], alpha,
-                         _ptr(ws, torch.uint8) if ws is not None else None, ws.numel() if ws is not None else 0,
-                         F32, _stream()), "sv_act_bwd")
+    check(lib.sv_act_bwd(_aptr(dy), _aptr(y, dy, "y"), _aptr(dz, dy, "dz"), _ptr(db), int(db_accumulate), rows, c,
+                         ACT[act], alpha, _ptr(ws, torch.uint8) if ws is not None else None,
+                         ws.numel() if ws is not None else 0, _dt(dy), _stream()), "sv_act_bwd")
 
 
 def bias_grad(dz, db, accumulate: bool, rows: int, c: int, ws):
-    check(lib.sv_bias_grad(_ptr(dz), _ptr(db), int(accumulate), rows, c, _ptr(ws, torch.uint8), ws.numel(), F32,
+    check(lib.sv_bias_grad(_aptr(dz), _ptr(db), int(accumulate), rows, c, _ptr(ws, torch.uint8), ws.numel(), _dt(dz),
                            _stream()), "sv_bias_grad")
 
 
@@ -265,30 +265,31 @@ def upsample2d_bwd(dy, dx, n, h, w, c, uh, uw):
 
 def batchnorm_fwd_train(x, gamma, beta, y, save_mean, save_invstd, moving_mean, moving_var, rows, c, eps, momentum,
                         unbiased: bool, ws):
-    check(lib.sv_batchnorm_fwd_train(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(save_mean), _ptr(save_invstd),
-                                     _ptr(moving_mean), _ptr(moving_var), rows, c, eps, momentum, int(unbiased),
-                                     _ptr(ws, torch.uint8), ws.numel(), F32, _stream()), "sv_batchnorm_fwd_train")
+    check(lib.sv_batchnorm_fwd_train(_aptr(x), _ptr(gamma), _ptr(beta), _aptr(y, x, "y"), _ptr(save_mean),
+                                     _ptr(save_invstd), _ptr(moving_mean), _ptr(moving_var), rows, c, eps, momentum,
+                                     int(unbiased), _ptr(ws, torch.uint8), ws.numel(), _dt(x), _stream()),
+          "sv_batchnorm_fwd_train")
 
 
 def batchnorm_fwd_infer(x, gamma, beta, moving_mean, moving_var, y, rows, c, eps):
-    check(lib.sv_batchnorm_fwd_infer(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var), _ptr(y),
-                                     rows, c, eps, F32, _stream()), "sv_batchnorm_fwd_infer")
+    check(lib.sv_batchnorm_fwd_infer(_aptr(x), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
+                                     _aptr(y, x, "y"), rows, c, eps, _dt(x), _stream()), "sv_batchnorm_fwd_infer")
 
 
 def batchnorm_bwd(x, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta, accumulate: bool, rows, c, ws):
-    check(lib.sv_batchnorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd), _ptr(dx),
-                               _ptr(dgamma), _ptr(dbeta), int(accumulate), rows, c, _ptr(ws, torch.uint8),
-                               ws.numel(), F32, _stream()), "sv_batchnorm_bwd")
+    check(lib.sv_batchnorm_bwd(_aptr(x), _aptr(dy, x, "dy"), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
+                               _aptr(dx, x, "dx"), _ptr(dgamma), _ptr(dbeta), int(accumulate), rows, c,
+                               _ptr(ws, torch.uint8), ws.numel(), _dt(x), _stream()), "sv_batchnorm_bwd")
 
 
 def concat_channels_fwd(a, b, y, rows, ca, cb):
-    check(lib.sv_concat_channels_fwd(_ptr(a), _ptr(b), _ptr(y), rows, ca, cb, F32, _stream()),
+    check(lib.sv_concat_channels_fwd(_aptr(a), _aptr(b, a, "b"), _aptr(y, a, "y"), rows, ca, cb, _dt(a), _stream()),
           "sv_concat_channels_fwd")
 
 
 def concat_channels_bwd(dy, da, db, rows, ca, cb):
-    check(lib.sv_concat_channels_bwd(_ptr(dy), _ptr(da), _ptr(db), rows, ca, cb, F32, _stream()),
-          "sv_concat_channels_bwd")
+    check(lib.sv_concat_channels_bwd(_aptr(dy), _aptr(da, dy, "da"), _aptr(db, dy, "db"), rows, ca, cb, _dt(dy),
+                                     _stream()), "sv_concat_channels_bwd")
 
 
 def dense_fwd(x, w, bias, y, m, k, n, act: str, alpha: float):
@@ -344,29 +345,30 @@ def loss_mse(y_true, y_pred, loss_out, partials, dpred=None, loss_scale=1.0, wei
     n_pix = y_pred.numel() // c
     if y_true.numel() != y_pred.numel():
         raise ValueError(f"MSE: y_true {tuple(y_true.shape)} vs y_pred {tuple(y_pred.shape)}")
-    check(lib.sv_loss_mse(_ptr(y_true), _ptr(y_pred), _ptr(weight), weight_stride, weight_scale, _ptr(loss_out),
-                          int(accumulate), _ptr(dpred), loss_scale, n_pix, c, _ptr(partials), _ptr(running),
-                          float(running_weight), F32, _stream()),
+    check(lib.sv_loss_mse(_ptr(y_true), _aptr(y_pred), _ptr(weight), weight_stride, weight_scale, _ptr(loss_out),
+                          int(accumulate), _aptr(dpred, y_pred, "dpred"), loss_scale, n_pix, c, _ptr(partials),
+                          _ptr(running), float(running_weight), _dt(y_pred), _stream()),
           "sv_loss_mse")
 
 
 def loss_mse_map(y_true, y_pred, out, weight=None, weight_stride=1, weight_scale=1.0):
     c = y_pred.shape[-1]
-    check(lib.sv_loss_mse_map(_ptr(y_true), _ptr(y_pred), _ptr(weight), weight_stride, weight_scale, _ptr(out),
-                              y_pred.numel() // c, c, F32, _stream()), "sv_loss_mse_map")
+    check(lib.sv_loss_mse_map(_ptr(y_true), _aptr(y_pred), _ptr(weight), weight_stride, weight_scale, _ptr(out),
+                              y_pred.numel() // c, c, _dt(y_pred), _stream()), "sv_loss_mse_map")
 
 
 def loss_mae(y_true, y_pred, loss_out, partials, dpred=None, loss_scale=1.0, accumulate=False):
     if y_true.numel() != y_pred.numel():
         raise ValueError(f"MAE: y_true {tuple(y_true.shape)} vs y_pred {tuple(y_pred.shape)}")
-    check(lib.sv_loss_mae(_ptr(y_true), _ptr(y_pred), _ptr(loss_out), int(accumulate), _ptr(dpred), loss_scale,
-                          y_pred.numel(), _ptr(partials), F32, _stream()), "sv_loss_mae")
+    check(lib.sv_loss_mae(_ptr(y_true), _aptr(y_pred), _ptr(loss_out), int(accumulate), _aptr(dpred, y_pred, "dpred"),
+                          loss_scale, y_pred.numel(), _ptr(partials), _dt(y_pred), _stream()), "sv_loss_mae")
 
 
 def loss_bce(pred, label: float, from_logits: bool, loss_out, partials, dpred=None, loss_scale=1.0,
              accumulate=False):
-    check(lib.sv_loss_bce(_ptr(pred), label, int(from_logits), _ptr(loss_out), int(accumulate), _ptr(dpred),
-                          loss_scale, pred.numel(), _ptr(partials), F32, _stream()), "sv_loss_bce")
+    check(lib.sv_loss_bce(_aptr(pred), label, int(from_logits), _ptr(loss_out), int(accumulate),
+                          _aptr(dpred, pred, "dpred"), loss_scale, pred.numel(), _ptr(partials), _dt(pred), _stream()),
+          "sv_loss_bce")
 
 
 def adam_prepare(state, lr0, beta1, beta2, decay_steps, decay_rate, staircase):
@@ -417,9 +419,10 @@ def reorder_rows(images, order, out):
 
 
 def mask_input(x, mask, y):
+    """y = x * (1 - mask); x and mask float32, y float32 or bfloat16."""
     if not (x.numel() == mask.numel() == y.numel()):
         raise ValueError("mask_input: sizes differ")
-    check(lib.sv_mask_input(_ptr(x), _ptr(mask), _ptr(y), x.numel(), _stream()), "sv_mask_input")
+    check(lib.sv_mask_input_dt(_ptr(x), _ptr(mask), _aptr(y), x.numel(), _dt(y), _stream()), "sv_mask_input_dt")
 
 
 def fill(t, value: float):
@@ -427,6 +430,19 @@ def fill(t, value: float):
 
 
 def axpy(y, x, a: float):
+    """y += a * x (both float32 or both bfloat16)."""
     if x.numel() != y.numel():
         raise ValueError("axpy: sizes differ")
-    check(lib.sv_axpy_f32(_ptr(y), _ptr(x), a, x.numel(), _stream()), "sv_axpy_f32")
+    check(lib.sv_axpy(_aptr(y), _aptr(x, y, "x"), a, x.numel(), _dt(y), _stream()), "sv_axpy")
+
+
+def cast(src, dst):
+    """dst = src converted between float32 and bfloat16 (either direction)."""
+    if src.numel() != dst.numel():
+        raise ValueError("cast: sizes differ")
+    if src.dtype == torch.float32 and dst.dtype == torch.bfloat16:
+        check(lib.sv_cast_f32_bf16(_ptr(src), _ptr(dst, torch.bfloat16), src.numel(), _stream()), "sv_cast_f32_bf16")
+    elif src.dtype == torch.bfloat16 and dst.dtype == torch.float32:
+        check(lib.sv_cast_bf16_f32(_ptr(src, torch.bfloat16), _ptr(dst), src.numel(), _stream()), "sv_cast_bf16_f32")
+    else:
+        raise TypeError(f"cast: {src.dtype} -> {dst.dtype}")

@@ -89,6 +89,8 @@ class Adam:
         ops.adam_apply(model._params, model._grads, m, v, st, self.beta_1, self.beta_2, self.epsilon, grad_scale,
                        zero_grads)
         model._grads_clean = bool(zero_grads)
+        if model._params_lp is not None:
+            model._refresh_lp()  # the convs of a bf16 model read this copy
 
     # ---- keras surface: optimizer.apply_gradients(zip(grads, variables))
     def apply_gradients(self, grads_and_vars: Iterable):
@@ -111,6 +113,8 @@ class Adam:
             sl = slice(var.offset, var.offset + var.size)
             g = g.as_subclass(torch.Tensor).to(dtype=torch.float32).contiguous().view(-1)
             ops.adam_apply(var.data.view(-1), g, m[sl], v[sl], st, self.beta_1, self.beta_2, self.epsilon, 1.0)
+            if var.owner is not None:
+                var.owner._lp_dirty = True
 
     # ---- checkpointing (not a reference feature; used by the fixed-seed trajectory tests)
     def state_dict(self) -> dict:

@@ -141,11 +141,16 @@ class _StepState:
     """Static device buffers and the captured HIP graph of one (generator, discriminator, batch size)."""
 
     def __init__(self, ce, disc, bs: int, device):
+        if ce._act_dtype != disc._act_dtype:
+            raise ValueError("context encoder and discriminator must be built under the same mixed-precision policy")
+        adt = ce._act_dtype
         shp = (bs,) + ce.input_shape_
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=device)  # noqa: E731
-        self.X, self.mask, self.Xm = f(*shp), f(*shp), f(*shp)
-        self.dpred = f(*((bs,) + ce.output_shape_))
-        self.d_real, self.d_fake = f(bs, 1), f(bs, 1)
+        a = lambda *s: torch.empty(s, dtype=adt, device=device)  # noqa: E731  activations / their gradients
+        self.X, self.mask = f(*shp), f(*shp)
+        self.Xm = a(*shp)
+        self.dpred = a(*((bs,) + ce.output_shape_))
+        self.d_real, self.d_fake = a(bs, 1), a(bs, 1)
         self.l2, self.lt, self.lf, self.disc_loss, self.total = f(1), f(1), f(1), f(1), f(1)
         self.graph = None
         self.warm = False

@@ -62,15 +62,20 @@ def measure_generator_loss(disc_generated_output, gen_output, y, lambda_weight: 
 
 class _StepState:
     def __init__(self, gen, disc, bs, device):
+        if gen._act_dtype != disc._act_dtype:
+            raise ValueError("generator and discriminator must be built under the same mixed-precision policy")
+        adt = gen._act_dtype
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=device)  # noqa: E731
+        a = lambda *s: torch.empty(s, dtype=adt, device=device)  # noqa: E731  activations / their gradients
         h, w, cx = gen.input_shape_
         cy = gen.output_shape_[-1]
-        self.X, self.y = f(bs, h, w, cx), f(bs, h, w, cy)
-        self.cat_real, self.cat_fake = f(bs, h, w, cx + cy), f(bs, h, w, cx + cy)
-        self.d_real, self.d_fake, self.d_gan = f(bs, 1), f(bs, 1), f(bs, 1)
-        self.dgen = f(bs, h, w, cy)       # lambda * dMAE/dgen
-        self.dgen_gan = f(bs, h, w, cy)   # gradient of the GAN term w.r.t. the generated image
-        self.dX_unused = f(bs, h, w, cx)
+        self.X, self.y = f(bs, h, w, cx), f(bs, h, w, cy)  # float32: what the caller hands over, and the loss targets
+        self.Xa, self.ya = (self.X, self.y) if adt == torch.float32 else (a(bs, h, w, cx), a(bs, h, w, cy))
+        self.cat_real, self.cat_fake = a(bs, h, w, cx + cy), a(bs, h, w, cx + cy)
+        self.d_real, self.d_fake, self.d_gan = a(bs, 1), a(bs, 1), a(bs, 1)
+        self.dgen = a(bs, h, w, cy)       # lambda * dMAE/dgen
+        self.dgen_gan = a(bs, h, w, cy)   # gradient of the GAN term w.r.t. the generated image
+        self.dX_unused = a(bs, h, w, cx)
         self.l_real, self.l_fake, self.l_gan, self.l_l1 = f(1), f(1), f(1), f(1)
         self.disc_loss, self.gen_total = f(1), f(1)
         self.graph = None
@@ -101,6 +106,9 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
     rows = n * h * w
     gen.zero_grad_raw()
     disc.zero_grad_raw()
+    if st.Xa is not st.X:  # bf16 policy: the models read bf16 copies of the inputs
+        ops.cast(st.X, st.Xa)
+        ops.cast(st.y, st.ya)
     main0 = torch.cuda.current_stream()
     z_real = None
     if overlap:  # D([X, y]) needs nothing from the generator: it runs beside the generator's forward pass
@@ -108,17 +116,17 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
         start.record(main0)
         with torch.cuda.stream(st.side):
             st.side.wait_event(start)
-            ops.concat_channels_fwd(st.X, st.y, st.cat_real, rows, cx, cy)
+            ops.concat_channels_fwd(st.Xa, st.ya, st.cat_real, rows, cx, cy)
             z_real = disc.forward_raw(st.cat_real, True)   # call 0
             real_done = torch.cuda.Event()
             real_done.record(st.side)
-    gen_out = gen.forward_raw(st.X, True)
+    gen_out = gen.forward_raw(st.Xa, True)
     if overlap:
         main0.wait_event(real_done)  # D(fake) follows D(real): BatchNorm's moving statistics are updated in that order
     else:
-        ops.concat_channels_fwd(st.X, st.y, st.cat_real, rows, cx, cy)
+        ops.concat_channels_fwd(st.Xa, st.ya, st.cat_real, rows, cx, cy)
         z_real = disc.forward_raw(st.cat_real, True)   # call 0
-    ops.concat_channels_fwd(st.X, gen_out, st.cat_fake, rows, cx, cy)
+    ops.concat_channels_fwd(st.Xa, gen_out, st.cat_fake, rows, cx, cy)
     z_fake = disc.forward_raw(st.cat_fake, True)   # call 1
     # generator loss: BCE(1, D(fake)) + lambda * MAE(y, gen_out)
     bce.value_and_grad(1.0, z_fake, st.l_gan, st.d_gan, 1.0)

@@ -50,6 +50,10 @@ CASES = [
     (4, 4, 1, "valid", 4, 4, 256, 1, 7),      # discriminator head: one logit
     (3, 3, 2, "same", 7, 9, 72, 40, 1),       # ragged extents, tiles partly empty
     (4, 4, 2, "same", 8, 8, 128, 96, 2),
+    # enough result tiles for the 128-row tiles (128 x 128 and 128 x 64), with ragged row counts
+    (4, 4, 2, "same", 16, 16, 64, 128, 771),
+    (2, 2, 2, "same", 16, 16, 64, 64, 773),
+    (4, 4, 2, "same", 8, 8, 64, 136, 260),
 ]
 
 
@@ -95,6 +99,8 @@ T_CASES = [
     (4, 4, 2, "same", 4, 4, 128, 64, 3),
     (4, 4, 2, "same", 16, 16, 64, 3, 2),      # context-encoder output layer
     (3, 3, 2, "same", 5, 6, 24, 10, 1),
+    (4, 4, 2, "same", 8, 8, 128, 128, 195),   # 4 row classes x 128-row tiles
+    (2, 2, 2, "same", 8, 8, 128, 64, 770),
 ]
 
 
