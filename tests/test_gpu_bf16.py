@@ -133,3 +133,142 @@ def test_conv2d_transpose_bf16(cfg):
     dw = torch.empty((kh, kw, cout, cin), device="cuda")
     ops.conv2d_transpose_wgrad(g, dev16(x), dev16(dz), dw, False, wsb)
     close(dw, dw_o, F32_RTOL, "convT wgrad")
+
+
+# ================================================================================================ model level
+# Two oracles per model, both the float64 CPU restatement with the model's float32 master weights:
+#   emulation - rounds to bf16 exactly where the engine stores bf16 (input, every layer output, every gradient between
+#               layers, the filters the convs read): what is left is summation order and the occasional one-ulp flip,
+#               amplified by the layers downstream (BatchNorm over small batches amplifies most);
+#   exact     - no rounding anywhere: the distance from it is what the bf16 policy costs.  A rounded activation that
+#               crosses zero flips its ReLU / LeakyReLU mask, so gradients that have come back through k such layers
+#               differ from the exact ones by ~sqrt(k * 0.3 %) in relative L2 however exact the kernels are.
+def _rel_l2(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def _bf16_model_errors(make_model, make_ref, x, tgt):
+    from oracle import torch_ref
+    from spectrum_vae_amd import losses, mixed_precision
+    from spectrum_vae_amd.losses import to_device_f32
+    mixed_precision.set_global_policy("mixed_bfloat16")
+    try:
+        model = make_model()
+    finally:
+        mixed_precision.set_global_policy("float32")
+    assert model.compute_dtype == "bfloat16"
+    model.build((None,) + tuple(x.shape[1:]))
+    model._materialize()
+    model.zero_grad()
+    pred = model.forward_raw(to_device_f32(x), True)
+    assert pred.dtype == torch.bfloat16
+    loss = torch.empty(1, device="cuda")
+    dpred = torch.empty_like(pred)
+    losses.MeanSquaredError().value_and_grad(to_device_f32(tgt), pred, loss, dpred)
+    model.backward_raw(dpred, -1, need_dx=False)
+    g = [v.grad.detach().cpu().numpy() for v in model.trainable_variables]
+    assert all(a.dtype == np.float32 for a in g)  # kernel / bias / BatchNorm gradients stay float32
+    out = {}
+    for name, lowp in (("emulation", True), ("exact", False)):
+        ref = make_ref(lowp)
+        ref.load_params([v.numpy() for v in model.trainable_variables])
+        for p in ref.params:
+            p.grad = None
+        pr = ref(torch.from_numpy(x).to(ref.params[0].dtype), training=True)
+        l = torch_ref.mse(torch.from_numpy(tgt).to(pr.dtype), pr)
+        l.backward()
+        g_ref = [p.grad.numpy() for p in ref.params]
+        out[name] = dict(pred=_rel_l2(pred.float().cpu().numpy(), pr.detach().numpy()),
+                         loss=abs(float(loss) - float(l.detach())) / abs(float(l.detach())),
+                         grad_all=_rel_l2(np.concatenate([a.ravel() for a in g]), np.concatenate([b.ravel() for b in g_ref])),
+                         grad_worst=max(_rel_l2(a, b) for a, b in zip(g, g_ref)))
+    model._calls.clear()
+    return out
+
+
+def _data(n, c=3, seed=1833):
+    from spectrum_vae_amd.data import synth_training_tensor
+    return synth_training_tensor(n, seed)[..., :c].copy()
+
+
+def test_unet_bf16_matches_oracle():
+    """unet.ContextEncoder (unet.py:84-148) under the bf16 policy, batch 16.  Measured on MI355X: against the emulation
+    prediction 1.2e-4, all gradients 5.5e-4, worst tensor 9e-3; against the exact oracle 3.8e-3, 1.3e-2, 0.11."""
+    from oracle import models as omodels
+    from spectrum_vae_amd import unet
+    e = _bf16_model_errors(unet.ContextEncoder, lambda lowp: omodels.RefUNet(dtype=torch.float64, lowp=lowp),
+                           _data(16, 1), _data(16))
+    emu, ex = e["emulation"], e["exact"]
+    assert emu["pred"] <= 1e-3 and emu["loss"] <= 1e-4 and emu["grad_all"] <= 3e-3 and emu["grad_worst"] <= 3e-2, e
+    assert ex["pred"] <= 1.5e-2 and ex["loss"] <= 1e-3 and ex["grad_all"] <= 4e-2 and ex["grad_worst"] <= 0.3, e
+
+
+def test_context_encoder_and_discriminator_bf16_match_oracle():
+    """context_encoder.ContextEncoder / Discriminator (context_encoder.py:212-361) under the bf16 policy, batch 16.
+    The context encoder funnels through a 1 x 1 x 1000 bottleneck and BatchNorm over 16 x 4 x 4 positions, which
+    amplifies every one-ulp difference about 3x per layer (first conv output agrees to 1e-5, the prediction to 7e-3);
+    measured against the emulation: prediction 7e-3, all gradients 6.7e-2; discriminator 2.3e-3, 5.7e-3."""
+    from oracle import models as omodels
+    from oracle.torch_ref import RefSequential
+    from spectrum_vae_amd import context_encoder
+    x = _data(16)
+    enc, dec = omodels.context_encoder()
+    e = _bf16_model_errors(context_encoder.ContextEncoder,
+                           lambda lowp: RefSequential(enc + dec, (32, 32, 3), torch.float64, lowp=lowp), x, x)
+    assert e["emulation"]["pred"] <= 2.5e-2 and e["emulation"]["grad_all"] <= 0.2, e
+    assert e["exact"]["pred"] <= 5e-2 and e["exact"]["grad_all"] <= 0.3, e
+    # torch's float64 CPU conv backward refuses the discriminator's one-filter head: its float32 restatement stands in
+    # (three orders of magnitude closer to the truth than the bf16 effects measured here)
+    d = _bf16_model_errors(context_encoder.Discriminator,
+                           lambda lowp: RefSequential(omodels.discriminator(), (32, 32, 3), torch.float32, lowp=lowp), x,
+                           np.full((16, 1), 0.3, np.float32))
+    assert d["emulation"]["pred"] <= 1e-2 and d["emulation"]["grad_all"] <= 2e-2 and d["emulation"]["grad_worst"] <= 3e-2, d
+    assert d["exact"]["pred"] <= 1.5e-2 and d["exact"]["grad_all"] <= 0.15, d
+
+
+def test_unet_gan_step_bf16():
+    """run_unet.train_step (run_unet.py:164-203) under the bf16 policy against the bf16-emulating CPU restatement of
+    the same step: the four losses of the first step within 2e-3, the first Adam updates in agreement, then replayed
+    (graph) steps stay finite and close.  bf16 tolerance of the configuration: 2e-3 on the losses of one step."""
+    from oracle import models as omodels
+    from oracle.torch_ref import KerasAdam
+    from spectrum_vae_amd import mixed_precision, unet
+    from spectrum_vae_amd.run_unet import build_optimizer, train_step
+    from test_gpu_models import RefUNetDisc, assert_first_updates_agree, ref_unet_step
+    full = _data(48)
+    X, y = full[..., :1].copy(), full
+    mixed_precision.set_global_policy("mixed_bfloat16")
+    try:
+        gen, disc = unet.Generator(), unet.Discriminator()
+    finally:
+        mixed_precision.set_global_policy("float32")
+    gen.build((None, 32, 32, 1)); disc.build((None, 32, 32, 4))
+    gen._materialize(); disc._materialize()
+    rg = omodels.RefUNet(dtype=torch.float32, lowp=True)
+    rd = RefUNetDisc()
+    rd.seq.lowp = True
+    rg.load_params([v.numpy() for v in gen.trainable_variables])
+    rd.seq.load_params([v.numpy() for v in disc.trainable_variables])
+    og, od = build_optimizer(learning_rate=2e-4), build_optimizer(learning_rate=2e-4)
+    rog = KerasAdam(rg.params, 2e-4, beta1=0.5, decay_steps=10, decay_rate=0.96)
+    rod = KerasAdam(rd.params, 2e-4, beta1=0.5, decay_steps=10, decay_rate=0.96)
+    Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
+    w0 = [v.numpy() for v in gen.trainable_variables + disc.trainable_variables]
+    for step in range(5):
+        sl = slice((step % 3) * 16, (step % 3 + 1) * 16)
+        got = [float(v) for v in train_step(gen, disc, og, od, X[sl], y[sl])]
+        want = ref_unet_step(rg, rd, rog, rod, Xt[sl], yt[sl])
+        assert all(np.isfinite(got))
+        tol = 2e-3 if step == 0 else 5e-2
+        for name, g, w in zip(("disc", "gen_total", "gan", "l1"), got, want):
+            assert abs(g - w) <= tol * max(1.0, abs(w)), (step, name, g, w)
+        if step == 0:
+            assert_first_updates_agree(gen.trainable_variables + disc.trainable_variables, w0, rg.params + rd.params,
+                                       frac=0.9)
+    st = next(iter(gen._gan_steps.values()))
+    assert st.graph is not None and st.cat_fake.dtype == torch.bfloat16
+    assert og.iterations == 5 and od.iterations == 5
+    # the bf16 copy the convs read follows the float32 masters
+    v = gen.trainable_variables[0]
+    assert torch.equal(v.data_lp.float(), v.data.to(torch.bfloat16).float())
