@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256) void splitk_finish_k(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
-// The GEMM path pays off when the "column" dimension fills a good part of a 16-wide MFMA tile.
-bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode) {
+// Index ranges the implicit-GEMM kernels can decode, and a reduction of at least min_k terms.
+bool conv_gemm_shape_ok(const sv_conv_geom& g, int mode, int min_k) {
     if (g.up_h != 1 || g.up_w != 1) return false;
     const int ncols = mode == GEMM_DGRAD ? g.Cin : g.Cout;
     const int64_t kdim = mode == GEMM_DGRAD ? (int64_t)g.KH * g.KW * g.Cout
@@ -360,8 +360,11 @@ bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode) {
     const int64_t rdec = mode == GEMM_WGRAD ? kdim : rows, cdec = mode == GEMM_WGRAD ? rows : kdim;
     if (rdec * sp >= (1ll << 32) || cdec * (g.Cin > g.Cout ? g.Cin : g.Cout) >= (1ll << 32)) return false;
     if ((int64_t)g.SH * g.SW > 65535 || (int64_t)g.H * g.W > 65535) return false;  // row classes ride on grid.z
-    return ncols >= 1 && kdim >= 16 && rows < (1ll << 30) && kdim < (1ll << 30);
+    return ncols >= 1 && kdim >= min_k && rows < (1ll << 30) && kdim < (1ll << 30);
 }
+
+// The f32 GEMM path pays off from a reduction of 16 terms (one step of the kernel) on.
+bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode) { return conv_gemm_shape_ok(g, mode, 16); }
 
 static int tile_cols(int ncols) { return ncols <= 16 ? 16 : BN; }
 
@@ -439,8 +442,8 @@ size_t conv_gemm_bf16_wgrad_workspace(const sv_conv_geom& g);  // conv_gemm_bf16
 
 // One query serves both storage types (the entry point does not know the dtype): the larger of the two kernels' needs.
 size_t conv_gemm_wgrad_workspace(const sv_conv_geom& g) {
-    if (!conv_gemm_worthwhile(g, GEMM_WGRAD)) return 0;
-    const size_t f32 = (size_t)conv_gemm_wgrad_splits(g) * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
+    const size_t f32 = conv_gemm_worthwhile(g, GEMM_WGRAD)
+                           ? (size_t)conv_gemm_wgrad_splits(g) * g.KH * g.KW * g.Cin * g.Cout * sizeof(float) : 0;
     const size_t b16 = conv_gemm_bf16_wgrad_workspace(g);
     return f32 > b16 ? f32 : b16;
 }

@@ -255,17 +255,35 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
                     }
                 }
             }
-        } else if (MODE == BGEMM_DGRAD) {  // Cout % 8 == 0 is a launch condition of this mode (va)
+        } else if (MODE == BGEMM_DGRAD) {
             const int kt = k0 + 8 * qc;
-            const bool kok = kt < kend;
-            int kh, kw, co;
-            dgrad_tap(kok ? kt : 0, kh, kw, co);
+            if (p.va) {
+                const bool kok = kt < kend;
+                int kh, kw, co;
+                dgrad_tap(kok ? kt : 0, kh, kw, co);
 #pragma unroll
-            for (int i = 0; i < NAQ; ++i) {
-                const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
-                const int oh = th / g.SH, ow = tw / g.SW;  // exact by construction of the class
-                const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo;
-                av[i] = ld16(p.a + (((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co, ok);
+                for (int i = 0; i < NAQ; ++i) {
+                    const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
+                    const int oh = th / g.SH, ow = tw / g.SW;  // exact by construction of the class
+                    const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo;
+                    av[i] = ld16(p.a + (((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co, ok);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NAQ; ++i) av[i] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool kok = kt + e < kend;
+                    int kh, kw, co;
+                    dgrad_tap(kok ? kt + e : 0, kh, kw, co);
+#pragma unroll
+                    for (int i = 0; i < NAQ; ++i) {
+                        const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
+                        const int oh = th / g.SH, ow = tw / g.SW;
+                        if (kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo)
+                            put_elem(av[i], e, bf_bits(p.a[(((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co]));
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -300,15 +318,33 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
         // ------------------------------------------------------------------ B
         if (MODE == BGEMM_DGRAD) {  // ROW image [n][k]: w[tap][ci = n][co = k]
             const int kt = k0 + 8 * qc;
-            const bool kok = kt < kend;
-            int kh, kw, co;
-            dgrad_tap(kok ? kt : 0, kh, kw, co);
-            const int tap = kh * g.KW + kw;
+            if (p.vb) {
+                const bool kok = kt < kend;
+                int kh, kw, co;
+                dgrad_tap(kok ? kt : 0, kh, kw, co);
+                const int tap = kh * g.KW + kw;
 #pragma unroll
-            for (int i = 0; i < NBQ; ++i) {
-                const int nl = (t >> 3) + 32 * i;
-                const int n = n0 + nl;
-                bv[i] = ld16(p.b + ((int64_t)tap * g.Cin + n) * g.Cout + co, kok && nl < BNT && n < p.N);
+                for (int i = 0; i < NBQ; ++i) {
+                    const int nl = (t >> 3) + 32 * i;
+                    const int n = n0 + nl;
+                    bv[i] = ld16(p.b + ((int64_t)tap * g.Cin + n) * g.Cout + co, kok && nl < BNT && n < p.N);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NBQ; ++i) bv[i] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool kok = kt + e < kend;
+                    int kh, kw, co;
+                    dgrad_tap(kok ? kt + e : 0, kh, kw, co);
+                    const int tap = kh * g.KW + kw;
+#pragma unroll
+                    for (int i = 0; i < NBQ; ++i) {
+                        const int nl = (t >> 3) + 32 * i;
+                        const int n = n0 + nl;
+                        if (kok && nl < BNT && n < p.N) put_elem(bv[i], e, bf_bits(p.b[((int64_t)tap * g.Cin + n) * g.Cout + co]));
+                    }
+                }
             }
         } else {  // TR image [k][n]: FWD w[k][n], WGRAD dz[r][n]; n contiguous in memory
 #pragma unroll
@@ -467,17 +503,15 @@ __global__ __launch_bounds__(256) void splitk_finish_bf16_k(const float* __restr
 // tiles here, as there, and never finer than the f32 kernel cuts them, so sv_conv2d_scratch_bytes covers both kernels;
 // the kernel-gradient workspace query takes the larger of the two kernels' needs (conv_gemm_bf16_wgrad_workspace).
 bool conv_gemm_worthwhile(const sv_conv_geom& g, int mode);
+bool conv_gemm_shape_ok(const sv_conv_geom& g, int mode, int min_k);
 int conv_gemm_splits(const sv_conv_geom& g, int mode);
 size_t conv_gemm_splitk_workspace(const sv_conv_geom& g, int mode);
 
 static bool aligned16b(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// The input-gradient product gathers both operands along Cout in 16-byte pieces: it needs Cout % 8 == 0.
-bool conv_gemm_bf16_ok(const sv_conv_geom& g, int mode) {
-    if (!conv_gemm_worthwhile(g, mode)) return false;
-    if (mode == BGEMM_DGRAD && (g.Cout & 7) != 0) return false;
-    return true;
-}
+// Every geometry the index decoding covers runs on this kernel, short reductions and odd channel counts included (their
+// operands are gathered element by element): the direct kernels' 2-byte loads through the vector path are slower still.
+bool conv_gemm_bf16_ok(const sv_conv_geom& g, int mode) { return conv_gemm_shape_ok(g, mode, 1); }
 
 // Result tile for `rows` x `ncols` results in `zmult` independent groups (row classes, reduction splits): the largest
 // tile that still leaves every CU more than one workgroup.
@@ -552,9 +586,8 @@ int launch_conv_gemm_bf16_dgrad(const sv_conv_geom& g, const void* dz, const voi
     p.a = (const bf16_t*)dz; p.b = (const bf16_t*)w; p.bias = bias; p.c = (bf16_t*)dx; p.act = act; p.alpha = alpha;
     p.M = g.N * g.H * g.W; p.N = g.Cin; p.K = g.KH * g.KW * g.Cout;
     p.one_out = g.Ho == 1 && g.Wo == 1;
-    if ((g.Cout & 7) != 0 || !aligned16b(dz) || !aligned16b(w))
-        return fail(SV_E_UNSUPPORTED, "conv_gemm_bf16<dgrad>: needs Cout %% 8 == 0 and 16-byte aligned tensors");
-    p.va = p.vb = 1;
+    p.va = (g.Cout & 7) == 0 && aligned16b(dz);
+    p.vb = (g.Cout & 7) == 0 && aligned16b(w);
     int classes, rows;
     int64_t kclass;
     if (p.one_out) {
@@ -614,7 +647,7 @@ static WgradSel bf16_wgrad_plan(const sv_conv_geom& g) {
 int conv_gemm_bf16_wgrad_splits(const sv_conv_geom& g) { return bf16_wgrad_plan(g).splits; }
 
 size_t conv_gemm_bf16_wgrad_workspace(const sv_conv_geom& g) {
-    if (!conv_gemm_worthwhile(g, BGEMM_WGRAD)) return 0;
+    if (!conv_gemm_bf16_ok(g, BGEMM_WGRAD)) return 0;
     return (size_t)bf16_wgrad_plan(g).splits * g.KH * g.KW * g.Cin * g.Cout * sizeof(float);
 }
 

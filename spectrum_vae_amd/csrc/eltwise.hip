@@ -547,10 +547,11 @@ struct ColPlan {
 };
 ColPlan col_plan(int64_t rows, int C) {
     // A thread's row loop is a chain of dependent-latency loads, so keep it near 8 iterations (a block sweeps
-    // 256 / C rows at once when C < 256); at most 1024 blocks, which the 4-wave fold then sums in 32 rounds of loads.
+    // 256 / C rows at once when C < 256); at most 512 blocks: the fold that follows is one workgroup per 64 channels
+    // whose 4 waves walk the blocks' partial sums, i.e. pure latency that grows with the block count.
     const int64_t sweep = C < 256 ? 256 / C : 1;
     int64_t rpb = 8 * sweep;
-    const int64_t floor_rpb = ceil_div(rows, 1024);
+    const int64_t floor_rpb = ceil_div(rows, 512);
     if (rpb < floor_rpb) rpb = floor_rpb;
     ColPlan p;
     p.rows_per_block = rpb;
