@@ -276,7 +276,10 @@ int sv_reparam_kl_bwd(const float* mean, const float* logvar, const float* eps, 
                       float* dlogvar, float kl_weight, int B, int D, sv_stream_t stream);
 
 /* ---- losses.  Each writes the scalar loss to loss_out[0] (device; += when accumulate != 0) and, if dpred != NULL,
- *      loss_scale * dL/dpred.  partials is scratch of sv_loss_workspace_bytes().
+ *      loss_scale * dL/dpred, in ONE launch: the workgroup that arrives last folds the workgroups' partial sums in index
+ *      order (bit-reproducible).  partials is scratch of sv_loss_workspace_bytes() that must be ZERO-FILLED ONCE before its
+ *      first use (its tail holds the arrival counter, which every launch leaves zero); launches sharing one scratch must
+ *      not overlap in time.
  *  MSE (run_model.py:140,281; run_unet.py:102): mean over all elements.  With weight != NULL
  *  (run_context_encoder.py:190-198) weight is [n_pix] and the loss is sum_p w[p]*mean_c(d^2) / n_pix.
  *  weight_stride lets the caller pass channel 0 of an NHWC mask directly (stride = C). */
@@ -309,6 +312,14 @@ int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out,
  *      (grad_scale = 1/world_size after a sum all-reduce).  zero_grad != 0 also clears grad once it has been read, so
  *      the next backward pass of a training loop (which accumulates) needs no separate fill.  Buffers must be 16-byte
  *      aligned. */
+/* Both steps in one launch (every thread derives the step size from the count, the workgroup that finishes last advances
+ * it): what a training step uses.  step_state is 24 bytes here: the 16 of the two-launch form (same contents afterwards)
+ * and a third word holding an arrival counter that must be zero before the first launch (a zero-filled state is) and is
+ * left zero by every launch.
+ * theta_bf16 (may be NULL): a bf16 copy of theta written in the same pass, for models whose convs read bf16 filters. */
+int sv_adam_keras_step(float* theta, float* grad, float* m, float* v, int64_t n, int64_t* step_state, float lr0,
+                       float beta1, float beta2, float eps, int decay_steps, float decay_rate, int staircase,
+                       float grad_scale, int zero_grad, void* theta_bf16, sv_stream_t stream);
 int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float beta2, int decay_steps,
                           float decay_rate, int staircase, sv_stream_t stream);
 int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n, const int64_t* step_state,

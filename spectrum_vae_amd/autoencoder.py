@@ -146,7 +146,7 @@ class Sampling(Layer):
         b, d = z_mean.shape
         z = torch.empty_like(z_mean)
         kl = torch.empty(1, dtype=torch.float32, device=z_mean.device)
-        part = torch.empty(ops.loss_workspace_floats(), dtype=torch.float32, device=z_mean.device)
+        part = torch.zeros(ops.loss_workspace_floats(), dtype=torch.float32, device=z_mean.device)
         eps_in = to_device_f32(epsilon, z_mean.device) if epsilon is not None else None
         ops.reparam_kl_fwd(z_mean, z_log_var, eps_in, z, None, kl, part, self.seed, self.calls * b * d)
         self.calls += 1

@@ -793,8 +793,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const BlockPos bp
                 for (int r = 0; r < K; ++r) {
                     const float4 v4 = *reinterpret_cast<const float4*>(xp + r * a.xwp);
                     xv[r][0] = v4.x; xv[r][1] = v4.y; xv[r][2] = v4.z; xv[r][3] = v4.w;
+                    // the K - 1 columns past the strip as 8-byte pairs (XC - 4 is even): consecutive lanes sit 16 bytes
+                    // apart, where 4-byte reads collide four ways on the LDS banks
 #pragma unroll
-                    for (int c = 4; c < XC; ++c) xv[r][c] = xp[r * a.xwp + c];
+                    for (int c = 4; c < XC; c += 2) {
+                        const float2 v2 = *reinterpret_cast<const float2*>(xp + r * a.xwp + c);
+                        xv[r][c] = v2.x; xv[r][c + 1] = v2.y;
+                    }
                 }
                 const float* zp = z_lds + (ss * n_cot * CO_T + cot * CO_T) * a.zplane + oh * a.Wo + ow0;
                 float zv[CO_T][4];

@@ -6,6 +6,9 @@
 namespace sv {
 
 constexpr int kLossBlocks = 1024;
+// Loss workspace: kLossBlocks partial sums, then one 32-bit arrival counter (in a 16-byte tail).  The counter must be
+// zero before the first launch that uses the workspace; every launch leaves it zero again.
+constexpr size_t kLossWsBytes = (size_t)kLossBlocks * sizeof(float) + 16;
 
 // ------------------------------------------------------------------------------------------------ losses
 // mode 0: squared error, weight per pixel optional;  mode 1: absolute error;
@@ -15,7 +18,9 @@ template <int MODE, typename T>
 __global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const T* __restrict__ p,
                                                const float* __restrict__ weight, int wstride, float wscale, int C,
                                                float label, float inv_count, T* __restrict__ dpred,
-                                               float loss_scale, int64_t n, float* __restrict__ partials) {
+                                               float loss_scale, int64_t n, float* __restrict__ partials,
+                                               float* __restrict__ out, int accumulate, float* __restrict__ running,
+                                               float running_weight) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -44,7 +49,36 @@ __global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const
         if (dpred != nullptr) dpred[i] = (T)(loss_scale * g * inv_count);
     }
     const float s = block_sum_256(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    // The block whose arrival is last folds all partial sums (in index order, whichever block that is: the value does not
+    // depend on scheduling).  Partial sums travel as write-through stores and are read back past the L1; the counter
+    // is an agent-scope atomic issued after the store has drained.
+    __shared__ int is_last;
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(partials + kLossBlocks);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partials[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = prev == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __shared__ double dred[256];
+    double ds = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
+        ds += (double)__hip_atomic_load(&partials[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dred[threadIdx.x] = ds;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) dred[threadIdx.x] += dred[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)(dred[0] * (double)inv_count);
+        const float r = accumulate ? out[0] + v : v;
+        out[0] = r;
+        if (running != nullptr) running[0] += running_weight * r;  // an epoch's running sum, in the same launch
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // one block of 256 threads: fixed-order tree over the (<= 1024) block partials
@@ -104,6 +138,17 @@ __global__ void adam_prepare_k(int64_t* __restrict__ state, float lr0, float bet
     }
 }
 
+// One element's update with the roundings spelled out, so that every kernel using it (vector body or scalar tail,
+// one-launch or two-launch form) produces the same bits.
+__device__ __forceinline__ void adam_update1(float& th, float& m, float& v, float g, float alpha, float beta1, float beta2,
+                                             float eps, float grad_scale) {
+#pragma clang fp contract(off)
+    const float gg = g * grad_scale;
+    m = __fmaf_rn(beta1, m, (1.f - beta1) * gg);
+    v = __fmaf_rn(beta2, v, ((1.f - beta2) * gg) * gg);
+    th = th - (alpha * m) / (sqrtf(v) + eps);
+}
+
 __global__ void adam_apply_k(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m,
                              float* __restrict__ v, int64_t n, const int64_t* __restrict__ state, float beta1,
                              float beta2, float eps, float grad_scale, int zero_grad) {
@@ -115,13 +160,7 @@ __global__ void adam_apply_k(float* __restrict__ theta, float* __restrict__ grad
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         float4 th = reinterpret_cast<float4*>(theta)[i];
-#define SV_ADAM1(f)                                        \
-    {                                                      \
-        const float gg = g.f * grad_scale;                 \
-        mm.f = beta1 * mm.f + (1.f - beta1) * gg;          \
-        vv.f = beta2 * vv.f + (1.f - beta2) * gg * gg;     \
-        th.f -= alpha * mm.f / (sqrtf(vv.f) + eps);        \
-    }
+#define SV_ADAM1(f) adam_update1(th.f, mm.f, vv.f, g.f, alpha, beta1, beta2, eps, grad_scale);
         SV_ADAM1(x) SV_ADAM1(y) SV_ADAM1(z) SV_ADAM1(w)
 #undef SV_ADAM1
         reinterpret_cast<float4*>(m)[i] = mm;
@@ -130,13 +169,78 @@ __global__ void adam_apply_k(float* __restrict__ theta, float* __restrict__ grad
         if (zero_grad) reinterpret_cast<float4*>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float gg = grad[i] * grad_scale;
-        const float mi = beta1 * m[i] + (1.f - beta1) * gg;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gg * gg;
+        float th = theta[i], mi = m[i], vi = v[i];
+        adam_update1(th, mi, vi, grad[i], alpha, beta1, beta2, eps, grad_scale);
         m[i] = mi;
         v[i] = vi;
-        theta[i] -= alpha * mi / (sqrtf(vi) + eps);
+        theta[i] = th;
         if (zero_grad) grad[i] = 0.f;
+    }
+}
+
+// Schedule + update in ONE launch.  Every thread derives the step size from the update count it reads at its start; the
+// count is advanced by the workgroup that finishes last (an arrival counter in the state's second word), i.e. after every
+// workgroup has read it.  state: int64 count, {alpha, lr} of the last update as two floats (the layout the two-launch form
+// keeps), then a third 8-byte word whose low half is the arrival counter (zero between launches).
+// theta_lp (optional): a bf16 copy of theta refreshed in the same pass (the filters a bf16 model's convs read).
+__global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, int64_t* __restrict__ state, float lr0,
+                                                    float beta1, float beta2, float eps, int decay_steps, float decay_rate,
+                                                    int staircase, float grad_scale, int zero_grad,
+                                                    __bf16* __restrict__ theta_lp) {
+    __shared__ float alpha_s, lr_s;
+    const int64_t it = state[0];
+    if (threadIdx.x == 0) {
+        double lr = (double)lr0;
+        if (decay_steps > 0) {
+            double e = (double)it / (double)decay_steps;
+            if (staircase) e = floor(e);
+            lr *= pow((double)decay_rate, e);
+        }
+        const double t = (double)(it + 1);
+        alpha_s = (float)(lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+        lr_s = (float)lr;
+    }
+    __syncthreads();
+    const float alpha = alpha_s;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 g = reinterpret_cast<const float4*>(grad)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float4 th = reinterpret_cast<float4*>(theta)[i];
+#define SV_ADAM1(f) adam_update1(th.f, mm.f, vv.f, g.f, alpha, beta1, beta2, eps, grad_scale);
+        SV_ADAM1(x) SV_ADAM1(y) SV_ADAM1(z) SV_ADAM1(w)
+#undef SV_ADAM1
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        reinterpret_cast<float4*>(theta)[i] = th;
+        if (zero_grad) reinterpret_cast<float4*>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (theta_lp != nullptr) {
+            theta_lp[4 * i] = (__bf16)th.x; theta_lp[4 * i + 1] = (__bf16)th.y;
+            theta_lp[4 * i + 2] = (__bf16)th.z; theta_lp[4 * i + 3] = (__bf16)th.w;
+        }
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float th = theta[i], mi = m[i], vi = v[i];
+        adam_update1(th, mi, vi, grad[i], alpha, beta1, beta2, eps, grad_scale);
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] = th;
+        if (zero_grad) grad[i] = 0.f;
+        if (theta_lp != nullptr) theta_lp[i] = (__bf16)th;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int* ticket = reinterpret_cast<unsigned int*>(state + 2);
+        const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {  // every workgroup has read the count: advance it for the next launch
+            state[0] = it + 1;
+            reinterpret_cast<float*>(state + 1)[0] = alpha_s;
+            reinterpret_cast<float*>(state + 1)[1] = lr_s;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -270,7 +374,7 @@ using namespace sv;
 
 extern "C" {
 
-size_t sv_loss_workspace_bytes(void) { return (size_t)kLossBlocks * sizeof(float); }
+size_t sv_loss_workspace_bytes(void) { return kLossWsBytes; }
 
 int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int weight_stride, float weight_scale,
                 float* loss_out, int accumulate, void* dpred, float loss_scale, int64_t n_pix, int C, float* partials,
@@ -283,12 +387,8 @@ int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int
     const float inv = 1.f / (float)n;
     SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<0, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
                                         (const T*)y_pred, weight, weight_stride, weight_scale, C, 0.f, inv, (T*)dpred,
-                                        loss_scale, n, partials););
-    int rc = check_launch("sv_loss_mse");
-    if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate,
-                       running, running_weight);
-    return check_launch("sv_loss_mse/fold");
+                                        loss_scale, n, partials, loss_out, accumulate, running, running_weight););
+    return check_launch("sv_loss_mse");
 }
 
 int sv_loss_mse_map(const void* y_true, const void* y_pred, const float* weight, int weight_stride,
@@ -309,11 +409,8 @@ int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int acc
     const float inv = 1.f / (float)n;
     SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<1, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
                                         (const T*)y_pred, (const float*)nullptr, 1, 1.f, 1, 0.f, inv, (T*)dpred, loss_scale,
-                                        n, partials););
-    int rc = check_launch("sv_loss_mae");
-    if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
-    return check_launch("sv_loss_mae/fold");
+                                        n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
+    return check_launch("sv_loss_mae");
 }
 
 int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out, int accumulate, void* dpred,
@@ -325,15 +422,12 @@ int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out,
     if (from_logits)
         SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<3, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
                                             (const T*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (T*)dpred,
-                                            loss_scale, n, partials););
+                                            loss_scale, n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
     else
         SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<2, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
                                             (const T*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (T*)dpred,
-                                            loss_scale, n, partials););
-    int rc = check_launch("sv_loss_bce");
-    if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
-    return check_launch("sv_loss_bce/fold");
+                                            loss_scale, n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
+    return check_launch("sv_loss_bce");
 }
 
 int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float beta2, int decay_steps,
@@ -354,6 +448,20 @@ int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n
     hipLaunchKernelGGL(adam_apply_k, dim3(ew_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, to_stream(stream), theta,
                        grad, m, v, n, step_state, beta1, beta2, eps, grad_scale, zero_grad);
     return check_launch("sv_adam_keras_apply");
+}
+
+int sv_adam_keras_step(float* theta, float* grad, float* m, float* v, int64_t n, int64_t* step_state, float lr0,
+                       float beta1, float beta2, float eps, int decay_steps, float decay_rate, int staircase,
+                       float grad_scale, int zero_grad, void* theta_bf16, sv_stream_t stream) {
+    SV_REQUIRE(theta && grad && m && v && step_state && n > 0, "sv_adam_keras_step: bad arguments");
+    SV_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "sv_adam_keras_step: betas out of range");
+    SV_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                   ((uintptr_t)v % 16 == 0),
+               "sv_adam_keras_step: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, to_stream(stream), theta, grad, m, v,
+                       n, step_state, lr0, beta1, beta2, eps, decay_steps, decay_rate, staircase, grad_scale, zero_grad,
+                       (__bf16*)theta_bf16);
+    return check_launch("sv_adam_keras_step");
 }
 
 int sv_dense_fwd(const void* x, const void* w, const void* bias, void* y, int M, int K, int N, int act, float alpha,

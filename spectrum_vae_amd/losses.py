@@ -22,7 +22,8 @@ _scratch = {}
 def _scratch_for(device):
     s = _scratch.get(device)
     if s is None:
-        s = {"partials": torch.empty(ops.loss_workspace_floats(), dtype=torch.float32, device=device)}
+        # zero-filled: the tail of the scratch is the arrival counter of the one-launch losses
+        s = {"partials": torch.zeros(ops.loss_workspace_floats(), dtype=torch.float32, device=device)}
         _scratch[device] = s
     return s
 

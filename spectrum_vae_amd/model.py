@@ -495,8 +495,9 @@ class Model(Layer):
 
     def _train_step_body(self, b: dict, same_xy: bool, weight: float):
         if self._reducer is None:
-            self._fwd_bwd(b, same_xy, weight, prepare_opt=True)
-            self.optimizer.apply_model(self, 1.0, prepared=True, zero_grads=True)
+            side = self._side_stream() is not None  # with side streams the schedule update runs beside the forward pass
+            self._fwd_bwd(b, same_xy, weight, prepare_opt=side)
+            self.optimizer.apply_model(self, 1.0, prepared=side, zero_grads=True)
             return
         self._fwd_bwd(b, same_xy, weight)
         scale = self._reducer.all_reduce(self._grads)

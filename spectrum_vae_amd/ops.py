@@ -376,6 +376,19 @@ def adam_prepare(state, lr0, beta1, beta2, decay_steps, decay_rate, staircase):
                                     int(staircase), _stream()), "sv_adam_keras_prepare")
 
 
+def adam_step(theta, grad, m, v, state, lr0, beta1, beta2, eps, decay_steps, decay_rate, staircase, grad_scale=1.0,
+              zero_grad=False, theta_lp=None):
+    """Schedule + update in one launch; ``theta_lp``: optional bfloat16 copy of theta refreshed in the same pass."""
+    if not (theta.numel() == grad.numel() == m.numel() == v.numel()):
+        raise ValueError("adam: buffer sizes differ")
+    if theta_lp is not None and theta_lp.numel() != theta.numel():
+        raise ValueError("adam: the bf16 copy has a different size")
+    check(lib.sv_adam_keras_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), _ptr(state, torch.int64), lr0,
+                                 beta1, beta2, eps, int(decay_steps or 0), decay_rate, int(staircase), grad_scale,
+                                 int(zero_grad), _ptr(theta_lp, torch.bfloat16) if theta_lp is not None else None,
+                                 _stream()), "sv_adam_keras_step")
+
+
 def adam_apply(theta, grad, m, v, state, beta1, beta2, eps, grad_scale=1.0, zero_grad=False):
     if not (theta.numel() == grad.numel() == m.numel() == v.numel()):
         raise ValueError("adam: buffer sizes differ")

@@ -44,13 +44,13 @@ class Adam:
             self.schedule = None
             self.lr0 = float(learning_rate)
         self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
-        self._state: Optional[torch.Tensor] = None  # int64[2] on the device: update count, {alpha, lr}
+        self._state: Optional[torch.Tensor] = None  # int64[3] on the device: update count, {alpha, lr}, arrival counter
         self._slots: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ---- device state
     def _ensure_state(self, device):
         if self._state is None:
-            self._state = torch.zeros(2, dtype=torch.int64, device=device)
+            self._state = torch.zeros(3, dtype=torch.int64, device=device)
         return self._state
 
     def _slots_for(self, model):
@@ -84,13 +84,20 @@ class Adam:
     def apply_model(self, model, grad_scale: float = 1.0, prepared: bool = False, zero_grads: bool = False):
         """``zero_grads``: the launch also clears the model's gradient buffer (training loops whose next backward
         accumulates into it), which saves the separate fill of the next step."""
-        st = self._ensure_state(model._params.device) if prepared else self._prepare(model._params.device)
         m, v = self._slots_for(model)
-        ops.adam_apply(model._params, model._grads, m, v, st, self.beta_1, self.beta_2, self.epsilon, grad_scale,
-                       zero_grads)
+        st = self._ensure_state(model._params.device)
+        if prepared:
+            ops.adam_apply(model._params, model._grads, m, v, st, self.beta_1, self.beta_2, self.epsilon, grad_scale,
+                           zero_grads)
+            if model._params_lp is not None:
+                model._refresh_lp()  # the convs of a bf16 model read this copy
+        else:  # schedule, update and (bf16 models) the refresh of the filter copy in one launch
+            sc = self.schedule
+            ops.adam_step(model._params, model._grads, m, v, st, self.lr0, self.beta_1, self.beta_2, self.epsilon,
+                          sc.decay_steps if sc else 0, sc.decay_rate if sc else 1.0, sc.staircase if sc else False,
+                          grad_scale, zero_grads, model._params_lp)
+            model._lp_dirty = False
         model._grads_clean = bool(zero_grads)
-        if model._params_lp is not None:
-            model._refresh_lp()  # the convs of a bf16 model read this copy
 
     # ---- keras surface: optimizer.apply_gradients(zip(grads, variables))
     def apply_gradients(self, grads_and_vars: Iterable):

@@ -423,7 +423,7 @@ def test_losses():
     rng = np.random.default_rng(16)
     shape = (5, 8, 8, 3)
     t, p = rng.standard_normal(shape), rng.standard_normal(shape)
-    part = torch.empty(ops.loss_workspace_floats(), device="cuda")
+    part = torch.zeros(ops.loss_workspace_floats(), device="cuda")
     out = torch.empty(1, device="cuda")
     dp = torch.empty(shape, device="cuda")
     ops.loss_mse(dev(t), dev(p), out, part, dp)
@@ -506,13 +506,53 @@ def test_adam_keras_and_schedule():
     assert torch.equal(ga, gz) and not gb.any()
 
 
+@pytest.mark.parametrize("n", [1003, 70000, 2_000_003])
+def test_adam_single_launch_step_equals_two_launch_form(n):
+    """Schedule + update (+ the bf16 copy) in one launch: bit-equal to prepare + apply, count advanced exactly once per
+    launch whatever the number of workgroups, arrival counter back at zero."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(171)
+    th_a = dev(rng.standard_normal(n))
+    th_b = th_a.clone()
+    m_a, v_a, m_b, v_b = (torch.zeros(n, device="cuda") for _ in range(4))
+    st_a = torch.zeros(2, dtype=torch.int64, device="cuda")
+    st_b = torch.zeros(3, dtype=torch.int64, device="cuda")
+    lp = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for it in range(12):
+        g = dev(rng.standard_normal(n))
+        ga, gb = g.clone(), g.clone()
+        ops.adam_prepare(st_a, 5e-4, 0.9, 0.999, 5, 0.9, it % 2 == 0)
+        ops.adam_apply(th_a, ga, m_a, v_a, st_a, 0.9, 0.999, 1e-7, 0.5, zero_grad=True)
+        ops.adam_step(th_b, gb, m_b, v_b, st_b, 5e-4, 0.9, 0.999, 1e-7, 5, 0.9, it % 2 == 0, 0.5, zero_grad=True,
+                      theta_lp=lp)
+        assert not gb.any()
+    assert torch.equal(th_a, th_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b)
+    assert torch.equal(st_a, st_b[:2]) and int(st_b[0].item()) == 12 and int(st_b[2].item()) == 0
+    assert torch.equal(lp, th_b.to(torch.bfloat16))
+
+
+def test_loss_scratch_counter_returns_to_zero():
+    """The one-launch losses fold in the workgroup that arrives last and leave the arrival counter (the scratch's tail) at
+    zero, so one zero-filled scratch serves any sequence of launches of any size."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(172)
+    part = torch.zeros(ops.loss_workspace_floats(), device="cuda")
+    out = torch.empty(1, device="cuda")
+    for shape in [(1024, 64, 36, 1), (3, 5, 7, 1), (256, 64, 36, 1), (1, 1, 1, 1)]:
+        t, p = rng.random(shape), rng.random(shape)
+        d = torch.empty(shape, device="cuda")
+        ops.loss_mse(dev(t), dev(p), out, part, d)
+        close(out, np.array([np_ops.mse(t, p)]), what=f"mse {shape}")
+        assert int(part[-4:].view(torch.int32)[0].item()) == 0
+
+
 def test_reparam_kl():
     from spectrum_vae_amd import ops
     rng = np.random.default_rng(18)
     b, d = 64, 8
     mu, lv, eps = rng.standard_normal((b, d)), rng.standard_normal((b, d)) * 0.5, rng.standard_normal((b, d))
     z, kl = torch.empty((b, d), device="cuda"), torch.empty(1, device="cuda")
-    part = torch.empty(ops.loss_workspace_floats(), device="cuda")
+    part = torch.zeros(ops.loss_workspace_floats(), device="cuda")
     ops.reparam_kl_fwd(dev(mu), dev(lv), dev(eps), z, None, kl, part)
     close(z, np_ops.sampling(mu, lv, eps), what="sampling")
     close(kl, np.array([np_ops.kl_standard_normal(mu, lv)]), what="kl")
