@@ -114,6 +114,14 @@ typedef struct sv_net_layer {
 int sv_convnet_supported(const sv_net_layer* layers, int n_layers, int N, int H, int W);
 int sv_convnet_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
                    int dtype, sv_stream_t stream);
+/* The same launch with the reconstruction loss of the training step (`self.loss(x, decoded)` with MeanSquaredError,
+ * run_model.py:140,281) evaluated while the output leaves the workgroup: dpred = loss_scale * dMSE/dy, and
+ * partials[0..*n_partials) (room for sv_loss_workspace_bytes()) receive per-workgroup sums of squared errors; the loss is
+ * their sum / (N * Hout * Wout * Cout), folded later on the same stream by sv_fold_scalar or by sv_adam_keras_step's
+ * fold arguments.  The last layer must not be pooled. */
+int sv_convnet_fwd_mse(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
+                       const float* y_true, float* dpred, float loss_scale, float* partials, int* n_partials, int dtype,
+                       sv_stream_t stream);
 
 /* ---- Whole-network backward of the same chain (the gradient tape of run_model.py:281-289 / `model.fit`): given
  *      dpred = dL/d(output of the last layer) and the y / idx tensors sv_convnet_fwd wrote, grads (+)= the gradient of
@@ -276,10 +284,7 @@ int sv_reparam_kl_bwd(const float* mean, const float* logvar, const float* eps, 
                       float* dlogvar, float kl_weight, int B, int D, sv_stream_t stream);
 
 /* ---- losses.  Each writes the scalar loss to loss_out[0] (device; += when accumulate != 0) and, if dpred != NULL,
- *      loss_scale * dL/dpred, in ONE launch: the workgroup that arrives last folds the workgroups' partial sums in index
- *      order (bit-reproducible).  partials is scratch of sv_loss_workspace_bytes() that must be ZERO-FILLED ONCE before its
- *      first use (its tail holds the arrival counter, which every launch leaves zero); launches sharing one scratch must
- *      not overlap in time.
+ *      loss_scale * dL/dpred.  partials is scratch of sv_loss_workspace_bytes().
  *  MSE (run_model.py:140,281; run_unet.py:102): mean over all elements.  With weight != NULL
  *  (run_context_encoder.py:190-198) weight is [n_pix] and the loss is sum_p w[p]*mean_c(d^2) / n_pix.
  *  weight_stride lets the caller pass channel 0 of an NHWC mask directly (stride = C). */
@@ -316,10 +321,18 @@ int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out,
  * it): what a training step uses.  step_state is 24 bytes here: the 16 of the two-launch form (same contents afterwards)
  * and a third word holding an arrival counter that must be zero before the first launch (a zero-filled state is) and is
  * left zero by every launch.
- * theta_bf16 (may be NULL): a bf16 copy of theta written in the same pass, for models whose convs read bf16 filters. */
+ * theta_bf16 (may be NULL): a bf16 copy of theta written in the same pass, for models whose convs read bf16 filters.
+ * fold_partials (may be NULL): a pending scalar fold carried by one workgroup of this launch:
+ * fold_out[0] = fold_scale * sum(fold_partials[0..fold_n)) in a fixed order, fold_running[0] += fold_running_weight *
+ * fold_out[0] when fold_running != NULL (the epoch's running loss of the fit loop). */
 int sv_adam_keras_step(float* theta, float* grad, float* m, float* v, int64_t n, int64_t* step_state, float lr0,
                        float beta1, float beta2, float eps, int decay_steps, float decay_rate, int staircase,
-                       float grad_scale, int zero_grad, void* theta_bf16, sv_stream_t stream);
+                       float grad_scale, int zero_grad, void* theta_bf16, const float* fold_partials, int fold_n,
+                       float fold_scale, float* fold_out, float* fold_running, float fold_running_weight,
+                       sv_stream_t stream);
+/* out[0] = [out[0] +] scale * sum(partials[0..n)) in a fixed order (one workgroup); running as above. */
+int sv_fold_scalar(const float* partials, int n, float scale, float* out, int accumulate, float* running,
+                   float running_weight, sv_stream_t stream);
 int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float beta2, int decay_steps,
                           float decay_rate, int staircase, sv_stream_t stream);
 int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n, const int64_t* step_state,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sv_conv2d_bwd": (_i, [_g, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _sz, _i, _p]),
     "sv_convnet_supported": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i]),
     "sv_convnet_fwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _i, _p]),
+    "sv_convnet_fwd_mse": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, C.POINTER(C.c_int), _i, _p]),
     "sv_convnet_bwd_workspace_bytes": (_sz, [C.POINTER(NetLayer), _i, _i, _i, _i, _i64]),
     "sv_convnet_bwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _p, _p, _i64, _i, _p, _sz, _i, _p]),
     "sv_conv2d_bwd_partial": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p, _sz, _i, _p]),
@@ -108,7 +109,9 @@ SIGNATURES = {
     "sv_loss_mse_map": (_i, [_p, _p, _p, _i, _f, _p, _i64, _i, _i, _p]),
     "sv_loss_mae": (_i, [_p, _p, _p, _i, _p, _f, _i64, _p, _i, _p]),
     "sv_loss_bce": (_i, [_p, _f, _i, _p, _i, _p, _f, _i64, _p, _i, _p]),
-    "sv_adam_keras_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _f, _i, _f, _i, _p, _p]),
+    "sv_adam_keras_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _f, _i, _f, _i, _p, _p, _i, _f, _p, _p, _f,
+                                _p]),
+    "sv_fold_scalar": (_i, [_p, _i, _f, _p, _i, _p, _f, _p]),
     "sv_adam_keras_prepare": (_i, [_p, _f, _f, _f, _i, _f, _i, _p]),
     "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),
     "sv_gather_rows": (_i, [_p, _i, _p, _p, _i64, _i64, _p]),

@@ -54,6 +54,13 @@ struct NetFwdArgs {
     int N, S, n_layers;
     int w_off;    // LDS float offset of the filter arena ([tap][Cin][cop] + cop bias values)
     int idx_off;  // LDS float offset of the argmax byte arena
+    // squared-error loss evaluated while the network output leaves (all null / zero when the forward runs alone):
+    // loss_t = targets shaped like the output, loss_dpred receives loss_gscale * (y - t), loss_partials[blockIdx.x] the
+    // workgroup's sum of (y - t)^2
+    const float* loss_t;
+    float* loss_dpred;
+    float* loss_partials;
+    float loss_gscale;
     NetLayer L[kMaxNetLayers];
 };
 
@@ -365,9 +372,11 @@ __device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const Ne
     }
 }
 
-// output arena (planar) -> global NHWC, argmax bytes -> global
+// output arena (planar) -> global NHWC, argmax bytes -> global.  LOSS: the values are also compared with the targets
+// (squared error summed into lacc, its gradient written) on their way out.
+template <bool LOSS>
 __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer& L, const float* smem, int n0, int ns,
-                                             int nt) {
+                                             int nt, float& lacc) {
     const int Ho = L.Hs * L.up, Wo = L.Ws * L.up;
     const int Hout = L.pool ? Ho >> 1 : Ho, Wout = L.pool ? Wo >> 1 : Wo;
     const int P = Hout * Wout;
@@ -384,7 +393,18 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
             const int row = fd(p, fW), col = p - row * Wout;
             const float* q = out + (size_t)(s * L.Cout + 4 * c4) * L.out_plane + (row + oh) * L.out_wp + col + oh;
             const float4 v = make_float4(q[0], q[L.out_plane], q[2 * L.out_plane], q[3 * L.out_plane]);
-            *reinterpret_cast<float4*>(L.y + ((size_t)n0 * P + r) * L.Cout + 4 * c4) = v;
+            const size_t gi = ((size_t)n0 * P + r) * L.Cout + 4 * c4;
+            *reinterpret_cast<float4*>(L.y + gi) = v;
+            if (LOSS) {
+                const float4 t = *reinterpret_cast<const float4*>(a.loss_t + gi);
+                const float4 d = make_float4(v.x - t.x, v.y - t.y, v.z - t.z, v.w - t.w);
+                lacc += d.x * d.x;
+                lacc += d.y * d.y;
+                lacc += d.z * d.z;
+                lacc += d.w * d.w;
+                *reinterpret_cast<float4*>(a.loss_dpred + gi) =
+                    make_float4(a.loss_gscale * d.x, a.loss_gscale * d.y, a.loss_gscale * d.z, a.loss_gscale * d.w);
+            }
         }
         if (L.pool && L.idx != nullptr) {
             const uint32_t* ib = reinterpret_cast<const uint32_t*>(smem + a.idx_off);
@@ -398,7 +418,14 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
             const int r = fd(u, fC), c = u - r * L.Cout;
             const int s = fd(r, fP), p = r - s * P;
             const int row = fd(p, fW), col = p - row * Wout;
-            L.y[(size_t)n0 * P * L.Cout + u] = out[(size_t)(s * L.Cout + c) * L.out_plane + (row + oh) * L.out_wp + col + oh];
+            const float v = out[(size_t)(s * L.Cout + c) * L.out_plane + (row + oh) * L.out_wp + col + oh];
+            const size_t gi = (size_t)n0 * P * L.Cout + u;
+            L.y[gi] = v;
+            if (LOSS) {
+                const float d = v - a.loss_t[gi];
+                lacc += d * d;
+                a.loss_dpred[gi] = a.loss_gscale * d;
+            }
         }
         if (L.pool && L.idx != nullptr) {
             const uint8_t* ib = reinterpret_cast<const uint8_t*>(smem + a.idx_off);
@@ -414,6 +441,7 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
     float* w_lds = smem + a.w_off;
     float4 wpre[kNetWPre];
     float bpre;
+    float lacc = 0.f;
     NET_MARK(0);
     for (int n0 = blockIdx.x * a.S; n0 < a.N; n0 += gridDim.x * a.S) {
         const int ns = min(a.S, a.N - n0);
@@ -467,8 +495,20 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
             __syncthreads();
             NET_MARK(3 + 3 * l);
             // [E]
-            net_copy_out(a, L, smem, n0, ns, nt);
+            if (a.loss_t != nullptr && l + 1 == a.n_layers) net_copy_out<true>(a, L, smem, n0, ns, nt, lacc);
+            else net_copy_out<false>(a, L, smem, n0, ns, nt, lacc);
             NET_MARK(4 + 3 * l);
+        }
+    }
+    if (a.loss_t != nullptr) {  // fixed-order sum over the workgroup: lanes of a wave, then the waves in index order
+        __shared__ float lred[16];
+        for (int o = 32; o > 0; o >>= 1) lacc += __shfl_down(lacc, o);
+        if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = lacc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < (nt >> 6); ++w) t += lred[w];
+            a.loss_partials[blockIdx.x] = t;
         }
     }
 }
@@ -1215,21 +1255,52 @@ int sv_convnet_supported(const sv_net_layer* layers, int n_layers, int N, int H,
     return plan_net_fwd(layers, n_layers, N, H, W).ok ? 1 : 0;
 }
 
-int sv_convnet_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
-                   int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_convnet_fwd");
-    int rc = net_validate(layers, n_layers, N, H, W, "sv_convnet_fwd");
+static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x,
+                           const void* params, const float* y_true, float* dpred, float loss_scale, float* partials,
+                           int* n_partials, sv_stream_t stream) {
+    int rc = net_validate(layers, n_layers, N, H, W, who);
     if (rc) return rc;
-    SV_REQUIRE(x && params, "sv_convnet_fwd: null tensor");
-    for (int l = 0; l < n_layers; ++l) SV_REQUIRE(layers[l].y != nullptr, "sv_convnet_fwd: layer %d has no output buffer", l);
+    SV_REQUIRE(x && params, "%s: null tensor", who);
+    for (int l = 0; l < n_layers; ++l) SV_REQUIRE(layers[l].y != nullptr, "%s: layer %d has no output buffer", who, l);
     NetPlan p = plan_net_fwd(layers, n_layers, N, H, W);
-    if (!p.ok) return fail(SV_E_UNSUPPORTED, "sv_convnet_fwd: the activations of one sample do not fit the LDS arenas");
+    if (!p.ok) return fail(SV_E_UNSUPPORTED, "%s: the activations of one sample do not fit the LDS arenas", who);
     rc = net_enable_lds(p.lds_bytes);
     if (rc) return rc;
     p.args.x = (const float*)x;
     p.args.params = (const float*)params;
+    if (y_true != nullptr) {
+        const sv_net_layer& last = layers[n_layers - 1];
+        SV_REQUIRE(!last.pool, "%s: the last layer's output must leave unpooled", who);
+        int h = H, w = W;
+        for (int l = 0; l < n_layers; ++l) {
+            h = h * layers[l].up / (layers[l].pool ? 2 : 1);
+            w = w * layers[l].up / (layers[l].pool ? 2 : 1);
+        }
+        const double count = (double)N * h * w * last.Cout;
+        p.args.loss_t = y_true;
+        p.args.loss_dpred = dpred;
+        p.args.loss_partials = partials;
+        p.args.loss_gscale = (float)(2.0 * (double)loss_scale / count);
+        *n_partials = p.grid;
+    }
     hipLaunchKernelGGL((net_fwd_s1<3>), dim3((unsigned)p.grid), dim3((unsigned)p.nt), p.lds_bytes, to_stream(stream), p.args);
     return check_launch("net_fwd_s1");
+}
+
+int sv_convnet_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
+                   int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_convnet_fwd");
+    return convnet_fwd_any("sv_convnet_fwd", layers, n_layers, N, H, W, x, params, nullptr, nullptr, 0.f, nullptr, nullptr,
+                           stream);
+}
+
+int sv_convnet_fwd_mse(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
+                       const float* y_true, float* dpred, float loss_scale, float* partials, int* n_partials, int dtype,
+                       sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_convnet_fwd_mse");
+    SV_REQUIRE(y_true && dpred && partials && n_partials, "sv_convnet_fwd_mse: null loss argument");
+    return convnet_fwd_any("sv_convnet_fwd_mse", layers, n_layers, N, H, W, x, params, y_true, dpred, loss_scale, partials,
+                           n_partials, stream);
 }
 
 size_t sv_convnet_bwd_workspace_bytes(const sv_net_layer* layers, int n_layers, int N, int H, int W, int64_t n_params) {

@@ -6,9 +6,6 @@
 namespace sv {
 
 constexpr int kLossBlocks = 1024;
-// Loss workspace: kLossBlocks partial sums, then one 32-bit arrival counter (in a 16-byte tail).  The counter must be
-// zero before the first launch that uses the workspace; every launch leaves it zero again.
-constexpr size_t kLossWsBytes = (size_t)kLossBlocks * sizeof(float) + 16;
 
 // ------------------------------------------------------------------------------------------------ losses
 // mode 0: squared error, weight per pixel optional;  mode 1: absolute error;
@@ -18,9 +15,7 @@ template <int MODE, typename T>
 __global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const T* __restrict__ p,
                                                const float* __restrict__ weight, int wstride, float wscale, int C,
                                                float label, float inv_count, T* __restrict__ dpred,
-                                               float loss_scale, int64_t n, float* __restrict__ partials,
-                                               float* __restrict__ out, int accumulate, float* __restrict__ running,
-                                               float running_weight) {
+                                               float loss_scale, int64_t n, float* __restrict__ partials) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -49,42 +44,25 @@ __global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const
         if (dpred != nullptr) dpred[i] = (T)(loss_scale * g * inv_count);
     }
     const float s = block_sum_256(acc, red);
-    // The block whose arrival is last folds all partial sums (in index order, whichever block that is: the value does not
-    // depend on scheduling).  Partial sums travel as write-through stores and are read back past the L1; the counter
-    // is an agent-scope atomic issued after the store has drained.
-    __shared__ int is_last;
-    unsigned int* ticket = reinterpret_cast<unsigned int*>(partials + kLossBlocks);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&partials[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = prev == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __shared__ double dred[256];
-    double ds = 0.0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
-        ds += (double)__hip_atomic_load(&partials[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    dred[threadIdx.x] = ds;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) dred[threadIdx.x] += dred[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float v = (float)(dred[0] * (double)inv_count);
-        const float r = accumulate ? out[0] + v : v;
-        out[0] = r;
-        if (running != nullptr) running[0] += running_weight * r;  // an epoch's running sum, in the same launch
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-// one block of 256 threads: fixed-order tree over the (<= 1024) block partials
-__global__ __launch_bounds__(256) void loss_fold_k(const float* __restrict__ partials, int nblocks, float inv_count,
-                                                    float* __restrict__ out, int accumulate,
-                                                    float* __restrict__ running = nullptr, float running_weight = 0.f) {
+// A scalar fold some later launch of the same stream carries out on behalf of a kernel that left per-workgroup partial sums
+// (the fused forward + loss): out = [out +] scale * sum(partials[0..n)), running += running_weight * out.
+struct ScalarFold {
+    const float* partials;
+    int n;
+    float scale;
+    float* out;
+    int accumulate;
+    float* running;
+    float running_weight;
+};
+
+// 256 threads of one block: fixed-order tree over the partial sums
+__device__ __forceinline__ void fold_scalar_256(const float* __restrict__ partials, int nblocks, float inv_count,
+                                                float* __restrict__ out, int accumulate, float* __restrict__ running,
+                                                float running_weight) {
     __shared__ double red[256];
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partials[b];
@@ -100,6 +78,12 @@ __global__ __launch_bounds__(256) void loss_fold_k(const float* __restrict__ par
         out[0] = r;
         if (running != nullptr) running[0] += running_weight * r;  // an epoch's running sum, in the same launch
     }
+}
+
+__global__ __launch_bounds__(256) void loss_fold_k(const float* __restrict__ partials, int nblocks, float inv_count,
+                                                    float* __restrict__ out, int accumulate,
+                                                    float* __restrict__ running = nullptr, float running_weight = 0.f) {
+    fold_scalar_256(partials, nblocks, inv_count, out, accumulate, running, running_weight);
 }
 
 template <typename T>
@@ -187,8 +171,11 @@ __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ theta, fl
                                                     float* __restrict__ v, int64_t n, int64_t* __restrict__ state, float lr0,
                                                     float beta1, float beta2, float eps, int decay_steps, float decay_rate,
                                                     int staircase, float grad_scale, int zero_grad,
-                                                    __bf16* __restrict__ theta_lp) {
+                                                    __bf16* __restrict__ theta_lp, ScalarFold fold) {
     __shared__ float alpha_s, lr_s;
+    // the last workgroup carries a pending scalar fold (it has the least parameter work)
+    if (fold.partials != nullptr && blockIdx.x == gridDim.x - 1)
+        fold_scalar_256(fold.partials, fold.n, fold.scale, fold.out, fold.accumulate, fold.running, fold.running_weight);
     const int64_t it = state[0];
     if (threadIdx.x == 0) {
         double lr = (double)lr0;
@@ -374,7 +361,7 @@ using namespace sv;
 
 extern "C" {
 
-size_t sv_loss_workspace_bytes(void) { return kLossWsBytes; }
+size_t sv_loss_workspace_bytes(void) { return (size_t)kLossBlocks * sizeof(float); }
 
 int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int weight_stride, float weight_scale,
                 float* loss_out, int accumulate, void* dpred, float loss_scale, int64_t n_pix, int C, float* partials,
@@ -387,8 +374,12 @@ int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int
     const float inv = 1.f / (float)n;
     SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<0, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
                                         (const T*)y_pred, weight, weight_stride, weight_scale, C, 0.f, inv, (T*)dpred,
-                                        loss_scale, n, partials, loss_out, accumulate, running, running_weight););
-    return check_launch("sv_loss_mse");
+                                        loss_scale, n, partials););
+    int rc = check_launch("sv_loss_mse");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate,
+                       running, running_weight);
+    return check_launch("sv_loss_mse/fold");
 }
 
 int sv_loss_mse_map(const void* y_true, const void* y_pred, const float* weight, int weight_stride,
@@ -409,8 +400,11 @@ int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int acc
     const float inv = 1.f / (float)n;
     SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<1, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
                                         (const T*)y_pred, (const float*)nullptr, 1, 1.f, 1, 0.f, inv, (T*)dpred, loss_scale,
-                                        n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
-    return check_launch("sv_loss_mae");
+                                        n, partials););
+    int rc = check_launch("sv_loss_mae");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    return check_launch("sv_loss_mae/fold");
 }
 
 int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out, int accumulate, void* dpred,
@@ -422,12 +416,15 @@ int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out,
     if (from_logits)
         SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<3, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
                                             (const T*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (T*)dpred,
-                                            loss_scale, n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
+                                            loss_scale, n, partials););
     else
         SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<2, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
                                             (const T*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (T*)dpred,
-                                            loss_scale, n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
-    return check_launch("sv_loss_bce");
+                                            loss_scale, n, partials););
+    int rc = check_launch("sv_loss_bce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
+    return check_launch("sv_loss_bce/fold");
 }
 
 int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float beta2, int decay_steps,
@@ -450,17 +447,29 @@ int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n
     return check_launch("sv_adam_keras_apply");
 }
 
+int sv_fold_scalar(const float* partials, int n, float scale, float* out, int accumulate, float* running,
+                   float running_weight, sv_stream_t stream) {
+    SV_REQUIRE(partials && out && n > 0, "sv_fold_scalar: bad arguments");
+    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, n, scale, out, accumulate, running,
+                       running_weight);
+    return check_launch("sv_fold_scalar");
+}
+
 int sv_adam_keras_step(float* theta, float* grad, float* m, float* v, int64_t n, int64_t* step_state, float lr0,
                        float beta1, float beta2, float eps, int decay_steps, float decay_rate, int staircase,
-                       float grad_scale, int zero_grad, void* theta_bf16, sv_stream_t stream) {
+                       float grad_scale, int zero_grad, void* theta_bf16, const float* fold_partials, int fold_n,
+                       float fold_scale, float* fold_out, float* fold_running, float fold_running_weight,
+                       sv_stream_t stream) {
     SV_REQUIRE(theta && grad && m && v && step_state && n > 0, "sv_adam_keras_step: bad arguments");
+    SV_REQUIRE(fold_partials == nullptr || (fold_n > 0 && fold_out != nullptr), "sv_adam_keras_step: bad fold arguments");
     SV_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "sv_adam_keras_step: betas out of range");
     SV_REQUIRE(((uintptr_t)theta % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                    ((uintptr_t)v % 16 == 0),
                "sv_adam_keras_step: buffers must be 16-byte aligned");
+    const ScalarFold fold{fold_partials, fold_n, fold_scale, fold_out, 0, fold_running, fold_running_weight};
     hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, to_stream(stream), theta, grad, m, v,
                        n, step_state, lr0, beta1, beta2, eps, decay_steps, decay_rate, staircase, grad_scale, zero_grad,
-                       (__bf16*)theta_bf16);
+                       (__bf16*)theta_bf16, fold);
     return check_launch("sv_adam_keras_step");
 }
 

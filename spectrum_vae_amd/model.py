@@ -88,6 +88,7 @@ class Model(Layer):
         # Run the whole forward as ONE launch when the model is a plain chain of fusable 3x3 convs (see
         # ``_conv_chain``); the per-layer buffers are filled exactly as the per-layer path fills them.
         self.use_net_fused = True
+        self.fuse_loss = True  # MeanSquaredError evaluated inside the one-launch forward, folded by the optimizer launch
         # measured at batch 1024 (step time in ms for large / small = 256/256: 0.297, 128/256: 0.291, 128/128: 0.292, 64/256: 0.321)
         self.wgrad_batch_blocks_large = int(os.environ.get("SPECTRUM_WGRAD_BLOCKS_LARGE", "128"))  # layers of >= 256 pixels
         self.wgrad_batch_blocks = int(os.environ.get("SPECTRUM_WGRAD_BLOCKS", "256"))  # workgroups per layer when >= 3 layers share the batched kernel-gradient launch
@@ -304,8 +305,11 @@ class Model(Layer):
                 return None
         return chain or None
 
-    def _net_forward(self, ctx, x: torch.Tensor):
-        """One-launch forward; returns None when the model (or this batch size) is outside the fused family."""
+    def _net_forward(self, ctx, x: torch.Tensor, mse=None):
+        """One-launch forward; returns None when the model (or this batch size) is outside the fused family.
+        ``mse = (y_true, dpred, partials)``: the launch also evaluates the squared-error loss against ``y_true``
+        (gradient into ``dpred``, per-workgroup sums into ``partials``; ``ctx.loss_fold`` then describes the pending
+        fold ``(partials, n, 1 / count)``)."""
         n = x.shape[0]
         key = (n, ctx.slot if not isinstance(ctx.slot, int) else "train%d" % ctx.slot)
         plan = self._chain_cache.get(key)
@@ -331,7 +335,12 @@ class Model(Layer):
         if plan is False:
             return None
         arr, bufs, h, w = plan
-        ops.convnet_fwd(arr, n, h, w, x, self._params)
+        if mse is not None and bufs[-1][2] is None and tuple(mse[0].shape) == tuple(bufs[-1][1].shape):
+            y_true, dpred, partials = mse
+            cnt = ops.convnet_fwd_mse(arr, n, h, w, x, self._params, y_true, dpred, 1.0, partials)
+            ctx.loss_fold = (partials, cnt, 1.0 / y_true.numel())
+        else:
+            ops.convnet_fwd(arr, n, h, w, x, self._params)
         if ctx.training:
             ctx.net = (plan, x)
         prev = x
@@ -341,9 +350,10 @@ class Model(Layer):
             prev = y
         return prev
 
-    def forward_raw(self, x: torch.Tensor, training: bool, side=None) -> torch.Tensor:
+    def forward_raw(self, x: torch.Tensor, training: bool, side=None, mse=None) -> torch.Tensor:
         """Forward on a prepared device tensor; the result aliases the model's buffer pool.  ``side``: stream
-        the backward pass of this call may use for its weight-gradient kernels (the caller joins it)."""
+        the backward pass of this call may use for its weight-gradient kernels (the caller joins it).  ``mse``: see
+        ``_net_forward``; honoured only when the whole forward is the one-launch kernel (check ``ctx.loss_fold``)."""
         if training:
             ctx = CallCtx(self._pool, len(self._calls), True, self._act_dtype)
             ctx.side = side
@@ -354,8 +364,9 @@ class Model(Layer):
             if self._lp_dirty:
                 self._refresh_lp()
             x = self._to_act(x, ctx.slot)
+        ctx.loss_fold = None
         if self.use_net_fused and not ctx.lp:
-            y = self._net_forward(ctx, x)
+            y = self._net_forward(ctx, x, mse)
             if y is not None:
                 return y
         return self.forward(ctx, x)
@@ -476,9 +487,15 @@ class Model(Layer):
                             self.optimizer.prepare(self._params.device)
                     else:
                         sd.wait_event(zeroed)
-        pred = self.forward_raw(b["x"], True, side)
         yt = b["x"] if same_xy else b["y"]
-        if getattr(self.loss, "fuses_running_sum", False):
+        mse = None
+        if type(self.loss) is losses_mod.MeanSquaredError and self.fuse_loss and self._act_dtype == torch.float32:
+            mse = (yt, b["dpred"], self._pool.get(("fit", "loss_partials"), (ops.loss_workspace_floats(),)))
+        pred = self.forward_raw(b["x"], True, side, mse)
+        fold = self._calls[-1].loss_fold
+        if fold is not None:  # loss and its gradient left with the forward launch; the optimizer launch folds the sums
+            fold = fold + (b["loss"], b["acc"], weight)
+        elif getattr(self.loss, "fuses_running_sum", False):
             self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0, running=b["acc"], running_weight=weight)
         else:
             self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0)
@@ -492,16 +509,17 @@ class Model(Layer):
                 done.record(sd)
                 main.wait_event(done)
         self._calls.clear()
+        return fold
 
     def _train_step_body(self, b: dict, same_xy: bool, weight: float):
         if self._reducer is None:
             side = self._side_stream() is not None  # with side streams the schedule update runs beside the forward pass
-            self._fwd_bwd(b, same_xy, weight, prepare_opt=side)
-            self.optimizer.apply_model(self, 1.0, prepared=side, zero_grads=True)
+            fold = self._fwd_bwd(b, same_xy, weight, prepare_opt=side)
+            self.optimizer.apply_model(self, 1.0, prepared=side, zero_grads=True, fold=fold)
             return
-        self._fwd_bwd(b, same_xy, weight)
+        fold = self._fwd_bwd(b, same_xy, weight)
         scale = self._reducer.all_reduce(self._grads)
-        self.optimizer.apply_model(self, scale, zero_grads=True)
+        self.optimizer.apply_model(self, scale, zero_grads=True, fold=fold)
 
     def zero_grad_raw(self):
         ops.fill(self._grads, 0.0)
@@ -535,9 +553,9 @@ class Model(Layer):
                 g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 # thread-local capture: the process group's watchdog thread polls events while this thread records
                 with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
-                    self._fwd_bwd(b, same_xy, weight)
+                    fold = self._fwd_bwd(b, same_xy, weight)
                 with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
-                    self.optimizer.apply_model(self, scale, zero_grads=True)
+                    self.optimizer.apply_model(self, scale, zero_grads=True, fold=fold)
                 g = (g_fb, g_opt)
             self._graphs[key] = g
         if not self._grads_clean:

@@ -176,6 +176,8 @@ class CallCtx:
         # here; the owner finishes all of them with one launch after the backward pass.  None: reduce per layer.
         self.wgrad_jobs: Optional[list] = None
         self.wgrad_finish: list = []
+        # (partials, n, scale) when the forward launch also evaluated the loss and left per-workgroup sums to fold
+        self.loss_fold: Optional[tuple] = None
 
     def buf(self, layer, role, shape, dtype=None):
         return self.pool.get((id(layer), role, self.slot), shape, self.dtype if dtype is None else dtype)

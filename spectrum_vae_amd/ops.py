@@ -160,6 +160,22 @@ def convnet_fwd(arr, n: int, h: int, w: int, x, params):
     check(lib.sv_convnet_fwd(arr, len(arr), n, h, w, _ptr(x), _ptr(params), F32, _stream()), "sv_convnet_fwd")
 
 
+def convnet_fwd_mse(arr, n: int, h: int, w: int, x, params, y_true, dpred, loss_scale, partials) -> int:
+    """Forward + squared-error loss gradient in one launch; returns how many entries of ``partials`` hold the
+    per-workgroup sums of squared errors (fold them with ``fold_scalar`` or the optimizer launch)."""
+    if y_true.numel() != dpred.numel() or partials.numel() < loss_workspace_floats():
+        raise ValueError("convnet_fwd_mse: y_true / dpred sizes differ or the partial-sum scratch is too small")
+    cnt = C.c_int(0)
+    check(lib.sv_convnet_fwd_mse(arr, len(arr), n, h, w, _ptr(x), _ptr(params), _ptr(y_true), _ptr(dpred), loss_scale,
+                                 _ptr(partials), C.byref(cnt), F32, _stream()), "sv_convnet_fwd_mse")
+    return int(cnt.value)
+
+
+def fold_scalar(partials, n: int, scale: float, out, accumulate=False, running=None, running_weight=0.0):
+    check(lib.sv_fold_scalar(_ptr(partials), int(n), float(scale), _ptr(out), int(accumulate), _ptr(running),
+                             float(running_weight), _stream()), "sv_fold_scalar")
+
+
 def convnet_bwd_workspace(arr, n: int, h: int, w: int, n_params: int) -> int:
     return int(lib.sv_convnet_bwd_workspace_bytes(arr, len(arr), n, h, w, n_params))
 
@@ -377,8 +393,9 @@ def adam_prepare(state, lr0, beta1, beta2, decay_steps, decay_rate, staircase):
 
 
 def adam_step(theta, grad, m, v, state, lr0, beta1, beta2, eps, decay_steps, decay_rate, staircase, grad_scale=1.0,
-              zero_grad=False, theta_lp=None):
-    """Schedule + update in one launch; ``theta_lp``: optional bfloat16 copy of theta refreshed in the same pass."""
+              zero_grad=False, theta_lp=None, fold=None):
+    """Schedule + update in one launch; ``theta_lp``: optional bfloat16 copy of theta refreshed in the same pass;
+    ``fold``: optional pending scalar fold ``(partials, n, scale, out, running, running_weight)`` carried by the launch."""
     if not (theta.numel() == grad.numel() == m.numel() == v.numel()):
         raise ValueError("adam: buffer sizes differ")
     if theta_lp is not None and theta_lp.numel() != theta.numel():
@@ -386,6 +403,8 @@ def adam_step(theta, grad, m, v, state, lr0, beta1, beta2, eps, decay_steps, dec
     check(lib.sv_adam_keras_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), _ptr(state, torch.int64), lr0,
                                  beta1, beta2, eps, int(decay_steps or 0), decay_rate, int(staircase), grad_scale,
                                  int(zero_grad), _ptr(theta_lp, torch.bfloat16) if theta_lp is not None else None,
+                                 *((_ptr(fold[0]), int(fold[1]), float(fold[2]), _ptr(fold[3]), _ptr(fold[4]),
+                                    float(fold[5])) if fold is not None else (None, 0, 0.0, None, None, 0.0)),
                                  _stream()), "sv_adam_keras_step")
 
 

@@ -530,6 +530,60 @@ def test_whole_network_forward_matches_per_layer_path_and_oracle(n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 5, 64, 1100])
+def test_forward_launch_with_loss_matches_the_separate_loss(n):
+    """MSE evaluated while the one-launch forward writes its output: gradient and value against the loss kernel, the value
+    folded once by sv_fold_scalar and once by the optimizer launch (which must also still apply its update)."""
+    from spectrum_vae_amd import autoencoder, losses, ops
+    from spectrum_vae_amd.losses import to_device_f32
+    from spectrum_vae_amd.optimizers import Adam
+    x = data(n, seed=23 + n)
+    model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+    model.build((None, 32, 32, 3))
+    model._materialize()
+    xt = to_device_f32(x)
+    pred = model.forward_raw(xt, True).clone()
+    want_loss, want_d = torch.zeros(1, device="cuda"), torch.empty_like(pred)
+    losses.MeanSquaredError().value_and_grad(xt, pred, want_loss, want_d, 1.0)
+    model._calls.clear()
+    part = torch.full((ops.loss_workspace_floats(),), float("nan"), device="cuda")
+    got_d = torch.empty_like(pred)
+    pred2 = model.forward_raw(xt, True, None, (xt, got_d, part))
+    fold = model._calls[-1].loss_fold
+    assert fold is not None and fold[1] >= 1 and torch.equal(pred2, pred)
+    assert rel(got_d.cpu().numpy(), want_d.cpu().numpy()) < 1e-6
+    got = torch.zeros(1, device="cuda")
+    ops.fold_scalar(part, fold[1], fold[2], got)
+    assert abs(float(got) - float(want_loss)) <= 2e-6 * abs(float(want_loss))
+    # the same fold riding on the optimizer launch, with a running sum
+    out2, run = torch.zeros(1, device="cuda"), torch.full((1,), 3.0, device="cuda")
+    opt = Adam(1e-3)
+    model._grads.normal_()
+    before = model._params.clone()
+    opt.apply_model(model, 1.0, zero_grads=True, fold=(part, fold[1], fold[2], out2, run, 0.5))
+    assert float(out2) == float(got) and abs(float(run) - (3.0 + 0.5 * float(got))) < 1e-6
+    assert opt.iterations == 1 and not torch.equal(before, model._params) and not model._grads.any()
+
+
+@pytest.mark.gpu
+def test_fit_with_loss_inside_the_forward_launch_equals_the_separate_loss():
+    from spectrum_vae_amd import autoencoder, losses
+    from spectrum_vae_amd.optimizers import Adam
+    x = data(96, seed=31)
+    hist = {}
+    for fuse in (True, False):
+        model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+        model.fuse_loss = fuse
+        model.build((None, 32, 32, 3))
+        model.compile(optimizer=Adam(1e-3), loss=losses.MeanSquaredError())
+        torch.manual_seed(5)
+        h = model.fit(x, x, epochs=3, batch_size=32, shuffle=False, verbose=0)
+        hist[fuse] = (np.array(h.history["loss"]), model._params.cpu().numpy().copy())
+    assert np.allclose(hist[True][0], hist[False][0], rtol=1e-5)
+    assert np.abs(hist[True][1] - hist[False][1]).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 64, 1100])
 def test_whole_network_backward_matches_per_layer_path(n):
     """Gradients of the one-launch backward against the per-layer kernels, for MSE against the input."""
     from spectrum_vae_amd import autoencoder, losses

@@ -531,21 +531,6 @@ def test_adam_single_launch_step_equals_two_launch_form(n):
     assert torch.equal(lp, th_b.to(torch.bfloat16))
 
 
-def test_loss_scratch_counter_returns_to_zero():
-    """The one-launch losses fold in the workgroup that arrives last and leave the arrival counter (the scratch's tail) at
-    zero, so one zero-filled scratch serves any sequence of launches of any size."""
-    from spectrum_vae_amd import ops
-    rng = np.random.default_rng(172)
-    part = torch.zeros(ops.loss_workspace_floats(), device="cuda")
-    out = torch.empty(1, device="cuda")
-    for shape in [(1024, 64, 36, 1), (3, 5, 7, 1), (256, 64, 36, 1), (1, 1, 1, 1)]:
-        t, p = rng.random(shape), rng.random(shape)
-        d = torch.empty(shape, device="cuda")
-        ops.loss_mse(dev(t), dev(p), out, part, d)
-        close(out, np.array([np_ops.mse(t, p)]), what=f"mse {shape}")
-        assert int(part[-4:].view(torch.int32)[0].item()) == 0
-
-
 def test_reparam_kl():
     from spectrum_vae_amd import ops
     rng = np.random.default_rng(18)
