@@ -275,10 +275,12 @@ int sv_reduce_sum_h_bwd(const void* dy, void* dx, int N, int H, int W, int C, in
 /* ---- Sampling (autoencoder.py:264-272): z = mean + exp(0.5*logvar)*eps, eps ~ N(0,1) from a counter-based
  *      generator (seed, offset) or, when eps_in != NULL, supplied by the caller.  kl_out (1 float) receives
  *      mean_b( -1/2 sum_d(1 + logvar - mean^2 - exp(logvar)) ); the KL term has no counterpart in the reference.
- *      eps_out (optional) stores the epsilon used, for the backward pass. */
+ *      eps_out (optional) stores the epsilon used, for the backward pass.  rng_counter (optional, one uint64 on the
+ *      device): its value is added to offset and the call advances it by B*D after drawing, so a recorded (HIP graph)
+ *      step draws fresh values at every replay. */
 int sv_reparam_kl_fwd(const float* mean, const float* logvar, const float* eps_in, float* z, float* eps_out,
                       float* kl_out, float* partials /* sv_loss_workspace_bytes() */, int B, int D, uint64_t seed,
-                      uint64_t offset, sv_stream_t stream);
+                      uint64_t offset, uint64_t* rng_counter, sv_stream_t stream);
 /* dmean = dz + kl_weight*mean/B ; dlogvar = dz*0.5*exp(0.5*logvar)*eps + kl_weight*0.5*(exp(logvar)-1)/B */
 int sv_reparam_kl_bwd(const float* mean, const float* logvar, const float* eps, const float* dz, float* dmean,
                       float* dlogvar, float kl_weight, int B, int D, sv_stream_t stream);

@@ -94,6 +94,55 @@ def caepadded(input_shape=(32, 32, 3), initial_filters=8, conv_layer_multiplier=
     return enc, dec
 
 
+class RefVAEPadded:
+    """Variational form of ``caepadded``: NO REFERENCE MODEL (the reference ships only the Sampling layer,
+    autoencoder.py:264-272).  Conv stack + Flatten + Dense layers of autoencoder.py:461-494 -> two linear Dense heads
+    (z_mean, z_log_var) -> z = mean + exp(0.5 * logvar) * eps (autoencoder.py:272) -> the decoder of
+    autoencoder.py:496-526.  loss = mse(x, decoded) + beta * mean_b(-1/2 sum_d(1 + logvar - mean^2 - exp(logvar))).
+    Parameter order: encoder, z_mean, z_log_var, decoder (each in Keras order)."""
+
+    def __init__(self, input_shape=(32, 32, 3), initial_filters=8, conv_layer_multiplier=2, conv_layers=3, fc_layers=2,
+                 fc_layer_size=64, activation="elu", kernel_size=3, conv_operations=2, latent_dimensions=8, beta=1.0,
+                 dtype=torch.float64, seed=1833):
+        enc, dec = caepadded(input_shape, initial_filters, conv_layer_multiplier, conv_layers, fc_layers, fc_layer_size,
+                             0.0, activation, kernel_size, conv_operations, latent_dimensions, False)
+        enc = enc[:-1]  # the auto-encoder's bottleneck Dense is replaced by the two heads
+        self.beta = float(beta)
+        self.encoder = RefSequential(enc, input_shape, dtype, seed)
+        feat = self.encoder.output_shape
+        self.z_mean = RefSequential([_dense(latent_dimensions, None)], feat, dtype, seed + 1)
+        self.z_log_var = RefSequential([_dense(latent_dimensions, None)], feat, dtype, seed + 2)
+        self.decoder = RefSequential(dec, (latent_dimensions,), dtype, seed + 3)
+        self.dtype = dtype
+
+    @property
+    def parts(self):
+        return [self.encoder, self.z_mean, self.z_log_var, self.decoder]
+
+    @property
+    def params(self):
+        return [p for m in self.parts for p in m.params]
+
+    def load_params(self, arrays: Sequence):
+        i = 0
+        for m in self.parts:
+            m.load_params(arrays[i:i + len(m.params)])
+            i += len(m.params)
+        assert i == len(arrays)
+
+    def __call__(self, x, eps, training=False):
+        """Returns (decoded, kl); ``eps``: the (batch, latent) standard-normal draw."""
+        h = self.encoder(x, training=training)
+        mean, logvar = self.z_mean(h, training=training), self.z_log_var(h, training=training)
+        z = mean + torch.exp(0.5 * logvar) * eps
+        kl = torch.mean(-0.5 * torch.sum(1 + logvar - mean * mean - torch.exp(logvar), dim=1))
+        return self.decoder(z, training=training), kl
+
+    def loss(self, x, eps, training=True):
+        dec, kl = self(x, eps, training)
+        return torch.mean((dec - x) ** 2) + self.beta * kl
+
+
 def cae1d(input_shape=(32, 32, 3), initial_filters=8, conv_layer_multiplier=2, conv_layers=3, fc_layers=2,
           fc_layer_size=64, dropout=0.5, activation="elu", kernel_size=3, conv_operations=2,
           latent_dimensions=8) -> Tuple[list, list]:

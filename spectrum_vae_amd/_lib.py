@@ -102,7 +102,7 @@ SIGNATURES = {
     "sv_dropout_bwd": (_i, [_p, _p, _i64, _f, _u64, _u64, _i, _p]),
     "sv_reduce_sum_h_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "sv_reduce_sum_h_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
-    "sv_reparam_kl_fwd": (_i, [_p] * 7 + [_i, _i, _u64, _u64, _p]),
+    "sv_reparam_kl_fwd": (_i, [_p] * 7 + [_i, _i, _u64, _u64, _p, _p]),
     "sv_reparam_kl_bwd": (_i, [_p] * 6 + [_f, _i, _i, _p]),
     "sv_loss_workspace_bytes": (_sz, []),
     "sv_loss_mse": (_i, [_p, _p, _p, _i, _f, _p, _i, _p, _f, _i64, _i, _p, _p, _f, _i, _p]),

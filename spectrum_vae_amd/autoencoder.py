@@ -129,31 +129,75 @@ class AE(_EncoderDecoder):
 class Sampling(Layer):
     """autoencoder.py:264-272: z = z_mean + exp(0.5 * z_log_var) * epsilon, epsilon ~ N(0, 1).
 
-    The reference defines the layer but no model uses it and no KL term exists there; ``VAEPadded``
-    below is where this build uses it, together with the analytic KL to N(0, 1) that the fused kernel
-    returns alongside z.  ``epsilon`` may be passed in for replayable tests."""
+    The reference defines the layer but no model uses it and no KL term exists there; ``VAEPadded`` (end of this
+    module) is where this build uses it, together with the analytic KL to N(0, 1) that the fused kernel returns
+    alongside z.  Epsilon comes from a counter-based generator whose position lives on the device (so recorded steps
+    keep drawing fresh values); ``replay(eps)`` substitutes supplied values, for replayable tests.
+
+    Two surfaces: ``layer([z_mean, z_log_var])`` as in the reference (eager, returns z; ``last_kl`` holds the KL), and
+    ``sample`` / ``sample_backward`` for models of the layer engine."""
 
     def __init__(self, seed: int = global_vars.DEFAULT_SEED, name=None):
         super().__init__(name)
         self.seed = int(seed)
-        self.calls = 0
         self.last_kl = None
+        self.stream_id = 0
+        self._counter = None
+        self._replay = None
+
+    def _position(self, device):
+        if self._counter is None or self._counter.device != device:
+            self._counter = torch.zeros(1, dtype=torch.int64, device=device)
+        return self._counter
+
+    def replay(self, epsilon):
+        """Use these epsilon values (array of the (batch, dim) shape of the next calls) instead of drawing; ``None``
+        returns to the generator.  The values are copied into a buffer the recorded steps read."""
+        if epsilon is None:
+            self._replay = None
+            return
+        from .losses import to_device_f32
+        e = to_device_f32(epsilon)
+        if self._replay is not None and tuple(self._replay.shape) == tuple(e.shape) and self._replay.device == e.device:
+            self._replay.copy_(e)
+        else:
+            self._replay = e.clone()
 
     def call(self, inputs, epsilon=None):
         from .losses import to_device_f32
         z_mean = to_device_f32(inputs[0])
         z_log_var = to_device_f32(inputs[1], z_mean.device)
-        b, d = z_mean.shape
         z = torch.empty_like(z_mean)
         kl = torch.empty(1, dtype=torch.float32, device=z_mean.device)
-        part = torch.zeros(ops.loss_workspace_floats(), dtype=torch.float32, device=z_mean.device)
+        part = torch.empty(ops.loss_workspace_floats(), dtype=torch.float32, device=z_mean.device)
         eps_in = to_device_f32(epsilon, z_mean.device) if epsilon is not None else None
-        ops.reparam_kl_fwd(z_mean, z_log_var, eps_in, z, None, kl, part, self.seed, self.calls * b * d)
-        self.calls += 1
+        ops.reparam_kl_fwd(z_mean, z_log_var, eps_in, z, None, kl, part, self.seed + 7919 * self.stream_id, 0,
+                           self._position(z_mean.device))
         self.last_kl = as_dtensor(kl.view(()))
         return as_dtensor(z)
 
     __call__ = call
+
+    # ---- layer-engine surface
+    def sample(self, ctx, mean, logvar):
+        ctx.need_f32(self)
+        b, d = mean.shape
+        z, eps, kl = ctx.buf(self, "z", (b, d)), ctx.buf(self, "eps", (b, d)), ctx.buf(self, "kl", (1,))
+        part = ctx.buf(self, "part", (ops.loss_workspace_floats(),))
+        eps_in = self._replay
+        if eps_in is not None and tuple(eps_in.shape) != (b, d):
+            raise ValueError(f"{self.name}: replayed epsilon {tuple(eps_in.shape)} does not match {(b, d)}")
+        ops.reparam_kl_fwd(mean, logvar, eps_in, z, eps, kl, part, self.seed + 7919 * self.stream_id, 0,
+                           self._position(mean.device))
+        ctx.saved[id(self)] = {"mean": mean, "logvar": logvar, "eps": eps}
+        return z, kl
+
+    def sample_backward(self, ctx, dz, kl_weight: float):
+        s = ctx.saved[id(self)]
+        dmean = ctx.buf(self, "dmean", tuple(dz.shape))
+        dlogvar = ctx.buf(self, "dlogvar", tuple(dz.shape))
+        ops.reparam_kl_bwd(s["mean"], s["logvar"], s["eps"], dz, dmean, dlogvar, kl_weight)
+        return dmean, dlogvar
 
 
 class CAE1D(_EncoderDecoder):
@@ -248,3 +292,74 @@ class CAEPadded(_EncoderDecoder):
                                         activation)
         self.encoder = Sequential(enc, name="encoder")
         self.decoder = Sequential(dec, name="decoder")
+
+
+class VAEPadded(Model):
+    """Variational form of ``CAEPadded``.  NO REFERENCE COUNTERPART as a model: the reference ships the ``Sampling`` layer
+    (autoencoder.py:264-272) but nothing that uses it.  Built from the reference's pieces: the conv encoder stack and
+    dense layers of CAEPadded (autoencoder.py:461-494), two linear Dense heads (z_mean, z_log_var), ``Sampling``, and
+    CAEPadded's decoder (autoencoder.py:496-526).
+
+    Training loss = compiled loss(x, decoded) + beta * KL(q(z|x) || N(0, 1)), the KL averaged over the batch; ``fit``
+    reports that sum.  ``sampling.replay(eps)`` fixes the noise."""
+
+    def __init__(self, input_shape=_DEFAULT_IN, initial_filters: int = 8, conv_layer_multiplier: int = 2,
+                 conv_layers: int = 3, fc_layers: int = 2, fc_layer_size: int = 64, activation: str = "elu",
+                 kernel_size: int = 3, conv_operations: int = 2, latent_dimensions: int = 8, beta: float = 1.0,
+                 batch_norm: bool = False):
+        super().__init__(name="vae_padded")
+        if latent_dimensions < 1:
+            raise ValueError("VAEPadded needs latent_dimensions >= 1")
+        self.beta = float(beta)
+        enc, filters = _conv_stack((kernel_size, kernel_size), (2, 2), "same", initial_filters,
+                                   conv_layer_multiplier, conv_layers, conv_operations, activation, batch_norm)
+        enc = [Input(shape=input_shape)] + enc + [Flatten()]
+        for _ in range(fc_layers):
+            enc.append(Dense(fc_layer_size, activation=activation))
+            if batch_norm:
+                enc.append(BatchNormalization())
+        self.encoder = Sequential(enc, name="encoder")
+        self.z_mean = Dense(latent_dimensions, name="z_mean")
+        self.z_log_var = Dense(latent_dimensions, name="z_log_var")
+        self.sampling = Sampling()
+        dec: List[Layer] = [Input(shape=latent_dimensions)]
+        dec += [Dense(fc_layer_size, activation=activation) for _ in range(fc_layers)]
+        fh = int(input_shape[0] / (2 ** conv_layers))
+        fw = int(input_shape[1] / (2 ** conv_layers))
+        dec.append(Dense(fh * fw * filters, activation=activation))
+        dec.append(Reshape((fh, fw, int(filters))))
+        dec += _caepadded_decoder_convs(filters, conv_layers, conv_operations, conv_layer_multiplier, kernel_size,
+                                        activation)
+        self.decoder = Sequential(dec, name="decoder")
+
+    def _build(self, in_shape):
+        h = self.encoder.build(in_shape)
+        self.z_mean.build(h)
+        return self.decoder.build(self.z_log_var.build(h))
+
+    def forward(self, ctx, x):
+        h = self.encoder.forward(ctx, x)
+        mean = self.z_mean.forward(ctx, h)
+        logvar = self.z_log_var.forward(ctx, h)
+        z, kl = self.sampling.sample(ctx, mean, logvar)
+        ctx.extra_losses = [(kl, self.beta)]
+        return self.decoder.forward(ctx, z)
+
+    def backward(self, ctx, dy, need_dx=True):
+        dz = self.decoder.backward(ctx, dy, need_dx=True)
+        dmean, dlogvar = self.sampling.sample_backward(ctx, dz, self.beta)
+        dh = self.z_mean.backward(ctx, dmean, need_dx=True)
+        ops.axpy(dh, self.z_log_var.backward(ctx, dlogvar, need_dx=True), 1.0)
+        return self.encoder.backward(ctx, dh, need_dx=need_dx)
+
+    def encode(self, x):
+        """(z_mean, z_log_var) of a batch, inference mode."""
+        from .losses import to_device_f32
+        from .nn import CallCtx
+        t = to_device_f32(x)
+        if not self.built:
+            self.build((None,) + tuple(t.shape[1:]))
+        self._materialize(t.device)
+        ctx = CallCtx(self._pool, ("encode",), False)
+        h = self.encoder.forward(ctx, t)
+        return as_dtensor(self.z_mean.forward(ctx, h).clone()), as_dtensor(self.z_log_var.forward(ctx, h).clone())

@@ -313,9 +313,11 @@ int launch_gemm(const float* a, int64_t am, int64_t ak, const float* b, int64_t 
 __global__ __launch_bounds__(256) void reparam_fwd_k(const float* __restrict__ mean, const float* __restrict__ logvar,
                                                       const float* __restrict__ eps_in, float* __restrict__ z,
                                                       float* __restrict__ eps_out, float* __restrict__ partials,
-                                                      int64_t n, uint64_t seed, uint64_t offset) {
+                                                      int64_t n, uint64_t seed, uint64_t offset,
+                                                      const uint64_t* __restrict__ counter) {
     __shared__ float red[4];
     float acc = 0.f;
+    if (counter != nullptr) offset += counter[0];  // advanced by the fold launch that follows, after every read here
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float e;
         if (eps_in != nullptr) {
@@ -332,6 +334,14 @@ __global__ __launch_bounds__(256) void reparam_fwd_k(const float* __restrict__ m
     }
     const float s = block_sum_256(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// the KL fold; also moves the device-side random-stream position past the n values the sampling launch just drew
+__global__ __launch_bounds__(256) void reparam_fold_k(const float* __restrict__ partials, int nblocks, float inv_b,
+                                                       float* __restrict__ kl_out, uint64_t* __restrict__ counter,
+                                                       uint64_t n) {
+    fold_scalar_256(partials, nblocks, inv_b, kl_out, 0, nullptr, 0.f);
+    if (counter != nullptr && threadIdx.x == 0) counter[0] += n;
 }
 
 __global__ void reparam_bwd_k(const float* __restrict__ mean, const float* __restrict__ logvar,
@@ -500,15 +510,16 @@ int sv_dense_wgrad(const void* x, const void* dz, void* dw, int accumulate, int 
 
 int sv_reparam_kl_fwd(const float* mean, const float* logvar, const float* eps_in, float* z, float* eps_out,
                       float* kl_out, float* partials, int B, int D, uint64_t seed, uint64_t offset,
-                      sv_stream_t stream) {
+                      uint64_t* rng_counter, sv_stream_t stream) {
     SV_REQUIRE(mean && logvar && z && kl_out && partials && B > 0 && D > 0, "sv_reparam_kl_fwd: bad arguments");
     const int64_t n = (int64_t)B * D;
     const int nb = ew_grid(n, 256, kLossBlocks);
     hipLaunchKernelGGL(reparam_fwd_k, dim3(nb), dim3(256), 0, to_stream(stream), mean, logvar, eps_in, z, eps_out,
-                       partials, n, seed, offset);
+                       partials, n, seed, offset, (const uint64_t*)rng_counter);
     int rc = check_launch("sv_reparam_kl_fwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, 1.f / (float)B, kl_out, 0);
+    hipLaunchKernelGGL(reparam_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, 1.f / (float)B, kl_out,
+                       eps_in == nullptr ? rng_counter : nullptr, (uint64_t)n);
     return check_launch("sv_reparam_kl_fwd/fold");
 }
 

@@ -365,6 +365,7 @@ class Model(Layer):
                 self._refresh_lp()
             x = self._to_act(x, ctx.slot)
         ctx.loss_fold = None
+        self._last_ctx = ctx
         if self.use_net_fused and not ctx.lp:
             y = self._net_forward(ctx, x, mse)
             if y is not None:
@@ -493,8 +494,14 @@ class Model(Layer):
             mse = (yt, b["dpred"], self._pool.get(("fit", "loss_partials"), (ops.loss_workspace_floats(),)))
         pred = self.forward_raw(b["x"], True, side, mse)
         fold = self._calls[-1].loss_fold
+        extras = self._calls[-1].extra_losses
         if fold is not None:  # loss and its gradient left with the forward launch; the optimizer launch folds the sums
             fold = fold + (b["loss"], b["acc"], weight)
+        elif extras:  # terms the forward pass contributed (a VAE's KL): loss = compiled loss + sum(weight * term)
+            self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0)
+            for term, w in extras:
+                ops.axpy(b["loss"], term, w)
+            ops.axpy(b["acc"], b["loss"], weight)
         elif getattr(self.loss, "fuses_running_sum", False):
             self.loss.value_and_grad(yt, pred, b["loss"], b["dpred"], 1.0, running=b["acc"], running_weight=weight)
         else:
@@ -664,6 +671,8 @@ class Model(Layer):
                 ops.gather_rows(Y[start:start + cur], None, yb)
             pred = self.forward_raw(xb, False)
             self.loss.value_and_grad(yb, pred, loss, None, 1.0)
+            for term, w in self._last_ctx.extra_losses:
+                ops.axpy(loss, term, w)
             ops.axpy(acc, loss, float(cur))
         return float(acc.item()) / max(n, 1)
 

@@ -178,6 +178,8 @@ class CallCtx:
         self.wgrad_finish: list = []
         # (partials, n, scale) when the forward launch also evaluated the loss and left per-workgroup sums to fold
         self.loss_fold: Optional[tuple] = None
+        # [(device scalar, weight)]: terms the forward pass adds to the training loss (Keras ``add_loss``)
+        self.extra_losses: list = []
 
     def buf(self, layer, role, shape, dtype=None):
         return self.pool.get((id(layer), role, self.slot), shape, self.dtype if dtype is None else dtype)

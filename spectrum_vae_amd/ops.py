@@ -338,10 +338,15 @@ def reduce_sum_h_bwd(dy, dx, n, h, w, c):
     check(lib.sv_reduce_sum_h_bwd(_ptr(dy), _ptr(dx), n, h, w, c, F32, _stream()), "sv_reduce_sum_h_bwd")
 
 
-def reparam_kl_fwd(mean, logvar, eps_in, z, eps_out, kl_out, partials, seed=0, offset=0):
+def reparam_kl_fwd(mean, logvar, eps_in, z, eps_out, kl_out, partials, seed=0, offset=0, counter=None):
+    """``counter``: optional int64[1] device tensor holding the position in the random stream (read, then advanced by
+    the launch), which keeps a recorded step drawing fresh values."""
     b, d = mean.shape
+    if tuple(logvar.shape) != (b, d) or tuple(z.shape) != (b, d) or (eps_in is not None and eps_in.numel() != b * d):
+        raise ValueError("reparam_kl_fwd: mean / logvar / z / epsilon shapes differ")
     check(lib.sv_reparam_kl_fwd(_ptr(mean), _ptr(logvar), _ptr(eps_in), _ptr(z), _ptr(eps_out), _ptr(kl_out),
-                                _ptr(partials), b, d, seed, offset, _stream()), "sv_reparam_kl_fwd")
+                                _ptr(partials), b, d, seed, offset, _ptr(counter, torch.int64), _stream()),
+          "sv_reparam_kl_fwd")
 
 
 def reparam_kl_bwd(mean, logvar, eps, dz, dmean, dlogvar, kl_weight: float):

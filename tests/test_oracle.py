@@ -269,3 +269,32 @@ def test_training_tensor_format():
     assert x[..., 2].min() >= -1 and x[..., 2].max() <= 1
     assert (x[..., 2] == x[:, :1, :, 2]).all()  # distances tiled down the haplotypes
     assert ((x[..., 0] == 1).sum(axis=1) <= 16).all()  # +1 is the minor allele
+
+
+def test_vae_twin_closed_forms():
+    """The variational twin (no reference model exists for it): its KL against the closed form for constant heads, the
+    Sampling formula of autoencoder.py:272, and dELBO/d(z_mean bias) against a central difference."""
+    from oracle.models import RefVAEPadded
+    torch.manual_seed(0)
+    vae = RefVAEPadded(conv_operations=1, latent_dimensions=4, beta=0.7)
+    x = torch.rand(3, 32, 32, 3, dtype=torch.float64)
+    eps = torch.randn(3, 4, dtype=torch.float64)
+    with torch.no_grad():  # heads that ignore their input: mean = 0.3, logvar = -0.4
+        for part, c in ((vae.z_mean, 0.3), (vae.z_log_var, -0.4)):
+            part.params[0].zero_()
+            part.params[1].fill_(c)
+    dec, kl = vae(x, eps)
+    want_kl = -0.5 * 4 * (1 - 0.4 - 0.09 - np.exp(-0.4))
+    assert abs(float(kl.detach()) - want_kl) < 1e-12
+    z = 0.3 + np.exp(-0.2) * eps
+    assert torch.allclose(dec, vae.decoder(z), atol=1e-14)
+    loss = vae.loss(x, eps)
+    loss.backward()
+    b = vae.z_mean.params[1]
+    g = b.grad[1].item()
+    with torch.no_grad():
+        b[1] += 1e-6
+        up = float(vae.loss(x, eps))
+        b[1] -= 2e-6
+        dn = float(vae.loss(x, eps))
+    assert abs((up - dn) / 2e-6 - g) < 1e-6 * max(1.0, abs(g))
