@@ -345,6 +345,13 @@ int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n
  *      Keras casts the float64 arrays np.zeros/np.concatenate produce (run_model.py:23,110,245) to float32. */
 int sv_gather_rows(const void* src, int src_is_f64, const int64_t* idx, float* dst, int64_t n_rows,
                    int64_t row_elems, sv_stream_t stream);
+/* Random block masks generated on the device (batch_random_mask / create_random_image_mask,
+ * run_context_encoder.py:24-58): per image the block [seg, 3 seg)^2 with seg = W / 8, then seg x seg blocks at uniform
+ * positions in [0, W - seg)^2 until at least pct_mask of W^2 pixels are 1; mask is [N][H][W][C] f32, equal over C.
+ * The reference draws from NumPy's unseeded global generator; here draw d of image n is a counter hash of
+ * (seed, offset + (n << 20) + 2d [+ 1]), so a mask is a pure function of the arguments. */
+int sv_random_block_mask(float* mask, int N, int H, int W, int C, double pct_mask, uint64_t seed, uint64_t offset,
+                         sv_stream_t stream);
 /* y = x * (1 - mask) (run_context_encoder.py:242) */
 int sv_mask_input(const float* x, const float* mask, float* y, int64_t n, sv_stream_t stream);
 /* the same with y in the storage type `dtype` (the masked input of a bf16 model) */

@@ -464,3 +464,35 @@ def glorot_uniform_limit(shape):
         rf = int(np.prod(shape[:-2]))
         fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
     return math.sqrt(6.0 / (fan_in + fan_out))
+
+
+# --------------------------------------------------------------------------- device-side random block masks
+_M64 = (1 << 64) - 1
+
+
+def mix64(x: int) -> int:
+    """The counter hash of the HIP library's generators (splitmix64 finaliser), on Python ints."""
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def random_block_mask(n, h, w, c, pct_mask=0.25, seed=0, offset=0, max_draws=1 << 16):
+    """create_random_image_mask / batch_random_mask (run_context_encoder.py:24-58) with the reference's
+    ``np.random.randint`` draws replaced by the library's counter hash, so the device kernel can be checked bit for bit:
+    draw d of image i takes ``(mix64(seed ^ mix64(offset + (i << 20) + 2 d [+ 1])) >> 11) % (w - seg)``."""
+    out = np.zeros((n, h, w, c))
+    seg = w // 8
+    for i in range(n):
+        mask = np.zeros((h, w, c))
+        mask[seg:seg * 3, seg:seg * 3, :] = 1
+        base = offset + (i << 20)
+        d = 0
+        while (np.sum(mask[:, :, 0]) / (w ** 2)) < pct_mask and d < max_draws:
+            rx = (mix64(seed ^ mix64((base + 2 * d) & _M64)) >> 11) % (w - seg)
+            ry = (mix64(seed ^ mix64((base + 2 * d + 1) & _M64)) >> 11) % (w - seg)
+            mask[rx:rx + seg, ry:ry + seg, :] = 1
+            d += 1
+        out[i] = mask
+    return out

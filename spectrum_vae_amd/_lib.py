@@ -116,6 +116,7 @@ SIGNATURES = {
     "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),
     "sv_gather_rows": (_i, [_p, _i, _p, _p, _i64, _i64, _p]),
     "sv_mask_input": (_i, [_p, _p, _p, _i64, _p]),
+    "sv_random_block_mask": (_i, [_p, _i, _i, _i, _i, C.c_double, _u64, _u64, _p]),
     "sv_mask_input_dt": (_i, [_p, _p, _p, _i64, _i, _p]),
     "sv_axpy": (_i, [_p, _p, _f, _i64, _i, _p]),
     "sv_fill_f32": (_i, [_p, _f, _i64, _p]),

@@ -516,6 +516,46 @@ __global__ void axpy_t_k(T* __restrict__ y, const T* __restrict__ x, float a, in
 }
 
 // y = x * (1 - mask), x and mask float32, y in the model's storage type
+// One 64-lane workgroup per image, the procedure of run_context_encoder.py:39-58: the block [seg, 3 seg)^2 with
+// seg = W / 8, then seg x seg blocks at uniform positions in [0, W - seg)^2 (rows past H clipped, as NumPy slicing does)
+// until at least pct of W^2 pixels are set.  Draw d of image n uses counters offset + (n << 20) + 2d (+1): a pure
+// function of its arguments.  The cap on draws is the loop's exit for coverages that take long to reach.
+constexpr int kMaskMaxDraws = 1 << 16;
+__global__ __launch_bounds__(64) void random_block_mask_k(float* __restrict__ mask, int H, int W, int C, double pct,
+                                                          uint64_t seed, uint64_t offset) {
+    extern __shared__ unsigned char bm[];
+    const int n = blockIdx.x, seg = W / 8, lane = threadIdx.x;
+    int cnt = 0;
+    for (int i = lane; i < H * W; i += 64) {
+        const int r = i / W, c = i - r * W;
+        const unsigned char v = r >= seg && r < 3 * seg && c >= seg && c < 3 * seg;
+        bm[i] = v;
+        cnt += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    __syncthreads();
+    const double total = (double)W * (double)W;
+    const uint64_t base = offset + ((uint64_t)n << 20);
+    const uint64_t span = (uint64_t)(W - seg);
+    for (int d = 0; d < kMaskMaxDraws && (double)cnt / total < pct; ++d) {
+        const int rx = (int)((mix64(seed ^ mix64(base + 2 * (uint64_t)d)) >> 11) % span);
+        const int ry = (int)((mix64(seed ^ mix64(base + 2 * (uint64_t)d + 1)) >> 11) % span);
+        int add = 0;
+        for (int i = lane; i < seg * seg; i += 64) {
+            const int r = rx + i / seg, c = ry + i % seg;
+            if (r < H && !bm[r * W + c]) {
+                bm[r * W + c] = 1;
+                ++add;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) add += __shfl_xor(add, o);
+        cnt += add;
+        __syncthreads();
+    }
+    float* out = mask + (size_t)n * H * W * C;
+    for (int i = lane; i < H * W * C; i += 64) out[i] = bm[i / C] ? 1.f : 0.f;
+}
+
 template <typename T>
 __global__ void mask_input_t_k(const float* __restrict__ x, const float* __restrict__ m, T* __restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -818,6 +858,18 @@ int sv_gather_rows(const void* src, int src_is_f64, const int64_t* idx, float* d
         hipLaunchKernelGGL(gather_rows_k<float>, dim3(grid), dim3(256), 0, to_stream(stream), (const float*)src, idx,
                            dst, n_rows, row_elems);
     return check_launch("sv_gather_rows");
+}
+
+int sv_random_block_mask(float* mask, int N, int H, int W, int C, double pct_mask, uint64_t seed, uint64_t offset,
+                         sv_stream_t stream) {
+    SV_REQUIRE(mask && N > 0 && H > 0 && W >= 8 && C > 0, "sv_random_block_mask: bad arguments (W >= 8 expected)");
+    SV_REQUIRE(pct_mask >= 0.0 && pct_mask <= 0.9, "sv_random_block_mask: pct_mask must be within [0, 0.9]");
+    SV_REQUIRE((double)H / (double)W > pct_mask, "sv_random_block_mask: %dx%d images cannot reach a coverage of %g", H, W,
+               pct_mask);
+    SV_REQUIRE((size_t)H * W <= 64 * 1024, "sv_random_block_mask: image too large for the LDS bitmap");
+    hipLaunchKernelGGL(random_block_mask_k, dim3((unsigned)N), dim3(64), (size_t)H * W, to_stream(stream), mask, H, W, C,
+                       pct_mask, seed, offset);
+    return check_launch("sv_random_block_mask");
 }
 
 int sv_mask_input(const float* x, const float* mask, float* y, int64_t n, sv_stream_t stream) {

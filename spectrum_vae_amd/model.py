@@ -555,6 +555,13 @@ class Model(Layer):
                 with torch.cuda.graph(graph):
                     self._train_step_body(b, same_xy, weight)
                 g = (graph,)
+            elif self._reducer.capturable(self._params.device):
+                # RCCL: the all-reduce is recorded with the rest of the step (one graph launch per step)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    self._train_step_body(b, same_xy, weight)
+                self._reducer.note_reduced(self._grads, -1)  # recording is not reducing
+                g = (graph, None, "collective inside")
             else:
                 scale = 1.0 / self._reducer.world
                 g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -570,7 +577,9 @@ class Model(Layer):
             # (or anything else that touched the gradients) since the last replay means clearing it here first
             ops.fill(self._grads, 0.0)
         g[0].replay()
-        if len(g) == 2:
+        if len(g) == 3:
+            self._reducer.note_reduced(self._grads)
+        elif len(g) == 2:
             self._reducer.all_reduce(self._grads)
             g[1].replay()
         self._grads_clean = True

@@ -462,6 +462,15 @@ def mask_input(x, mask, y):
     check(lib.sv_mask_input_dt(_ptr(x), _ptr(mask), _aptr(y), x.numel(), _dt(y), _stream()), "sv_mask_input_dt")
 
 
+def random_block_mask(mask, pct_mask: float, seed: int, offset: int = 0):
+    """Fill the NHWC float32 tensor ``mask`` with random block masks (equal over channels), one per image."""
+    if mask.dim() != 4:
+        raise ValueError("random_block_mask: an NHWC tensor is expected")
+    n, h, w, c = mask.shape
+    check(lib.sv_random_block_mask(_ptr(mask), n, h, w, c, float(pct_mask), int(seed), int(offset), _stream()),
+          "sv_random_block_mask")
+
+
 def fill(t, value: float):
     check(lib.sv_fill_f32(_ptr(t), value, t.numel(), _stream()), "sv_fill_f32")
 

@@ -8,8 +8,11 @@ launch (``grad_scale``) makes N ranks at batch B identical to one rank at batch 
 losses used here (BatchNorm statistics stay per-rank unless ``sync_batchnorm`` is added).
 
 Gradient messages are small (48 KB for the default CAEPadded, 18 MB for the context encoder), i.e. the
-collective is latency-bound on xGMI; it is issued as a single bucket on the compute stream between the
-captured forward/backward graph and the captured optimizer graph.
+collective is latency-bound on xGMI.  The flat buffer goes out in buckets of ``bucket_bytes`` (one bucket for the
+small models; a ring all-reduce of the larger ones pipelines over the buckets), on the compute stream.  With RCCL
+the collective is recorded INTO the step's HIP graph (after a probe that records and replays a small all-reduce and
+that every rank must pass); otherwise (gloo rehearsals, a failed probe) the step is two graphs with the all-reduce
+issued between them.
 """
 from __future__ import annotations
 
@@ -42,11 +45,16 @@ class GradReducer:
     """Sum-all-reduce of a flat gradient buffer.  ``all_reduce`` returns the factor the optimizer must apply
     to the summed gradient (1 / world_size)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, bucket_bytes: int = 8 << 20, force_collective: Optional[bool] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.calls = 0
         self.bytes = 0
+        self.bucket_bytes = int(bucket_bytes)
+        # issue the collective even in a one-rank group (tests of the recorded-collective path on a single GPU)
+        self.force = (os.environ.get("SPECTRUM_DP_FORCE_COLLECTIVE") == "1") if force_collective is None \
+            else bool(force_collective)
+        self._capturable: Optional[bool] = None
         # gloo (CPU rehearsals, ranks sharing one GPU) reduces host memory: device buffers are staged through a
         # pinned host copy.  RCCL ("nccl") reduces the device buffer in place on the stream.
         self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
@@ -62,12 +70,61 @@ class GradReducer:
         else:
             fn(flat)
 
+    def _collective(self) -> bool:
+        return dist.is_initialized() and (self.world > 1 or self.force)
+
+    def buckets(self, flat: torch.Tensor):
+        """Contiguous views of ``flat`` of at most ``bucket_bytes`` each (16-byte aligned cuts)."""
+        v = flat.view(-1)
+        per = max(4, (self.bucket_bytes // v.element_size()) & ~3)
+        return [v[i:i + per] for i in range(0, v.numel(), per)]
+
     def all_reduce(self, flat: torch.Tensor) -> float:
-        if self.world > 1:
-            self._reduce(flat, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
-        self.calls += 1
-        self.bytes += flat.numel() * flat.element_size()
+        if self._collective():
+            if self._host_staged and flat.is_cuda:
+                self._reduce(flat, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
+            else:
+                for b in self.buckets(flat):
+                    dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+        self.note_reduced(flat)
         return 1.0 / self.world
+
+    def note_reduced(self, flat: torch.Tensor, times: int = 1):
+        """Book-keeping of reductions (called for each replay of a graph that holds the collective; ``times = -1``
+        takes back the call that only recorded it)."""
+        self.calls += times
+        self.bytes += times * flat.numel() * flat.element_size()
+
+    def capturable(self, device) -> bool:
+        """Whether the all-reduce can be recorded into a HIP graph: RCCL only, and only after a probe - a small
+        all-reduce recorded once and replayed twice must give world^2 on every rank.  ``SPECTRUM_DP_CAPTURE=0`` keeps
+        the collective outside the graphs."""
+        if self._capturable is not None:
+            return self._capturable
+        ok = False
+        if (self._collective() and dist.get_backend(self.group) == "nccl" and torch.device(device).type == "cuda"
+                and os.environ.get("SPECTRUM_DP_CAPTURE", "1") != "0"):
+            flag = torch.ones(1, device=device)
+            try:
+                t = torch.ones(256, device=device)
+                dist.all_reduce(t, group=self.group)  # the communicator must exist before anything is recorded
+                torch.cuda.synchronize(device)
+                t.fill_(1.0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                g.replay()
+                g.replay()
+                torch.cuda.synchronize(device)
+                if float(t[0]) != float(self.world) ** 2 or float(t[-1]) != float(self.world) ** 2:
+                    flag.zero_()
+                self._probe_graph = g  # keep the recorded collective alive as long as its communicator
+            except Exception:  # noqa: BLE001 - any failure means: keep the collective outside the graphs
+                flag.zero_()
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)  # one rank failing switches every rank
+            ok = bool(flag.item() > 0)
+        self._capturable = ok
+        return ok
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         """Make every replica start from rank ``src``'s values (weights, BatchNorm state)."""
@@ -81,3 +138,53 @@ def shard_bounds(n: int, rank: int, world: int) -> tuple:
     collective)."""
     per = n // world
     return rank * per, (rank + 1) * per
+
+
+def run_dp_step(st, use_graph: bool, compute, pairs, device):
+    """One data-parallel optimizer step of a multi-model training loop (the GAN steps).
+
+    ``compute()`` enqueues everything up to and including the backward passes (no collective, no update);
+    ``pairs`` = [(model, optimizer)] in update order; a model without a reducer is updated locally.  ``st`` carries
+    ``warm`` and ``dp_graphs`` between calls.  First call eager; then either ONE recorded graph (compute, the bucketed
+    all-reduces, the updates) when every reducer can be recorded, or two graphs with the all-reduces issued between
+    them on the same stream."""
+    def reduce():
+        return [m._reducer.all_reduce(m._grads) if m._reducer is not None else 1.0 for m, _ in pairs]
+
+    def update(scales):
+        for (m, opt), s in zip(pairs, scales):
+            opt.apply_model(m, s)
+
+    if not use_graph or not st.warm:
+        compute()
+        update(reduce())
+        st.warm = True
+        return
+    if getattr(st, "dp_graphs", None) is None:
+        torch.cuda.synchronize()
+        reds = [m._reducer for m, _ in pairs if m._reducer is not None]
+        if all(r.capturable(device) for r in reds):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                compute()
+                update(reduce())
+            for m, _ in pairs:
+                if m._reducer is not None:
+                    m._reducer.note_reduced(m._grads, -1)  # recording is not reducing
+            st.dp_graphs = (g,)
+        else:
+            scales = [1.0 / m._reducer.world if m._reducer is not None else 1.0 for m, _ in pairs]
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                compute()
+            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                update(scales)
+            st.dp_graphs = (g1, g2)
+    st.dp_graphs[0].replay()
+    if len(st.dp_graphs) == 2:
+        reduce()
+        st.dp_graphs[1].replay()
+    else:
+        for m, _ in pairs:
+            if m._reducer is not None:
+                m._reducer.note_reduced(m._grads)

@@ -14,7 +14,7 @@ from typing import Tuple
 import numpy as np
 import torch
 
-from . import context_encoder, global_vars, ops
+from . import context_encoder, global_vars, ops, parallel
 from .data import sort_min_diff
 from .losses import BinaryCrossentropy, MeanSquaredError, to_device_f32
 from .nn import as_dtensor, default_device
@@ -43,6 +43,15 @@ def batch_random_mask(X: np.ndarray, pct_mask: float = 0.25, rng=None) -> np.nda
     for i in np.arange(X.shape[0]):
         mask_arr[i] = create_random_image_mask(X[i], pct_mask=pct_mask, rng=rng)
     return mask_arr
+
+
+def batch_random_mask_device(shape, pct_mask: float = 0.25, seed: int = global_vars.DEFAULT_SEED, offset: int = 0, device=None):
+    """``batch_random_mask`` generated in HBM (one workgroup per image, the same block procedure with counter-hash
+    draws): returns a float32 device tensor of ``shape`` (N, H, W, C).  The training loop slices it per batch, so the
+    masks never cross PCIe."""
+    t = torch.empty(tuple(int(v) for v in shape), dtype=torch.float32, device=device or default_device())
+    ops.random_block_mask(t, pct_mask, seed, offset)
+    return t
 
 
 def create_image_mask(X: np.ndarray, pct_mask: float = 0.25):
@@ -170,8 +179,10 @@ def _step_state(ce, disc, ce_opt, disc_opt, bs: int, weight: float, device) -> _
     return st
 
 
-def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, overlap: bool = False):
-    """``overlap``: once ``pred`` and the reconstruction gradient exist, the context-encoder backward + update and the
+def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, overlap: bool = False,
+               defer_updates: bool = False):
+    """``defer_updates``: stop after the backward passes (the data-parallel step reduces the gradients and applies the
+    updates itself).  ``overlap``: once ``pred`` and the reconstruction gradient exist, the context-encoder backward + update and the
     discriminator forward / backward / update touch disjoint buffers (each model owns its buffer pool, workspace and
     optimizer state), so the former is forked onto a second stream; at batch 64 neither fills the chip on its own."""
     mse, bce = MeanSquaredError(), BinaryCrossentropy(from_logits=False)
@@ -217,15 +228,15 @@ def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, ove
     # discriminator update: gradient of disc_loss w.r.t. the discriminator's weights only
     disc.backward_raw(st.d_real, 0, need_dx=False)
     disc.backward_raw(st.d_fake, 1, need_dx=False)
-    s = disc._reducer.all_reduce(disc._grads) if disc._reducer is not None else 1.0
-    disc_opt.apply_model(disc, s)
+    if not defer_updates:
+        disc_opt.apply_model(disc, 1.0)
     # context-encoder update: gradient of the masked reconstruction loss only
     if joined is not None:
         main.wait_event(joined)
     else:
         ce.backward_raw(st.dpred, 0, need_dx=False)
-        s = ce._reducer.all_reduce(ce._grads) if ce._reducer is not None else 1.0
-        ce_opt.apply_model(ce, s)
+        if not defer_updates:
+            ce_opt.apply_model(ce, 1.0)
     ce._calls.clear()
     disc._calls.clear()
 
@@ -246,8 +257,11 @@ def train_step(context_encoder, discriminator, ce_opt, disc_opt, X, mask, l2_wei
     st = _step_state(ce, disc, ce_opt, disc_opt, Xd.shape[0], l2_weight, device)
     st.X.copy_(Xd)
     st.mask.copy_(Md)
-    graphable = use_graph and ce._reducer is None and disc._reducer is None
-    if not graphable or not st.warm:
+    if ce._reducer is not None or disc._reducer is not None:  # data-parallel: reduce both gradient buffers, then update
+        parallel.run_dp_step(st, use_graph,
+                             lambda: _step_body(ce, disc, ce_opt, disc_opt, st, l2_weight, defer_updates=True),
+                             [(disc, disc_opt), (ce, ce_opt)], device)
+    elif not use_graph or not st.warm:
         _step_body(ce, disc, ce_opt, disc_opt, st, l2_weight)
         st.warm = True
     else:
@@ -271,9 +285,14 @@ def main(n_train: int = 2048, epochs: int = 2, batch_size: int = 64, seed: int =
     split = int(0.8 * n_train)
     perm = rng.permutation(n_train)
     X_train, X_test = data[perm[:split]], data[perm[split:]]
-    X_train_mask = batch_random_mask(X_train, 0.25, rng)
-    X_test_mask = batch_random_mask(X_test, 0.25, rng)
-    model = build_model(input_shape=X_train.shape[1:], activation="relu", latent_dimensions=1_000)
+    # the training set and its masks live in HBM for the whole run (the masks are generated there); a step slices both
+    device = default_device()
+    X_train, X_test = to_device_f32(X_train, device), to_device_f32(X_test, device)
+    X_train_mask = batch_random_mask_device(X_train.shape, 0.25, seed, 0, device)
+    X_test_mask = batch_random_mask_device(X_test.shape, 0.25, seed, X_train.shape[0] << 20, device)
+    X_test_masked = torch.empty_like(X_test)
+    ops.mask_input(X_test, X_test_mask, X_test_masked)
+    model = build_model(input_shape=tuple(X_train.shape[1:]), activation="relu", latent_dimensions=1_000)
     disc = context_encoder.Discriminator()
     disc.build_graph((1, global_vars.NUM_HAPLOTYPES, global_vars.NUM_SNPS, global_vars.NUM_CHANNELS))
     disc.discriminator.summary()
@@ -285,14 +304,14 @@ def main(n_train: int = 2048, epochs: int = 2, batch_size: int = 64, seed: int =
             sl = slice(batch_size * step, batch_size * (step + 1))
             disc_loss, recon_loss, total_loss = train_step(model, disc, ce_optimizer, disc_optimizer, X_train[sl],
                                                            X_train_mask[sl])
-        predictions = model.predict(X_test * (1 - X_test_mask))
+        predictions = model.predict(X_test_masked)
         disc_loss_test = measure_disc_loss(disc, X_test, predictions)
         recon_loss_test = measure_recon_loss(X_test, predictions, X_test_mask)
         print(f"epoch {epoch}: disc {float(disc_loss):.5f} l2 {float(recon_loss):.5f} | "
               f"val disc {float(disc_loss_test):.5f} val l2 {float(recon_loss_test):.5f}")
         res.append({"epoch": epoch, "disc": float(disc_loss), "recon": float(recon_loss),
                     "val_disc": float(disc_loss_test), "val_recon": float(recon_loss_test)})
-    predictions = model.predict(X_test * (1 - X_test_mask))
+    predictions = model.predict(X_test_masked)
     loss_dist = measure_recon_loss(X_test, predictions, X_test_mask, reduction="none")
     per_sample = loss_dist.numpy().mean(axis=(1, 2))
     return res, per_sample

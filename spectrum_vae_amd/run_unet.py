@@ -15,7 +15,7 @@ from typing import Tuple
 import numpy as np
 import torch
 
-from . import global_vars, ops, unet
+from . import global_vars, ops, parallel, unet
 from .losses import BinaryCrossentropy, MeanAbsoluteError, MeanSquaredError, to_device_f32
 from .nn import as_dtensor, default_device
 from .optimizers import Adam, ExponentialDecay
@@ -96,8 +96,10 @@ def _step_state(gen, disc, gen_opt, disc_opt, bs: int, weight: float, device) ->
     return st
 
 
-def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: float, overlap: bool = False):
-    """``overlap``: once the GAN term's gradient has come back through the discriminator, the generator backward +
+def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: float, overlap: bool = False,
+               defer_updates: bool = False):
+    """``defer_updates``: stop after the backward passes (the data-parallel step reduces the gradients and applies the
+    updates itself).  ``overlap``: once the GAN term's gradient has come back through the discriminator, the generator backward +
     update and the discriminator backward + update touch disjoint buffers (each model owns its buffer pool, workspace
     and optimizer state), so the former is forked onto a second stream; at batch 32 neither fills the chip alone."""
     bce, mae = BinaryCrossentropy(from_logits=True), MeanAbsoluteError()
@@ -151,8 +153,8 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
     def generator_update():  # (3) dL/dgen = lambda * dMAE + dGAN
         ops.axpy(st.dgen, st.dgen_gan, 1.0)
         gen.backward_raw(st.dgen, 0, need_dx=False)
-        s = gen._reducer.all_reduce(gen._grads) if gen._reducer is not None else 1.0
-        gen_opt.apply_model(gen, s)
+        if not defer_updates:
+            gen_opt.apply_model(gen, 1.0)
 
     main, joined = torch.cuda.current_stream(), None
     if overlap:
@@ -166,8 +168,8 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
     # (2) discriminator update
     disc.backward_raw(st.d_real, 0, need_dx=False)
     disc.backward_raw(st.d_fake, 1, need_dx=False)
-    s = disc._reducer.all_reduce(disc._grads) if disc._reducer is not None else 1.0
-    disc_opt.apply_model(disc, s)
+    if not defer_updates:
+        disc_opt.apply_model(disc, 1.0)
     if joined is not None:
         main.wait_event(joined)
     else:
@@ -190,8 +192,11 @@ def train_step(generator, discriminator, ce_opt, disc_opt, X, y, lambda_weight: 
     st = _step_state(gen, disc, ce_opt, disc_opt, Xd.shape[0], lambda_weight, device)
     st.X.copy_(Xd)
     st.y.copy_(yd)
-    graphable = use_graph and gen._reducer is None and disc._reducer is None
-    if not graphable or not st.warm:
+    if gen._reducer is not None or disc._reducer is not None:  # data-parallel: reduce both gradient buffers, then update
+        parallel.run_dp_step(st, use_graph,
+                             lambda: _step_body(gen, disc, ce_opt, disc_opt, st, lambda_weight, defer_updates=True),
+                             [(disc, disc_opt), (gen, ce_opt)], device)
+    elif not use_graph or not st.warm:
         _step_body(gen, disc, ce_opt, disc_opt, st, lambda_weight)
         st.warm = True
     else:

@@ -20,10 +20,12 @@ def _free_port():
     return p
 
 
-def _run(world, bpr, steps, out):
+def _run(world, bpr, steps, out, worker="dp_hip_worker.py"):
+    """``worker`` dp_hip_worker.py: (bpr, steps) are its batch-per-rank and step count; dp_gan_worker.py: they are its
+    BACKEND and SHARDS arguments."""
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_hip_worker.py"), str(r), str(world), port, out,
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(r), str(world), port, out,
                                str(bpr), str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     for p in procs:
@@ -53,3 +55,42 @@ def test_two_ranks_at_batch_b_equal_one_rank_at_batch_2b(tmp_path):
     assert np.max(np.abs(r0["params"] - s0["params"])) <= 1e-5
     moved = np.max(np.abs(s0["params"])) > 0 and steps * 5e-4 > 1e-4
     assert moved
+
+
+
+PARAM_KEYS = ("ae_params", "ce_params", "ced_params", "un_params", "und_params")
+LOSS_KEYS = ("ae_losses", "ce_losses", "un_losses")
+
+
+def test_recorded_collective_and_gan_steps_equal_the_single_process_steps(tmp_path):
+    """One rank with RCCL and the collective forced: the auto-encoder step and both GAN steps run in their
+    data-parallel form (bucketed all-reduce of every model's flat gradient buffer, recorded inside the step's HIP graph
+    when the probe passes, else between two graphs).  A one-rank sum is the identity, so weights and losses must equal,
+    bit for bit, the same steps run serially without any reducer."""
+    dn, d0 = tmp_path / "nccl", tmp_path / "none"
+    dn.mkdir(); d0.mkdir()
+    (a,) = _run(1, "nccl", "same", str(dn), "dp_gan_worker.py")
+    (b,) = _run(1, "none", "same", str(d0), "dp_gan_worker.py")
+    for k in PARAM_KEYS + LOSS_KEYS:
+        assert np.array_equal(a[k], b[k]), k
+    # which form ran is decided by the probe; either way the graphs replayed (the worker asserts one reduction per step)
+    assert int(a["ae_graph_len"]) == (3 if int(a["capturable"]) else 2)
+    assert int(a["ce_graph_len"]) == (1 if int(a["capturable"]) else 2)
+
+
+def test_gan_steps_two_ranks_over_gloo(tmp_path):
+    """Two ranks sharing the GPU (gloo).  Same rows on both ranks: the averaged gradient is exactly the local one, so
+    both replicas must equal the single-process run bit for bit.  Different rows: replicas stay bit-identical to each
+    other (same start by broadcast, same reduced gradients) and differ from the single-shard run."""
+    ds, dd, d0 = tmp_path / "same", tmp_path / "split", tmp_path / "none"
+    ds.mkdir(); dd.mkdir(); d0.mkdir()
+    s0, s1 = _run(2, "gloo", "same", str(ds), "dp_gan_worker.py")
+    (ref,) = _run(1, "none", "same", str(d0), "dp_gan_worker.py")
+    for k in PARAM_KEYS + LOSS_KEYS:
+        assert np.array_equal(s0[k], s1[k]) and np.array_equal(s0[k], ref[k]), k
+    assert int(s0["ae_graph_len"]) == 2 and int(s0["ce_graph_len"]) == 2
+    p0, p1 = _run(2, "gloo", "split", str(dd), "dp_gan_worker.py")
+    for k in PARAM_KEYS:
+        assert np.array_equal(p0[k], p1[k]), k
+        assert not np.array_equal(p0[k], ref[k]), k
+    assert not np.array_equal(p0["ae_losses"], p1["ae_losses"])

@@ -792,3 +792,13 @@ def test_recorded_step_survives_a_larger_scratch_request():
     assert l0 == l1
     for a, c in zip(w0, w1):
         assert np.array_equal(a, c)
+
+
+@pytest.mark.gpu
+def test_context_encoder_driver_runs_on_device_masks():
+    """run_context_encoder.main with the training set and its masks resident in HBM (masks generated there)."""
+    from spectrum_vae_amd import run_context_encoder
+    res, per_sample = run_context_encoder.main(n_train=320, epochs=2, batch_size=64)
+    assert len(res) == 2 and per_sample.shape == (64,)
+    assert all(np.isfinite(list(r.values())).all() for r in res)
+    assert res[1]["recon"] < res[0]["recon"] * 1.5

@@ -645,3 +645,33 @@ def test_conv2d_wgrad_batch_matches_per_layer_calls():
     for j, (dw_ref, db_ref) in zip(jobs, want):
         close(j["dw"], dw_ref.cpu().numpy(), what="batched dw, 2 workgroups")
         close(j["db"], db_ref.cpu().numpy(), what="batched db, 2 workgroups")
+
+
+@pytest.mark.parametrize("shape,pct", [((5, 32, 32, 3), 0.25), ((3, 32, 32, 1), 0.5), ((2, 64, 64, 3), 0.25),
+                                       ((4, 24, 32, 2), 0.3), ((1, 32, 32, 3), 0.0), ((2, 40, 40, 3), 0.85)])
+def test_random_block_mask_equals_host_procedure(shape, pct):
+    """Masks generated in HBM: bit-equal to the reference's block procedure (run_context_encoder.py:24-58) fed with the
+    same counter-hash draws; coverage reached; a different offset gives different masks."""
+    from spectrum_vae_amd import ops
+    n, h, w, c = shape
+    m = torch.full(shape, 7.0, device="cuda")
+    ops.random_block_mask(m, pct, seed=1833, offset=12345)
+    want = np_ops.random_block_mask(n, h, w, c, pct, seed=1833, offset=12345)
+    got = m.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert (got[..., 0].sum(axis=(1, 2)) / w ** 2 >= pct).all()
+    seg = w // 8
+    assert (got[:, seg:3 * seg, seg:3 * seg] == 1).all()
+    if pct > 0.2:
+        m2 = torch.empty(shape, device="cuda")
+        ops.random_block_mask(m2, pct, seed=1833, offset=12346)
+        assert not torch.equal(m, m2)
+        assert len({got[i].tobytes() for i in range(n)}) == n  # images of a batch get different masks
+
+
+def test_random_block_mask_rejects_unreachable_coverage():
+    from spectrum_vae_amd import ops
+    with pytest.raises(Exception):
+        ops.random_block_mask(torch.empty((1, 4, 32, 3), device="cuda"), 0.25, 0)  # the reference would never return
+    with pytest.raises(Exception):
+        ops.random_block_mask(torch.empty((1, 32, 32, 3), device="cuda"), 0.95, 0)
