@@ -247,6 +247,29 @@ int sv_batchnorm_fwd_infer(const void* x, const float* gamma, const float* beta,
 int sv_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const float* save_mean,
                      const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t rows,
                      int C, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
+/* The same three operations with what surrounds the layer in the GAN models folded into their launches, and with
+ * statistics GROUPS: the rows split into `groups` equal consecutive parts that are normalised independently
+ * (save_mean / save_invstd are [groups][C]; the moving statistics receive one update per group, in order) - the
+ * discriminator of run_context_encoder.py:165-187 / run_unet.py:128-161 is called on the real and on the generated
+ * batch, which is one pass over both here.  workspace: sv_batchnorm_workspace_bytes(rows, C, groups).
+ *  - act / alpha (forward): a following activation layer (unet.py:51-53, BatchNormalization -> LeakyReLU) applied to the
+ *    normalised value in the same launch; y is then the activation's output.
+ *  - y_act / act_out (backward): that output; the incoming gradient is dy * act_out'(y_act).
+ *  - act_in / alpha_in / dbias_in (backward): the activation of the conv that PRODUCED x (context_encoder.py:61-64,
+ *    Conv2D(activation=LeakyReLU) -> BatchNormalization): dx is multiplied by act_in'(x), i.e. it is the gradient at the
+ *    conv's pre-activation, and dbias_in (may be NULL) receives its column sums, the conv's bias gradient. */
+size_t sv_batchnorm_workspace_bytes(int64_t rows, int C, int groups);
+int sv_batchnorm_act_fwd_train(const void* x, const float* gamma, const float* beta, void* y, float* save_mean,
+                               float* save_invstd, float* moving_mean, float* moving_var, int64_t rows, int C, float eps,
+                               float momentum, int unbiased_moving_var, int groups, int act, float alpha, void* workspace,
+                               size_t workspace_bytes, int dtype, sv_stream_t stream);
+int sv_batchnorm_act_fwd_infer(const void* x, const float* gamma, const float* beta, const float* moving_mean,
+                               const float* moving_var, void* y, int64_t rows, int C, float eps, int act, float alpha,
+                               int dtype, sv_stream_t stream);
+int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int act_out, float alpha_out, const float* gamma,
+                         const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta,
+                         int accumulate, int act_in, float alpha_in, float* dbias_in, int dbias_accumulate, int64_t rows,
+                         int C, int groups, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
 
 /* ---- Concatenate on the channel axis (unet.py:144): y[r] = [a[r], b[r]] and its split backward */
 int sv_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int Ca, int Cb, int dtype,
@@ -339,6 +362,15 @@ int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float bet
                           float decay_rate, int staircase, sv_stream_t stream);
 int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n, const int64_t* step_state,
                         float beta1, float beta2, float eps, float grad_scale, int zero_grad, sv_stream_t stream);
+
+/* ---- deferred reductions (no reference counterpart; launch-count control for the backward pass of the GAN steps,
+ *      run_context_encoder.py:225-260, run_unet.py:164-203).  Between _begin and _flush on one host thread, every
+ *      "sum the partial slabs into dw / db" launch inside sv_conv2d_wgrad[_ws], sv_conv2d_transpose_wgrad, sv_act_bwd and
+ *      sv_bias_grad is queued instead; _flush(launch = 1) runs all queued sums in ONE launch on `stream` (the stream
+ *      the producers ran on), _flush(launch = 0) drops them (error paths).  While a reduction is queued its workspace
+ *      must not be reused: give every call in the bracket its own workspace.  Results are the same fixed-order sums. */
+int sv_deferred_reduce_begin(void);
+int sv_deferred_reduce_flush(int launch, sv_stream_t stream);
 
 /* ---- batching helpers for Model.fit / predict (run_model.py:141-146,283-289,300):
  *      dst[i, :] = src[idx[i], :] with rows of row_elems elements; src may be f64 or f32 (src_is_f64), dst is f32:

@@ -93,6 +93,11 @@ SIGNATURES = {
     "sv_batchnorm_fwd_train": (_i, [_p] * 8 + [_i64, _i, _f, _f, _i, _p, _sz, _i, _p]),
     "sv_batchnorm_fwd_infer": (_i, [_p] * 6 + [_i64, _i, _f, _i, _p]),
     "sv_batchnorm_bwd": (_i, [_p] * 8 + [_i, _i64, _i, _p, _sz, _i, _p]),
+    "sv_batchnorm_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "sv_batchnorm_act_fwd_train": (_i, [_p] * 8 + [_i64, _i, _f, _f, _i, _i, _i, _f, _p, _sz, _i, _p]),
+    "sv_batchnorm_act_fwd_infer": (_i, [_p] * 6 + [_i64, _i, _f, _i, _f, _i, _p]),
+    "sv_batchnorm_act_bwd": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _i, _i64, _i, _i, _p, _sz,
+                                  _i, _p]),
     "sv_concat_channels_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
     "sv_concat_channels_bwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
     "sv_dense_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
@@ -111,6 +116,8 @@ SIGNATURES = {
     "sv_loss_bce": (_i, [_p, _f, _i, _p, _i, _p, _f, _i64, _p, _i, _p]),
     "sv_adam_keras_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _f, _i, _f, _i, _p, _p, _i, _f, _p, _p, _f,
                                 _p]),
+    "sv_deferred_reduce_begin": (_i, []),
+    "sv_deferred_reduce_flush": (_i, [_i, _p]),
     "sv_fold_scalar": (_i, [_p, _i, _f, _p, _i, _p, _f, _p]),
     "sv_adam_keras_prepare": (_i, [_p, _f, _f, _f, _i, _f, _i, _p]),
     "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),

@@ -296,4 +296,12 @@ int sv_conv2d_transpose_wgrad(const sv_conv_geom* g, const void* x, const void* 
                                workspace_bytes, to_stream(stream));
 }
 
+// ---- deferred reductions
+int sv_deferred_reduce_begin(void) {
+    deferred_begin();
+    return SV_OK;
+}
+
+int sv_deferred_reduce_flush(int launch, sv_stream_t stream) { return deferred_flush(to_stream(stream), launch != 0); }
+
 }  // extern "C"

@@ -159,4 +159,10 @@ __device__ __forceinline__ float u01(uint64_t seed, uint64_t ctr) {
     return (float)(mix64(seed ^ mix64(ctr)) >> 40) * (1.0f / 16777216.0f);
 }
 
+// Deferred reductions (conv_direct.hip): true when the "dst (+)= sum of `slabs` rows of n floats at src" step was queued
+// for the flush instead of being launched now.
+bool defer_reduce(const float* src, float* dst, int64_t n, int slabs, int accumulate);
+void deferred_begin();
+int deferred_flush(hipStream_t st, bool launch);
+
 }  // namespace sv

@@ -5,6 +5,8 @@
 // scalar path.  Shapes on the benchmarked path are routed to the tiled kernels in conv_tiled.hip first.
 #include <stdarg.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace sv {
@@ -184,11 +186,10 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct(sv_conv_geom g, const
 // dw[i] (+)= sum_sp part[sp][i].  64 consecutive outputs per block (one coalesced 256-byte row per slab),
 // 16 waves each summing every 16th slab with 8 loads in flight, then a fixed-order fold through LDS:
 // latency-parallel and bitwise reproducible.
-__global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
-                                                      int64_t kc, int n_split, int accumulate) {
-    __shared__ float red[16][64];
+__device__ __forceinline__ void wgrad_reduce_rows(const float* __restrict__ part, float* __restrict__ dw, int64_t kc,
+                                                  int n_split, int accumulate, int block, float (&red)[16][64]) {
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t i = (int64_t)block * 64 + lane;
     float s = 0.f;
     if (i < kc) {
         int sp = grp;
@@ -209,6 +210,77 @@ __global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ p
         for (int g = 0; g < 16; ++g) t += red[g][lane];
         dw[i] = t;
     }
+}
+
+__global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw,
+                                                      int64_t kc, int n_split, int accumulate) {
+    __shared__ float red[16][64];
+    wgrad_reduce_rows(part, dw, kc, n_split, accumulate, blockIdx.x, red);
+}
+
+// ---- deferred reductions: between sv_deferred_reduce_begin and _flush (same host thread) every "sum the slabs into the
+// gradient" step of the library is queued instead of launched; the flush runs all of them in ONE launch (a job table, one
+// range of workgroups per job).  The caller keeps every queued job's slabs untouched until the flush.
+constexpr int kMaxDeferredJobs = 48;
+struct DeferredJob {
+    const float* src;
+    float* dst;
+    int64_t n;
+    int slabs, accumulate;
+};
+struct DeferredArgs {
+    int n_jobs;
+    int first[kMaxDeferredJobs + 1];
+    DeferredJob job[kMaxDeferredJobs];
+};
+__global__ __launch_bounds__(1024) void reduce_multi_k(DeferredArgs m) {
+    __shared__ float red[16][64];
+    int j = 0;
+    while (j + 1 < m.n_jobs && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const DeferredJob& q = m.job[j];
+    wgrad_reduce_rows(q.src, q.dst, q.n, q.slabs, q.accumulate, blockIdx.x - m.first[j], red);
+}
+
+static thread_local bool t_defer_on = false;
+static thread_local std::vector<DeferredJob> t_deferred;
+
+bool defer_reduce(const float* src, float* dst, int64_t n, int slabs, int accumulate) {
+    if (!t_defer_on) return false;
+    t_deferred.push_back(DeferredJob{src, dst, n, slabs, accumulate});
+    return true;
+}
+
+void deferred_begin() {
+    t_deferred.clear();
+    t_defer_on = true;
+}
+
+int deferred_flush(hipStream_t st, bool launch) {
+    t_defer_on = false;
+    if (!launch) {
+        t_deferred.clear();
+        return SV_OK;
+    }
+    size_t done = 0;
+    while (done < t_deferred.size()) {
+        DeferredArgs m{};
+        int blocks = 0;
+        while (done < t_deferred.size() && m.n_jobs < kMaxDeferredJobs) {
+            m.job[m.n_jobs] = t_deferred[done++];
+            m.first[m.n_jobs] = blocks;
+            blocks += (int)ceil_div(m.job[m.n_jobs].n, 64);
+            ++m.n_jobs;
+        }
+        m.first[m.n_jobs] = blocks;
+        hipLaunchKernelGGL(reduce_multi_k, dim3((unsigned)blocks), dim3(1024), 0, st, m);
+        int rc = check_launch("reduce_multi");
+        if (rc) {
+            t_deferred.clear();
+            return rc;
+        }
+    }
+    t_deferred.clear();
+    return SV_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -312,6 +384,7 @@ int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, 
         if (splits == 1) return launch_conv_gemm_wgrad(g, x, dz, dw, 1, st, accumulate);  // tiles go straight into dw
         int rc = launch_conv_gemm_wgrad(g, x, dz, (float*)ws, splits, st, 0);
         if (rc) return rc;
+        if (defer_reduce((const float*)ws, dw, kc, splits, accumulate)) return SV_OK;
         hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, (const float*)ws, dw, kc, splits,
                            accumulate);
         return check_launch("wgrad_reduce");
@@ -325,6 +398,7 @@ int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, 
     wgrad_direct_any<float>(g, x, dz, part, pps, grid, cot, st);
     int rc = check_launch("conv2d_wgrad_direct");
     if (rc) return rc;
+    if (defer_reduce(part, dw, kc, ns, accumulate)) return SV_OK;
     hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, part, dw, kc, ns, accumulate);
     return check_launch("wgrad_reduce");
 }
@@ -365,6 +439,7 @@ int launch_wgrad_bf16(const sv_conv_geom& g, const void* x, const void* dz, floa
         if (splits == 1) return launch_conv_gemm_bf16_wgrad(g, x, dz, dw, 1, st, accumulate);
         int rc = launch_conv_gemm_bf16_wgrad(g, x, dz, (float*)ws, splits, st, 0);
         if (rc) return rc;
+        if (defer_reduce((const float*)ws, dw, kc, splits, accumulate)) return SV_OK;
         hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, (const float*)ws, dw, kc, splits,
                            accumulate);
         return check_launch("wgrad_reduce");
@@ -378,6 +453,7 @@ int launch_wgrad_bf16(const sv_conv_geom& g, const void* x, const void* dz, floa
     wgrad_direct_any<bf16_t>(g, (const bf16_t*)x, (const bf16_t*)dz, part, pps, grid, cot, st);
     int rc = check_launch("conv2d_wgrad_direct<bf16>");
     if (rc) return rc;
+    if (defer_reduce(part, dw, kc, ns, accumulate)) return SV_OK;
     hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, part, dw, kc, ns, accumulate);
     return check_launch("wgrad_reduce");
 }

@@ -109,12 +109,14 @@ __global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ z, float* 
     }
 }
 
-// Column sums of per-block partials, part[(b * NV + v) * C + c]: a workgroup of 256 owns 64 channels, its 4 waves walk
-// every 4th block (8 loads in flight each) and the four sums are combined in a fixed order - latency-parallel and
-// bitwise reproducible.  Returns true for the lanes (wave 0, c < C) that hold the result in out[].
+// Column sums of per-block partials, part[(b * NV + v) * C + c]: a workgroup of 1024 owns 64 channels, its 16 waves walk
+// every 16th block (8 loads in flight each) and the sixteen sums are combined in a fixed order - latency-parallel (the
+// walk is a chain of dependent round trips, so its length is what a fold costs) and bitwise reproducible.  Returns true for
+// the lanes (wave 0, c < C) that hold the result in out[].
+constexpr int kFoldWaves = 16;
 template <int NV, typename T>
 __device__ __forceinline__ bool fold_cols(const float* __restrict__ part, int nblocks, int C, int& c, T (&out)[NV]) {
-    __shared__ T red[3][NV][64];
+    __shared__ T red[kFoldWaves - 1][NV][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     c = blockIdx.x * 64 + lane;
     T s[NV];
@@ -122,18 +124,18 @@ __device__ __forceinline__ bool fold_cols(const float* __restrict__ part, int nb
     for (int v = 0; v < NV; ++v) s[v] = (T)0;
     if (c < C) {
         int b = grp;
-        for (; b + 28 < nblocks; b += 32) {
+        for (; b + 7 * kFoldWaves < nblocks; b += 8 * kFoldWaves) {
             float t[8][NV];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) t[u][v] = part[((int64_t)(b + 4 * u) * NV + v) * C + c];
+                for (int v = 0; v < NV; ++v) t[u][v] = part[((int64_t)(b + kFoldWaves * u) * NV + v) * C + c];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int v = 0; v < NV; ++v) s[v] += (T)t[u][v];
         }
-        for (; b < nblocks; b += 4)
+        for (; b < nblocks; b += kFoldWaves)
 #pragma unroll
             for (int v = 0; v < NV; ++v) s[v] += (T)part[((int64_t)b * NV + v) * C + c];
     }
@@ -144,12 +146,17 @@ __device__ __forceinline__ bool fold_cols(const float* __restrict__ part, int nb
     __syncthreads();
     if (grp != 0 || c >= C) return false;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) out[v] = ((s[v] + red[0][v][lane]) + red[1][v][lane]) + red[2][v][lane];
+    for (int v = 0; v < NV; ++v) {
+        T t = s[v];
+#pragma unroll
+        for (int g = 0; g < kFoldWaves - 1; ++g) t += red[g][v][lane];
+        out[v] = t;
+    }
     return true;
 }
 
 // out[c] (+)= sum_b part[b][c] (fixed order: deterministic)
-__global__ __launch_bounds__(256) void fold_partials_k(const float* __restrict__ part, float* __restrict__ out, int nblocks,
+__global__ __launch_bounds__(1024) void fold_partials_k(const float* __restrict__ part, float* __restrict__ out, int nblocks,
                                                        int C, int accumulate) {
     int c;
     float s[1];
@@ -251,6 +258,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_k(const T* __restrict__ x, float* __restrict__ part,
                                                    int64_t rows, int C, int64_t rows_per_block) {
     extern __shared__ float sm[];  // 2 * blockDim.x
+    // blockIdx.y = statistics group: `rows` consecutive rows with statistics (and a pivot row) of their own
+    x += (int64_t)blockIdx.y * rows * C;
+    part += (int64_t)blockIdx.y * gridDim.x * 2 * C;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
@@ -297,22 +307,25 @@ __global__ __launch_bounds__(256) void bn_stats_k(const T* __restrict__ x, float
 
 // pass 2: fold partials -> mean, invstd; update the moving statistics.
 template <typename T>
-__global__ void bn_finalize_k(const T* __restrict__ x, const float* __restrict__ part, int nblocks,
+__global__ __launch_bounds__(1024) void bn_finalize_k(const T* __restrict__ x, const float* __restrict__ part, int nblocks,
                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
                               float* __restrict__ moving_mean, float* __restrict__ moving_var, int64_t rows, int C,
-                              float eps, float momentum, int unbiased) {
-    {
+                              float eps, float momentum, int unbiased, int groups) {
+    // groups in order: the moving statistics receive one update per group, as separate calls on the groups would give
+    for (int g = 0; g < groups; ++g) {
         int c;
         double sq[2];
-        if (!fold_cols<2, double>(part, nblocks, C, c, sq)) return;
+        const bool mine = fold_cols<2, double>(part + (int64_t)g * nblocks * 2 * C, nblocks, C, c, sq);
+        __syncthreads();  // fold_cols' LDS staging is reused by the next group
+        if (!mine) continue;
         const double s = sq[0], q = sq[1];
         const double m = (double)rows;
         const double dmean = s / m;
         double var = q / m - dmean * dmean;
         if (var < 0.0) var = 0.0;
-        const float mean = (float)((double)(float)x[c] + dmean);
-        save_mean[c] = mean;
-        save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        const float mean = (float)((double)(float)x[(int64_t)g * rows * C + c] + dmean);
+        save_mean[g * C + c] = mean;
+        save_invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
         if (moving_mean != nullptr) {
             const double mv = unbiased && rows > 1 ? var * m / (m - 1.0) : var;
             moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * mean;
@@ -322,16 +335,30 @@ __global__ void bn_finalize_k(const T* __restrict__ x, const float* __restrict__
 }
 
 // y = (x - mean) * invstd * gamma + beta   (mean/invstd either saved batch stats or derived from moving stats)
+// A following activation layer may ride along (act != ACT_NONE): it sees the normalised value in its storage type, as it
+// would coming from a separate launch.
 template <typename T>
 __global__ void bn_apply_k(const T* __restrict__ x, const float* __restrict__ gamma,
                            const float* __restrict__ beta, const float* __restrict__ mean,
                            const float* __restrict__ var_or_invstd, int is_var, float eps, T* __restrict__ y,
-                           int64_t total, int C) {
+                           int64_t total, int C, int act, float alpha, int64_t group_elems) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
-        const float inv = is_var ? rsqrtf(var_or_invstd[c] + eps) : var_or_invstd[c];
-        y[i] = (T)(((float)x[i] - mean[c]) * inv * gamma[c] + beta[c]);
+        const int sc = group_elems >= total ? c : (int)(i / group_elems) * C + c;  // the row's statistics group
+        const float inv = is_var ? rsqrtf(var_or_invstd[sc] + eps) : var_or_invstd[sc];
+        const T v = (T)(((float)x[i] - mean[sc]) * inv * gamma[c] + beta[c]);
+        y[i] = act == SV_ACT_NONE ? v : (T)act_apply((float)v, act, alpha);
     }
+}
+
+// The gradient arriving at the normalised value: dy itself, or - when the activation layer that followed rode along in
+// the forward launch (yact = its output) - dy * act'(yact), rounded to the storage type as a separate launch would have.
+template <typename T>
+__device__ __forceinline__ float bn_incoming_grad(const T* __restrict__ dy, const T* __restrict__ yact, int64_t i,
+                                                  int act_out, float alpha_out) {
+    const float g = (float)dy[i];
+    if (yact == nullptr) return g;
+    return (float)(T)(g * act_grad_from_y((float)yact[i], act_out, alpha_out));
 }
 
 // backward pass 1: per-block partial (sum dy, sum dy*xhat) -> part[block][2][C]
@@ -339,8 +366,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_stats_k(const T* __restrict__ x, const T* __restrict__ dy,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float* __restrict__ part,
-                                                       int64_t rows, int C, int64_t rows_per_block) {
+                                                       int64_t rows, int C, int64_t rows_per_block,
+                                                       const T* __restrict__ yact, int act_out, float alpha_out) {
     extern __shared__ float sm[];
+    {  // blockIdx.y = statistics group
+        const int64_t go = (int64_t)blockIdx.y * rows * C;
+        x += go;
+        dy += go;
+        if (yact != nullptr) yact += go;
+        mean += blockIdx.y * C;
+        invstd += blockIdx.y * C;
+        part += (int64_t)blockIdx.y * gridDim.x * 2 * C;
+    }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
@@ -352,7 +389,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const T* __restrict__ x, c
             const float mu = mean[c], inv = invstd[c];
 #pragma unroll 4
             for (int64_t r = r0 + rr; r < r1; r += rif) {
-                const float g = (float)dy[r * C + c];
+                const float g = bn_incoming_grad(dy, yact, r * C + c, act_out, alpha_out);
                 s += g;
                 q = fmaf(g, ((float)x[r * C + c] - mu) * inv, q);
             }
@@ -375,7 +412,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const T* __restrict__ x, c
             float s = 0.f, q = 0.f;
 #pragma unroll 4
             for (int64_t r = r0; r < r1; ++r) {
-                const float g = (float)dy[r * C + c];
+                const float g = bn_incoming_grad(dy, yact, r * C + c, act_out, alpha_out);
                 s += g;
                 q = fmaf(g, ((float)x[r * C + c] - mu) * inv, q);
             }
@@ -386,17 +423,20 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const T* __restrict__ x, c
 }
 
 // fold -> stats2[0][C] = sum dy (dbeta), stats2[1][C] = sum dy*xhat (dgamma); also emit dgamma/dbeta
-__global__ void bn_bwd_fold_k(const float* __restrict__ part, int nblocks, float* __restrict__ stats2,
-                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int C) {
-    {
+__global__ __launch_bounds__(1024) void bn_bwd_fold_k(const float* __restrict__ part, int nblocks, float* __restrict__ stats2,
+                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int C, int groups) {
+    // stats2[g] = the group's sums (its rows' input gradient uses them); dgamma / dbeta sum over the groups in order
+    for (int g = 0; g < groups; ++g) {
         int c;
         float sq[2];
-        if (!fold_cols<2, float>(part, nblocks, C, c, sq)) return;
+        const bool mine = fold_cols<2, float>(part + (int64_t)g * nblocks * 2 * C, nblocks, C, c, sq);
+        __syncthreads();
+        if (!mine) continue;
         const float s = sq[0], q = sq[1];
-        stats2[c] = s;
-        stats2[C + c] = q;
-        dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s;
-        dgamma[c] = (accumulate ? dgamma[c] : 0.f) + q;
+        stats2[(2 * g) * C + c] = s;
+        stats2[(2 * g + 1) * C + c] = q;
+        dbeta[c] = (accumulate || g > 0 ? dbeta[c] : 0.f) + s;
+        dgamma[c] = (accumulate || g > 0 ? dgamma[c] : 0.f) + q;
     }
 }
 
@@ -405,14 +445,82 @@ template <typename T>
 __global__ void bn_bwd_apply_k(const T* __restrict__ x, const T* __restrict__ dy,
                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ stats2,
-                               T* __restrict__ dx, int64_t rows, int C) {
-    const int64_t total = rows * C;
+                               T* __restrict__ dx, int64_t rows, int C, int groups) {
+    const int64_t total = rows * C * groups, group_elems = rows * C;  // rows: per statistics group
     const float invm = 1.f / (float)rows;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
-        const float inv = invstd[c];
-        const float xh = ((float)x[i] - mean[c]) * inv;
-        dx[i] = (T)(gamma[c] * inv * ((float)dy[i] - invm * (stats2[c] + xh * stats2[C + c])));
+        const int g = groups == 1 ? 0 : (int)(i / group_elems);
+        const float inv = invstd[g * C + c];
+        const float xh = ((float)x[i] - mean[g * C + c]) * inv;
+        dx[i] = (T)(gamma[c] * inv * ((float)dy[i] - invm * (stats2[2 * g * C + c] + xh * stats2[(2 * g + 1) * C + c])));
+    }
+}
+
+// The same with the neighbouring activations folded in, one workgroup per block of rows (the layout of the statistics
+// pass).  yact: output of the activation layer that followed (its derivative scales the incoming gradient).  act_in: the
+// activation of the PRODUCER of x (a conv whose output feeds this layer): dx is multiplied by act_in'(x), i.e. the launch
+// emits the gradient at the conv's pre-activation, and partb[block][C] receives its column sums (the conv's bias
+// gradient) when not null.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const T* __restrict__ yact, int act_out, float alpha_out,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ stats2, T* __restrict__ dx,
+                                                            int act_in, float alpha_in, float* __restrict__ partb,
+                                                            int64_t rows, int C, int64_t rows_per_block) {
+    extern __shared__ float sm[];
+    {  // blockIdx.y = statistics group
+        const int64_t go = (int64_t)blockIdx.y * rows * C;
+        x += go;
+        dy += go;
+        dx += go;
+        if (yact != nullptr) yact += go;
+        mean += blockIdx.y * C;
+        invstd += blockIdx.y * C;
+        stats2 += 2 * blockIdx.y * C;
+        if (partb != nullptr) partb += (int64_t)blockIdx.y * gridDim.x * C;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    const float invm = 1.f / (float)rows;
+    auto one = [&](int64_t i, float mu, float inv, float ga, float s1, float s2) -> float {
+        const float xv = (float)x[i];
+        const float g = bn_incoming_grad(dy, yact, i, act_out, alpha_out);
+        const float xh = (xv - mu) * inv;
+        T d = (T)(ga * inv * (g - invm * (s1 + xh * s2)));
+        if (act_in != SV_ACT_NONE) d = (T)((float)d * act_grad_from_y(xv, act_in, alpha_in));
+        dx[i] = d;
+        return (float)d;
+    };
+    if (C <= (int)blockDim.x) {
+        const int rif = blockDim.x / C;
+        const int c = threadIdx.x % C, rr = threadIdx.x / C;
+        float acc = 0.f;
+        if (rr < rif) {
+            const float mu = mean[c], inv = invstd[c], ga = gamma[c], s1 = stats2[c], s2 = stats2[C + c];
+#pragma unroll 4
+            for (int64_t r = r0 + rr; r < r1; r += rif) acc += one(r * C + c, mu, inv, ga, s1, s2);
+        }
+        if (partb != nullptr) {
+            sm[threadIdx.x] = (rr < rif) ? acc : 0.f;
+            __syncthreads();
+            if (threadIdx.x < C) {
+                float t = 0.f;
+                for (int k = 0; k < rif; ++k) t += sm[k * C + threadIdx.x];
+                partb[(int64_t)blockIdx.x * C + threadIdx.x] = t;
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float mu = mean[c], inv = invstd[c], ga = gamma[c], s1 = stats2[c], s2 = stats2[C + c];
+            float acc = 0.f;
+#pragma unroll 4
+            for (int64_t r = r0; r < r1; ++r) acc += one(r * C + c, mu, inv, ga, s1, s2);
+            if (partb != nullptr) partb[(int64_t)blockIdx.x * C + c] = acc;
+        }
     }
 }
 
@@ -658,7 +766,8 @@ int sv_act_bwd(const void* dy, const void* y, void* dz, void* db, int db_accumul
                                         (const T*)dy, (const T*)y, (T*)dz, part, rows, C, act, alpha, p.rows_per_block););
     int rc = check_launch("sv_act_bwd");
     if (rc || db == nullptr) return rc;
-    hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, to_stream(stream), part, (float*)db,
+    if (defer_reduce(part, (float*)db, C, p.nblocks, db_accumulate)) return SV_OK;
+    hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, to_stream(stream), part, (float*)db,
                        p.nblocks, C, db_accumulate);
     return check_launch("sv_act_bwd/fold");
 }
@@ -675,7 +784,8 @@ int sv_bias_grad(const void* dz, void* db, int accumulate, int64_t rows, int C, 
                                         (const T*)dz, part, rows, C, p.rows_per_block););
     rc = check_launch("sv_bias_grad");
     if (rc) return rc;
-    hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, to_stream(stream), part, (float*)db,
+    if (defer_reduce(part, (float*)db, C, p.nblocks, accumulate)) return SV_OK;
+    hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, to_stream(stream), part, (float*)db,
                        p.nblocks, C, accumulate);
     return check_launch("sv_bias_grad/fold");
 }
@@ -726,70 +836,164 @@ int sv_upsample2d_bwd(const void* dy, void* dx, int N, int H, int W, int C, int 
     return check_launch("sv_upsample2d_bwd");
 }
 
-int sv_batchnorm_fwd_train(const void* x, const float* gamma, const float* beta, void* y, float* save_mean,
-                           float* save_invstd, float* moving_mean, float* moving_var, int64_t rows, int C, float eps,
-                           float momentum, int unbiased_moving_var, void* workspace, size_t workspace_bytes,
-                           int dtype, sv_stream_t stream) {
+// Row blocks of the backward launch that also carries neighbouring activations: it is a streaming pass, so it takes more
+// (shorter) blocks than the statistics passes; each leaves one row of bias partial sums.
+static ColPlan bn_apply_plan(int64_t rows_g, int C) {
+    const int64_t sweep = C < 256 ? 256 / C : 1;
+    int64_t rpb = 8 * sweep;
+    const int64_t floor_rpb = ceil_div(rows_g, 2048);
+    if (rpb < floor_rpb) rpb = floor_rpb;
+    ColPlan p;
+    p.rows_per_block = rpb;
+    p.nblocks = (int)ceil_div(rows_g, rpb);
+    return p;
+}
+
+static size_t bn_ws_bytes(int64_t rows_g, int C, int groups) {
+    ColPlan p = col_plan(rows_g, C), pa = bn_apply_plan(rows_g, C);
+    return ((size_t)groups * ((size_t)p.nblocks * 2 * C + 2 * (size_t)C + (size_t)pa.nblocks * C)) * sizeof(float);
+}
+
+size_t sv_batchnorm_workspace_bytes(int64_t rows, int C, int groups) {
+    if (rows <= 0 || C <= 0 || groups <= 0 || rows % groups) return 0;
+    return bn_ws_bytes(rows / groups, C, groups);
+}
+
+// workspace: [groups][nblocks][2][C] partial sums | [groups][2][C] folded sums | [groups * nblocks][C] bias partial sums
+static int bn_ws(void* ws, size_t ws_bytes, int64_t rows_g, int C, int groups, float** part, float** folded, float** partb,
+                 const char* who) {
+    const size_t need = bn_ws_bytes(rows_g, C, groups);
+    if (ws == nullptr || ws_bytes < need)
+        return fail(SV_E_WORKSPACE, "%s: workspace %zu bytes < required %zu", who, ws_bytes, need);
+    ColPlan p = col_plan(rows_g, C);
+    *part = (float*)ws;
+    *folded = *part + (size_t)groups * p.nblocks * 2 * C;
+    *partb = *folded + (size_t)groups * 2 * C;
+    return SV_OK;
+}
+
+int sv_batchnorm_act_fwd_train(const void* x, const float* gamma, const float* beta, void* y, float* save_mean,
+                               float* save_invstd, float* moving_mean, float* moving_var, int64_t rows, int C, float eps,
+                               float momentum, int unbiased_moving_var, int groups, int act, float alpha, void* workspace,
+                               size_t workspace_bytes, int dtype, sv_stream_t stream) {
     SV_F32_OR_BF16(dtype, "sv_batchnorm_fwd_train");
     SV_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && rows > 0 && C > 0 && C <= kMaxC,
                "sv_batchnorm_fwd_train: bad arguments (C=%d)", C);
+    SV_REQUIRE(groups >= 1 && groups <= 64 && rows % groups == 0,
+               "sv_batchnorm_fwd_train: %lld rows do not split into %d statistics groups", (long long)rows, groups);
     SV_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr),
                "sv_batchnorm_fwd_train: moving_mean and moving_var must both be given or both be NULL");
-    ColPlan p = col_plan(rows, C);
-    float *part = nullptr, *folded = nullptr;
-    int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_batchnorm_fwd_train");
+    const int64_t rows_g = rows / groups;
+    ColPlan p = col_plan(rows_g, C);
+    float *part = nullptr, *folded = nullptr, *partb = nullptr;
+    int rc = bn_ws(workspace, workspace_bytes, rows_g, C, groups, &part, &folded, &partb, "sv_batchnorm_fwd_train");
     if (rc) return rc;
     hipStream_t st = to_stream(stream);
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_stats_k<T>, dim3(p.nblocks), dim3(256), 512 * sizeof(float), st, (const T*)x, part,
-                                        rows, C, p.rows_per_block););
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_stats_k<T>, dim3(p.nblocks, groups), dim3(256), 512 * sizeof(float), st,
+                                        (const T*)x, part, rows_g, C, p.rows_per_block););
     rc = check_launch("bn_stats");
     if (rc) return rc;
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_finalize_k<T>, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, st, (const T*)x, part,
-                                        p.nblocks, save_mean, save_invstd, moving_mean, moving_var, rows, C, eps, momentum,
-                                        unbiased_moving_var););
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_finalize_k<T>, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st, (const T*)x, part,
+                                        p.nblocks, save_mean, save_invstd, moving_mean, moving_var, rows_g, C, eps, momentum,
+                                        unbiased_moving_var, groups););
     rc = check_launch("bn_finalize");
     if (rc) return rc;
     const int64_t total = rows * C;
     SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, st, (const T*)x, gamma,
-                                        beta, save_mean, save_invstd, 0, eps, (T*)y, total, C););
+                                        beta, save_mean, save_invstd, 0, eps, (T*)y, total, C, act, alpha, rows_g * C););
     return check_launch("bn_apply");
 }
 
-int sv_batchnorm_fwd_infer(const void* x, const float* gamma, const float* beta, const float* moving_mean,
-                           const float* moving_var, void* y, int64_t rows, int C, float eps, int dtype,
+int sv_batchnorm_fwd_train(const void* x, const float* gamma, const float* beta, void* y, float* save_mean,
+                           float* save_invstd, float* moving_mean, float* moving_var, int64_t rows, int C, float eps,
+                           float momentum, int unbiased_moving_var, void* workspace, size_t workspace_bytes, int dtype,
                            sv_stream_t stream) {
+    // the plain layer; its workspace contract (sv_colreduce_workspace_bytes) is the smaller historical one
+    if (workspace != nullptr && rows > 0 && C > 0 && workspace_bytes >= col_ws_bytes(rows, C) &&
+        workspace_bytes < bn_ws_bytes(rows, C, 1)) {
+        // the fused entry point's layout only adds the bias partial sums, which this call never writes
+        workspace_bytes = bn_ws_bytes(rows, C, 1);
+    }
+    return sv_batchnorm_act_fwd_train(x, gamma, beta, y, save_mean, save_invstd, moving_mean, moving_var, rows, C, eps,
+                                      momentum, unbiased_moving_var, 1, SV_ACT_NONE, 0.f, workspace, workspace_bytes, dtype,
+                                      stream);
+}
+
+int sv_batchnorm_act_fwd_infer(const void* x, const float* gamma, const float* beta, const float* moving_mean,
+                               const float* moving_var, void* y, int64_t rows, int C, float eps, int act, float alpha,
+                               int dtype, sv_stream_t stream) {
     SV_F32_OR_BF16(dtype, "sv_batchnorm_fwd_infer");
     SV_REQUIRE(x && gamma && beta && moving_mean && moving_var && y && rows > 0 && C > 0,
                "sv_batchnorm_fwd_infer: bad arguments");
     const int64_t total = rows * C;
     SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
-                                        (const T*)x, gamma, beta, moving_mean, moving_var, 1, eps, (T*)y, total, C););
+                                        (const T*)x, gamma, beta, moving_mean, moving_var, 1, eps, (T*)y, total, C, act, alpha,
+                                        total););
     return check_launch("sv_batchnorm_fwd_infer");
+}
+
+int sv_batchnorm_fwd_infer(const void* x, const float* gamma, const float* beta, const float* moving_mean,
+                           const float* moving_var, void* y, int64_t rows, int C, float eps, int dtype,
+                           sv_stream_t stream) {
+    return sv_batchnorm_act_fwd_infer(x, gamma, beta, moving_mean, moving_var, y, rows, C, eps, SV_ACT_NONE, 0.f, dtype,
+                                      stream);
+}
+
+int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int act_out, float alpha_out, const float* gamma,
+                         const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta,
+                         int accumulate, int act_in, float alpha_in, float* dbias_in, int dbias_accumulate, int64_t rows,
+                         int C, int groups, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_OR_BF16(dtype, "sv_batchnorm_bwd");
+    SV_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && rows > 0 && C > 0 &&
+                   C <= kMaxC,
+               "sv_batchnorm_bwd: bad arguments (C=%d)", C);
+    SV_REQUIRE(groups >= 1 && groups <= 64 && rows % groups == 0,
+               "sv_batchnorm_bwd: %lld rows do not split into %d statistics groups", (long long)rows, groups);
+    SV_REQUIRE((y_act == nullptr) == (act_out == SV_ACT_NONE), "sv_batchnorm_bwd: y_act and act_out go together");
+    const int64_t rows_g = rows / groups;
+    ColPlan p = col_plan(rows_g, C);
+    float *part = nullptr, *stats2 = nullptr, *partb = nullptr;
+    int rc = bn_ws(workspace, workspace_bytes, rows_g, C, groups, &part, &stats2, &partb, "sv_batchnorm_bwd");
+    if (rc) return rc;
+    hipStream_t st = to_stream(stream);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_stats_k<T>, dim3(p.nblocks, groups), dim3(256), 512 * sizeof(float), st,
+                                        (const T*)x, (const T*)dy, save_mean, save_invstd, part, rows_g, C, p.rows_per_block,
+                                        (const T*)y_act, act_out, alpha_out););
+    rc = check_launch("bn_bwd_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_fold_k, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
+                       accumulate, C, groups);
+    rc = check_launch("bn_bwd_fold");
+    if (rc) return rc;
+    if (y_act == nullptr && act_in == SV_ACT_NONE && dbias_in == nullptr) {
+        SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_grid(rows * C, 256, 8192)), dim3(256), 0, st,
+                                            (const T*)x, (const T*)dy, gamma, save_mean, save_invstd, stats2, (T*)dx, rows_g, C,
+                                            groups););
+        return check_launch("bn_bwd_apply");
+    }
+    const ColPlan pa = bn_apply_plan(rows_g, C);
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_rows_k<T>, dim3(pa.nblocks, groups), dim3(256), 256 * sizeof(float), st,
+                                        (const T*)x, (const T*)dy, (const T*)y_act, act_out, alpha_out, gamma, save_mean,
+                                        save_invstd, stats2, (T*)dx, act_in, alpha_in, dbias_in ? partb : nullptr, rows_g, C,
+                                        pa.rows_per_block););
+    rc = check_launch("bn_bwd_apply_rows");
+    if (rc || dbias_in == nullptr) return rc;
+    const int slabs = groups * pa.nblocks;
+    if (defer_reduce(partb, dbias_in, C, slabs, dbias_accumulate)) return SV_OK;
+    hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st, partb, dbias_in, slabs, C,
+                       dbias_accumulate);
+    return check_launch("bn_bwd/bias fold");
 }
 
 int sv_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const float* save_mean,
                      const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t rows,
                      int C, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_OR_BF16(dtype, "sv_batchnorm_bwd");
-    SV_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && rows > 0 && C > 0 &&
-                   C <= kMaxC,
-               "sv_batchnorm_bwd: bad arguments (C=%d)", C);
-    ColPlan p = col_plan(rows, C);
-    float *part = nullptr, *stats2 = nullptr;
-    int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &stats2, "sv_batchnorm_bwd");
-    if (rc) return rc;
-    hipStream_t st = to_stream(stream);
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_stats_k<T>, dim3(p.nblocks), dim3(256), 512 * sizeof(float), st, (const T*)x,
-                                        (const T*)dy, save_mean, save_invstd, part, rows, C, p.rows_per_block););
-    rc = check_launch("bn_bwd_stats");
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_fold_k, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
-                       accumulate, C);
-    rc = check_launch("bn_bwd_fold");
-    if (rc) return rc;
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_grid(rows * C, 256, 8192)), dim3(256), 0, st, (const T*)x,
-                                        (const T*)dy, gamma, save_mean, save_invstd, stats2, (T*)dx, rows, C););
-    return check_launch("bn_bwd_apply");
+    if (workspace != nullptr && rows > 0 && C > 0 && workspace_bytes >= col_ws_bytes(rows, C) &&
+        workspace_bytes < bn_ws_bytes(rows, C, 1)) {
+        workspace_bytes = bn_ws_bytes(rows, C, 1);  // see sv_batchnorm_fwd_train: the tail of the layout stays unwritten
+    }
+    return sv_batchnorm_act_bwd(x, dy, nullptr, SV_ACT_NONE, 0.f, gamma, save_mean, save_invstd, dx, dgamma, dbeta, accumulate,
+                                SV_ACT_NONE, 0.f, nullptr, 0, rows, C, 1, workspace, workspace_bytes, dtype, stream);
 }
 
 int sv_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int Ca, int Cb, int dtype,

@@ -102,22 +102,29 @@ __global__ void mse_map_k(const float* __restrict__ t, const T* __restrict__ p, 
 }
 
 // ------------------------------------------------------------------------------------------------ Adam (Keras legacy form)
+// Keras schedule and bias correction of update number it + 1 (run_model.py:77-89: ExponentialDecay, legacy Adam):
+// lr = lr0 * decay_rate^(it / decay_steps), alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t).  b^t is evaluated as
+// exp(t log b) in f64 (a shorter dependent chain than pow); one function, so that every kernel derives the same bits.
+__device__ __forceinline__ void adam_schedule(int64_t it, float lr0, float beta1, float beta2, int decay_steps,
+                                              float decay_rate, int staircase, float& alpha_out, float& lr_out) {
+    double lr = (double)lr0;
+    if (decay_steps > 0) {
+        double e = (double)it / (double)decay_steps;
+        if (staircase) e = floor(e);
+        lr *= exp(e * log((double)decay_rate));
+    }
+    const double t = (double)(it + 1);
+    alpha_out = (float)(lr * sqrt(-expm1(t * log((double)beta2))) / -expm1(t * log((double)beta1)));
+    lr_out = (float)lr;
+}
+
 // state[0] = number of updates applied so far (int64); state[1] holds {alpha, lr} as two floats.
 __global__ void adam_prepare_k(int64_t* __restrict__ state, float lr0, float beta1, float beta2, int decay_steps,
                                float decay_rate, int staircase) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t it = state[0];
-        double lr = (double)lr0;
-        if (decay_steps > 0) {
-            double e = (double)it / (double)decay_steps;
-            if (staircase) e = floor(e);
-            lr *= pow((double)decay_rate, e);
-        }
-        const double t = (double)(it + 1);
-        const double alpha = lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
         float* f = reinterpret_cast<float*>(state + 1);
-        f[0] = (float)alpha;
-        f[1] = (float)lr;
+        adam_schedule(it, lr0, beta1, beta2, decay_steps, decay_rate, staircase, f[0], f[1]);
         state[0] = it + 1;
     }
 }
@@ -177,17 +184,8 @@ __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ theta, fl
     if (fold.partials != nullptr && blockIdx.x == gridDim.x - 1)
         fold_scalar_256(fold.partials, fold.n, fold.scale, fold.out, fold.accumulate, fold.running, fold.running_weight);
     const int64_t it = state[0];
-    if (threadIdx.x == 0) {
-        double lr = (double)lr0;
-        if (decay_steps > 0) {
-            double e = (double)it / (double)decay_steps;
-            if (staircase) e = floor(e);
-            lr *= pow((double)decay_rate, e);
-        }
-        const double t = (double)(it + 1);
-        alpha_s = (float)(lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
-        lr_s = (float)lr;
-    }
+    if (threadIdx.x == 0)  // a chain of dependent f64 operations, paid once per workgroup
+        adam_schedule(it, lr0, beta1, beta2, decay_steps, decay_rate, staircase, alpha_s, lr_s);
     __syncthreads();
     const float alpha = alpha_s;
     const int64_t n4 = n >> 2;
@@ -477,7 +475,8 @@ int sv_adam_keras_step(float* theta, float* grad, float* m, float* v, int64_t n,
                    ((uintptr_t)v % 16 == 0),
                "sv_adam_keras_step: buffers must be 16-byte aligned");
     const ScalarFold fold{fold_partials, fold_n, fold_scale, fold_out, 0, fold_running, fold_running_weight};
-    hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(n / 4 + 1, 256, 4096)), dim3(256), 0, to_stream(stream), theta, grad, m, v,
+    // few workgroups (about one per CU): each pays the schedule's latency once and then streams its share
+    hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(n / 4 + 1, 256, 256)), dim3(256), 0, to_stream(stream), theta, grad, m, v,
                        n, step_state, lr0, beta1, beta2, eps, decay_steps, decay_rate, staircase, grad_scale, zero_grad,
                        (__bf16*)theta_bf16, fold);
     return check_launch("sv_adam_keras_step");

@@ -18,7 +18,8 @@ import torch
 from . import losses as losses_mod
 from . import ops
 from .losses import to_device_f32
-from .nn import DEFAULT_SEED, BufferPool, CallCtx, DTensor, Layer, Sequential, Variable, as_dtensor, default_device
+from .nn import (DEFAULT_SEED, BufferPool, CallCtx, DTensor, Layer, Sequential, Variable, as_dtensor, default_device,
+                 recording)
 
 ALIGN = 8  # floats; every variable starts on a 16-byte boundary of the flat buffer AND of its bf16 copy
 
@@ -88,6 +89,8 @@ class Model(Layer):
         # Run the whole forward as ONE launch when the model is a plain chain of fusable 3x3 convs (see
         # ``_conv_chain``); the per-layer buffers are filled exactly as the per-layer path fills them.
         self.use_net_fused = True
+        # one launch per backward pass for all kernel / bias gradient slab sums (SPECTRUM_DEFER_REDUCES=0: per layer)
+        self.defer_reduces = os.environ.get("SPECTRUM_DEFER_REDUCES", "1") != "0"
         self.fuse_loss = True  # MeanSquaredError evaluated inside the one-launch forward, folded by the optimizer launch
         # measured at batch 1024 (step time in ms for large / small = 256/256: 0.297, 128/256: 0.291, 128/128: 0.292, 64/256: 0.321)
         self.wgrad_batch_blocks_large = int(os.environ.get("SPECTRUM_WGRAD_BLOCKS_LARGE", "128"))  # layers of >= 256 pixels
@@ -350,7 +353,7 @@ class Model(Layer):
             prev = y
         return prev
 
-    def forward_raw(self, x: torch.Tensor, training: bool, side=None, mse=None) -> torch.Tensor:
+    def forward_raw(self, x: torch.Tensor, training: bool, side=None, mse=None, bn_groups: int = 1) -> torch.Tensor:
         """Forward on a prepared device tensor; the result aliases the model's buffer pool.  ``side``: stream
         the backward pass of this call may use for its weight-gradient kernels (the caller joins it).  ``mse``: see
         ``_net_forward``; honoured only when the whole forward is the one-launch kernel (check ``ctx.loss_fold``)."""
@@ -365,6 +368,7 @@ class Model(Layer):
                 self._refresh_lp()
             x = self._to_act(x, ctx.slot)
         ctx.loss_fold = None
+        ctx.bn_groups = int(bn_groups)  # the batch is this many independent BatchNorm groups (see CallCtx)
         self._last_ctx = ctx
         if self.use_net_fused and not ctx.lp:
             y = self._net_forward(ctx, x, mse)
@@ -373,8 +377,25 @@ class Model(Layer):
         return self.forward(ctx, x)
 
     def backward_raw(self, dy: torch.Tensor, call: int = -1, need_dx: bool = False):
-        """Backward of the ``call``-th remembered training call; parameter gradients accumulate."""
+        """Backward of the ``call``-th remembered training call; parameter gradients accumulate.  The per-layer
+        "sum the partial slabs into dw / db" steps of the strided / transposed conv family are queued and run as ONE
+        launch at the end of the pass (every layer then works in scratch of its own)."""
         ctx = self._calls[call]
+        if not (self.defer_reduces and ctx.param_grads and ctx.side is None):
+            return self._backward_raw(ctx, dy, need_dx)
+        ops.deferred_reduce_begin()
+        self._pool.begin_private()
+        try:
+            dx = self._backward_raw(ctx, dy, need_dx)
+        except BaseException:
+            ops.deferred_reduce_flush(False)
+            self._pool.end_private()
+            raise
+        ops.deferred_reduce_flush(True)
+        self._pool.end_private()
+        return dx
+
+    def _backward_raw(self, ctx, dy: torch.Tensor, need_dx: bool):
         self._grads_clean = False
         net = getattr(ctx, "net", None)
         if net is not None and self.use_net_fused_bwd and not need_dx and ctx.param_grads:
@@ -550,25 +571,33 @@ class Model(Layer):
             return
         if g == "warm":
             torch.cuda.synchronize()
-            if self._reducer is None:
+            g = None
+            if self._reducer is not None and self._reducer.capturable(self._params.device):
+                # RCCL: the all-reduce is recorded with the rest of the step (one graph launch per step)
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with recording(graph, capture_error_mode="thread_local"):
+                        self._train_step_body(b, same_xy, weight)
+                    g = (graph, None, "collective inside")
+                except RuntimeError:  # recording the whole step failed where the probe passed: collective between graphs
+                    self._reducer._capturable = False
+                    torch.cuda.synchronize()
+                    self._calls.clear()
+                self._reducer.note_reduced(self._grads, -1)  # recording is not reducing
+            if g is not None:
+                pass
+            elif self._reducer is None:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with recording(graph):
                     self._train_step_body(b, same_xy, weight)
                 g = (graph,)
-            elif self._reducer.capturable(self._params.device):
-                # RCCL: the all-reduce is recorded with the rest of the step (one graph launch per step)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    self._train_step_body(b, same_xy, weight)
-                self._reducer.note_reduced(self._grads, -1)  # recording is not reducing
-                g = (graph, None, "collective inside")
             else:
                 scale = 1.0 / self._reducer.world
                 g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 # thread-local capture: the process group's watchdog thread polls events while this thread records
-                with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
+                with recording(g_fb, capture_error_mode="thread_local"):
                     fold = self._fwd_bwd(b, same_xy, weight)
-                with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
+                with recording(g_opt, capture_error_mode="thread_local"):
                     self.optimizer.apply_model(self, scale, zero_grads=True, fold=fold)
                 g = (g_fb, g_opt)
             self._graphs[key] = g

@@ -15,6 +15,11 @@ arguments, NHWC activations, Keras weight layouts and weight ordering.
 """
 from __future__ import annotations
 
+import contextlib
+import gc
+
+import os
+
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -121,6 +126,11 @@ class BufferPool:
         self._ws_side: Dict[int, torch.Tensor] = {}
         self._retired: List[torch.Tensor] = []
         self.device: Optional[torch.device] = None
+        # private mode (deferred reductions pending): every workspace request gets its own slice of an arena
+        self._arena: Optional[torch.Tensor] = None
+        self._bump: Optional[int] = None
+        self._arena_peak = 0
+        self._pass_total = 0
 
     def get(self, key, shape, dtype=torch.float32) -> torch.Tensor:
         k = (key, tuple(shape), dtype)
@@ -133,6 +143,8 @@ class BufferPool:
     def workspace(self, nbytes: int) -> torch.Tensor:
         """Shared scratch for reductions; grows, never shrinks.  Kernels using it run on one stream."""
         nbytes = max(int(nbytes), 256)
+        if self._bump is not None:
+            return self._private(nbytes)
         if self._ws is None or self._ws.numel() < nbytes:
             if self._ws is not None:
                 # recorded HIP graphs hold the old buffer's raw address: it must stay allocated (and unused by anyone
@@ -140,6 +152,38 @@ class BufferPool:
                 self._retired.append(self._ws)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def begin_private(self):
+        """From here to ``end_private`` every ``workspace`` request returns memory of its own (slices of one arena):
+        kernels whose partial sums are reduced later, in one launch, must not share scratch.  The arena is sized from the
+        largest pass seen so far, so from the second pass on the slices sit at fixed addresses (recordable)."""
+        if self._arena is None or self._arena.numel() < self._arena_peak:
+            if self._arena is not None:
+                self._retired.append(self._arena)  # recorded graphs / queued kernels may still point into it
+            self._arena = torch.empty(max(self._arena_peak, 1 << 20), dtype=torch.uint8, device=self.device)
+        self._bump = 0
+        self._pass_total = 0
+
+    def end_private(self):
+        self._arena_peak = max(self._arena_peak, self._pass_total)
+        self._bump = None
+        if self._arena.numel() < self._arena_peak and not torch.cuda.is_current_stream_capturing():
+            # size the arena for the next pass now: that pass may be the one being recorded, which must not allocate
+            self._retired.append(self._arena)
+            self._arena = torch.empty(self._arena_peak, dtype=torch.uint8, device=self.device)
+
+    def _private(self, nbytes: int) -> torch.Tensor:
+        off = self._bump
+        size = (nbytes + 255) & ~255
+        if off + size > self._arena.numel():
+            # outgrown during a first pass: earlier slices stay valid in the retired arena; the next pass starts with
+            # an arena sized for everything this pass asked for
+            self._retired.append(self._arena)
+            self._arena = torch.empty(max(2 * self._arena.numel(), size), dtype=torch.uint8, device=self.device)
+            off = 0
+        self._bump = off + size
+        self._pass_total += size
+        return self._arena[off:off + nbytes]
 
     def workspace_side(self, lane: int, nbytes: int) -> torch.Tensor:
         """Scratch of the kernels issued on side stream ``lane`` (weight-gradient branch of the backward pass)."""
@@ -180,6 +224,9 @@ class CallCtx:
         self.loss_fold: Optional[tuple] = None
         # [(device scalar, weight)]: terms the forward pass adds to the training loss (Keras ``add_loss``)
         self.extra_losses: list = []
+        # BatchNorm statistics groups: the batch is this many equal consecutive parts, each normalised on its own (a
+        # discriminator called on [real; generated] in one pass instead of twice)
+        self.bn_groups = 1
 
     def buf(self, layer, role, shape, dtype=None):
         return self.pool.get((id(layer), role, self.slot), shape, self.dtype if dtype is None else dtype)
@@ -188,10 +235,44 @@ class CallCtx:
     def lp(self) -> bool:
         return self.dtype != torch.float32
 
+    def group_view(self, g: int) -> "CallCtx":
+        """The part of this call that belongs to statistics group ``g``, as a call of its own: saved activations sliced
+        to the group's samples, BatchNorm statistics to the group's row.  A backward pass through the view is the
+        backward pass of a separate forward call on those samples."""
+        groups = self.bn_groups
+        v = CallCtx(self.pool, ("grp", g, self.slot), self.training, self.dtype)
+        v.param_grads = self.param_grads
+        for key, d in self.saved.items():
+            nd = {}
+            for name, t in d.items():
+                if not isinstance(t, torch.Tensor):
+                    nd[name] = t
+                elif name in ("mean", "invstd"):
+                    nd[name] = t.view(groups, -1)[g]
+                else:
+                    b = t.shape[0] // groups
+                    nd[name] = t[g * b:(g + 1) * b]
+            v.saved[key] = nd
+        return v
+
     def need_f32(self, layer):
         if self.lp:
             raise NotImplementedError(f"{type(layer).__name__} ({layer.name}) has no bfloat16 kernels: build the model "
                                       "with the float32 policy")
+
+
+@contextlib.contextmanager
+def recording(graph, **kw):
+    """``torch.cuda.graph`` with the cyclic garbage collector paused: a finalizer that releases device objects (another
+    model's graphs, events) in the middle of a stream capture aborts the process."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 # --------------------------------------------------------------------------- base layer
@@ -435,7 +516,9 @@ class _ConvBase(Layer):
         rows = n * ho * wo
         dz = dy  # the activation backward runs in place on the incoming gradient buffer
         want_db = self.bias is not None and ctx.param_grads
-        if self.act is not None or want_db:
+        if s.get("dz_done"):
+            pass  # the BatchNormalization that follows this layer emitted dz (and the bias gradient) from its own launch
+        elif self.act is not None or want_db:
             ws = ctx.pool.workspace(ops.colreduce_workspace(rows, cout)) if want_db else None
             if self.act is not None:
                 ops.act_bwd(dy, y, dz, self.bias.grad if want_db else None, True, rows, cout, self.act, self.alpha, ws)
@@ -574,21 +657,29 @@ class BatchNormalization(Layer):
         self.unbiased = (len(in_shape) == 3) if self._unbiased is None else bool(self._unbiased)
         return in_shape
 
+    # set by Sequential's planner:
+    fused_act = None   # (act, alpha) of the activation layer that follows: applied in this layer's launches
+    prev_conv = None   # the conv in front whose activation backward (+ bias gradient) this layer's backward carries
+
     def forward(self, ctx, x):
         c = self.input_shape_[-1]
         rows = x.numel() // c
         y = ctx.buf(self, "y", tuple(x.shape))
+        act, alpha = self.fused_act if self.fused_act is not None else (None, 0.0)
         if ctx.training:
-            mean = ctx.buf(self, "mean", (c,), torch.float32)
-            invstd = ctx.buf(self, "invstd", (c,), torch.float32)
-            ws = ctx.pool.workspace(ops.colreduce_workspace(rows, c))
-            ops.batchnorm_fwd_train(x, self.gamma.data, self.beta.data, y, mean, invstd, self.moving_mean.data,
-                                    self.moving_variance.data, rows, c, self.epsilon, self.momentum, self.unbiased,
-                                    ws)
-            ctx.saved[id(self)] = {"x": x, "mean": mean, "invstd": invstd}
+            g = ctx.bn_groups
+            if x.shape[0] % g:
+                raise ValueError(f"{self.name}: a batch of {x.shape[0]} does not split into {g} statistics groups")
+            mean = ctx.buf(self, "mean", (g, c), torch.float32)
+            invstd = ctx.buf(self, "invstd", (g, c), torch.float32)
+            ws = ctx.pool.workspace(ops.batchnorm_workspace(rows, c, g))
+            ops.batchnorm_act_fwd_train(x, self.gamma.data, self.beta.data, y, mean, invstd, self.moving_mean.data,
+                                        self.moving_variance.data, rows, c, self.epsilon, self.momentum, self.unbiased,
+                                        g, act, alpha, ws)
+            ctx.saved[id(self)] = {"x": x, "y": y, "mean": mean, "invstd": invstd}
         else:
-            ops.batchnorm_fwd_infer(x, self.gamma.data, self.beta.data, self.moving_mean.data,
-                                    self.moving_variance.data, y, rows, c, self.epsilon)
+            ops.batchnorm_act_fwd_infer(x, self.gamma.data, self.beta.data, self.moving_mean.data,
+                                        self.moving_variance.data, y, rows, c, self.epsilon, act, alpha)
         return y
 
     def backward(self, ctx, dy, need_dx=True):
@@ -596,14 +687,25 @@ class BatchNormalization(Layer):
         x = s["x"]
         c = self.input_shape_[-1]
         rows = x.numel() // c
+        g = s["mean"].numel() // c
         dx = ctx.buf(self, "dx", tuple(x.shape))
-        ws = ctx.pool.workspace(ops.colreduce_workspace(rows, c))
+        ws = ctx.pool.workspace(ops.batchnorm_workspace(rows, c, g))
         if ctx.param_grads:
             dg, db, acc = self.gamma.grad, self.beta.grad, True
         else:
             dg, db, acc = (ctx.buf(self, "dg_scratch", (c,), torch.float32),
                            ctx.buf(self, "db_scratch", (c,), torch.float32), False)
-        ops.batchnorm_bwd(x, dy, self.gamma.data, s["mean"], s["invstd"], dx, dg, db, acc, rows, c, ws)
+        act_out, alpha_out = self.fused_act if self.fused_act is not None else (None, 0.0)
+        conv = self.prev_conv
+        act_in, alpha_in, dbias = None, 0.0, None
+        if (conv is not None and not conv.fused_bwd and conv.pool is None and id(conv) in ctx.saved
+                and ctx.saved[id(conv)]["y"].data_ptr() == x.data_ptr()):
+            act_in, alpha_in = conv.act, conv.alpha
+            if conv.bias is not None and ctx.param_grads:
+                dbias = conv.bias.grad
+            ctx.saved[id(conv)]["dz_done"] = True
+        ops.batchnorm_act_bwd(x, dy, s["y"] if act_out is not None else None, act_out, alpha_out, self.gamma.data,
+                              s["mean"], s["invstd"], dx, dg, db, acc, act_in, alpha_in, dbias, True, rows, c, g, ws)
         return dx
 
 
@@ -612,8 +714,10 @@ class Activation(Layer):
         super().__init__(name)
         self.act, self.alpha = _act_name(activation)
 
+    folded = False  # applied inside the BatchNormalization in front of it (set by Sequential's planner)
+
     def forward(self, ctx, x):
-        if self.act is None:
+        if self.act is None or self.folded:
             return x
         y = ctx.buf(self, "y", tuple(x.shape))
         ops.act_fwd(x, y, self.act, self.alpha)
@@ -622,7 +726,7 @@ class Activation(Layer):
         return y
 
     def backward(self, ctx, dy, need_dx=True):
-        if self.act is None or not need_dx:
+        if self.act is None or not need_dx or self.folded:
             return dy if need_dx else None
         y = ctx.saved[id(self)]["y"]
         c = y.shape[-1]
@@ -813,6 +917,17 @@ class Sequential(Layer):
                 self.layers[i + 1].up = l.size
                 continue  # the conv sees the *stored* (small) tensor's shape
             shape = l.build(shape)
+        if self.fuse and os.environ.get("SPECTRUM_BN_FUSE", "1") != "0":
+            for i, l in enumerate(self.layers):
+                if not isinstance(l, BatchNormalization):
+                    continue
+                nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
+                if type(nxt) in (Activation, LeakyReLU) and nxt.act is not None:
+                    l.fused_act = (nxt.act, nxt.alpha)  # BatchNormalization -> activation in one launch (unet.py:51-53)
+                    nxt.folded = True
+                prv = self.layers[i - 1] if i > 0 else None
+                if isinstance(prv, _ConvBase) and prv.act is not None:
+                    l.prev_conv = prv  # conv(activation) -> BatchNormalization (context_encoder.py:61-64), backward side
         if self.fuse:
             for i, l in enumerate(self.layers):
                 if type(l) is not Conv2D:

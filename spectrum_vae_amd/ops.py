@@ -171,6 +171,14 @@ def convnet_fwd_mse(arr, n: int, h: int, w: int, x, params, y_true, dpred, loss_
     return int(cnt.value)
 
 
+def deferred_reduce_begin():
+    check(lib.sv_deferred_reduce_begin(), "sv_deferred_reduce_begin")
+
+
+def deferred_reduce_flush(launch: bool = True):
+    check(lib.sv_deferred_reduce_flush(int(launch), _stream()), "sv_deferred_reduce_flush")
+
+
 def fold_scalar(partials, n: int, scale: float, out, accumulate=False, running=None, running_weight=0.0):
     check(lib.sv_fold_scalar(_ptr(partials), int(n), float(scale), _ptr(out), int(accumulate), _ptr(running),
                              float(running_weight), _stream()), "sv_fold_scalar")
@@ -296,6 +304,40 @@ def batchnorm_bwd(x, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta, accum
     check(lib.sv_batchnorm_bwd(_aptr(x), _aptr(dy, x, "dy"), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
                                _aptr(dx, x, "dx"), _ptr(dgamma), _ptr(dbeta), int(accumulate), rows, c,
                                _ptr(ws, torch.uint8), ws.numel(), _dt(x), _stream()), "sv_batchnorm_bwd")
+
+
+def batchnorm_workspace(rows: int, c: int, groups: int = 1) -> int:
+    return int(lib.sv_batchnorm_workspace_bytes(rows, c, groups))
+
+
+def batchnorm_act_fwd_train(x, gamma, beta, y, save_mean, save_invstd, moving_mean, moving_var, rows, c, eps, momentum,
+                            unbiased: bool, groups: int, act, alpha: float, ws):
+    """BatchNorm (``groups`` independent row groups) with a following activation in the same launches."""
+    if save_mean.numel() != groups * c or save_invstd.numel() != groups * c:
+        raise ValueError("batchnorm: saved statistics must be [groups][C]")
+    check(lib.sv_batchnorm_act_fwd_train(_aptr(x), _ptr(gamma), _ptr(beta), _aptr(y, x, "y"), _ptr(save_mean),
+                                         _ptr(save_invstd), _ptr(moving_mean), _ptr(moving_var), rows, c, eps, momentum,
+                                         int(unbiased), groups, ACT[act], alpha, _ptr(ws, torch.uint8), ws.numel(), _dt(x),
+                                         _stream()), "sv_batchnorm_act_fwd_train")
+
+
+def batchnorm_act_fwd_infer(x, gamma, beta, moving_mean, moving_var, y, rows, c, eps, act, alpha: float):
+    check(lib.sv_batchnorm_act_fwd_infer(_aptr(x), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
+                                         _aptr(y, x, "y"), rows, c, eps, ACT[act], alpha, _dt(x), _stream()),
+          "sv_batchnorm_act_fwd_infer")
+
+
+def batchnorm_act_bwd(x, dy, y_act, act_out, alpha_out: float, gamma, save_mean, save_invstd, dx, dgamma, dbeta,
+                      accumulate: bool, act_in, alpha_in: float, dbias_in, dbias_accumulate: bool, rows, c, groups: int, ws):
+    """Backward of ``batchnorm_act_fwd_train``; ``act_in`` / ``dbias_in``: also the activation backward (and bias
+    gradient) of the conv that produced ``x``."""
+    if save_mean.numel() != groups * c or save_invstd.numel() != groups * c:
+        raise ValueError("batchnorm: saved statistics must be [groups][C]")
+    check(lib.sv_batchnorm_act_bwd(_aptr(x), _aptr(dy, x, "dy"), _aptr(y_act, x, "y_act") if y_act is not None else None,
+                                   ACT[act_out], alpha_out, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
+                                   _aptr(dx, x, "dx"), _ptr(dgamma), _ptr(dbeta), int(accumulate), ACT[act_in], alpha_in,
+                                   _ptr(dbias_in), int(dbias_accumulate), rows, c, groups, _ptr(ws, torch.uint8), ws.numel(),
+                                   _dt(x), _stream()), "sv_batchnorm_act_bwd")
 
 
 def concat_channels_fwd(a, b, y, rows, ca, cb):
@@ -480,6 +522,13 @@ def axpy(y, x, a: float):
     if x.numel() != y.numel():
         raise ValueError("axpy: sizes differ")
     check(lib.sv_axpy(_aptr(y), _aptr(x, y, "x"), a, x.numel(), _dt(y), _stream()), "sv_axpy")
+
+
+def copy(src, dst):
+    """dst = src, same type and size (a device-to-device copy on the current stream)."""
+    if src.numel() != dst.numel() or src.dtype != dst.dtype:
+        raise ValueError("copy: size or type differs")
+    dst.as_subclass(torch.Tensor).view(-1).copy_(src.as_subclass(torch.Tensor).reshape(-1), non_blocking=True)
 
 
 def cast(src, dst):

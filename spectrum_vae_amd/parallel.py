@@ -22,6 +22,8 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from .nn import recording
+
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
     """Initialise torch.distributed from torchrun's environment.  Returns (rank, world_size, local_rank)."""
@@ -111,7 +113,7 @@ class GradReducer:
                 torch.cuda.synchronize(device)
                 t.fill_(1.0)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with recording(g, capture_error_mode="thread_local"):
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 g.replay()
                 g.replay()
@@ -165,7 +167,7 @@ def run_dp_step(st, use_graph: bool, compute, pairs, device):
         reds = [m._reducer for m, _ in pairs if m._reducer is not None]
         if all(r.capturable(device) for r in reds):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with recording(g, capture_error_mode="thread_local"):
                 compute()
                 update(reduce())
             for m, _ in pairs:
@@ -175,9 +177,9 @@ def run_dp_step(st, use_graph: bool, compute, pairs, device):
         else:
             scales = [1.0 / m._reducer.world if m._reducer is not None else 1.0 for m, _ in pairs]
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+            with recording(g1, capture_error_mode="thread_local"):
                 compute()
-            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            with recording(g2, capture_error_mode="thread_local"):
                 update(scales)
             st.dp_graphs = (g1, g2)
     st.dp_graphs[0].replay()

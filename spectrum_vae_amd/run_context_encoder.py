@@ -17,7 +17,7 @@ import torch
 from . import context_encoder, global_vars, ops, parallel
 from .data import sort_min_diff
 from .losses import BinaryCrossentropy, MeanSquaredError, to_device_f32
-from .nn import as_dtensor, default_device
+from .nn import as_dtensor, default_device, recording
 from .optimizers import Adam, ExponentialDecay
 
 
@@ -156,10 +156,14 @@ class _StepState:
         shp = (bs,) + ce.input_shape_
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=device)  # noqa: E731
         a = lambda *s: torch.empty(s, dtype=adt, device=device)  # noqa: E731  activations / their gradients
-        self.X, self.mask = f(*shp), f(*shp)
+        # the discriminator sees [real; generated] as ONE batch of 2 bs (two BatchNorm statistics groups)
+        self.both = a(2 * bs, *ce.input_shape_)
+        self.X = self.both[:bs] if adt == torch.float32 else f(*shp)  # float32: what the caller hands over
+        self.mask = f(*shp)
         self.Xm = a(*shp)
         self.dpred = a(*((bs,) + ce.output_shape_))
-        self.d_real, self.d_fake = a(bs, 1), a(bs, 1)
+        self.d_both = a(2 * bs, 1)
+        self.d_real, self.d_fake = self.d_both[:bs], self.d_both[bs:]
         self.l2, self.lt, self.lf, self.disc_loss, self.total = f(1), f(1), f(1), f(1), f(1)
         self.graph = None
         self.warm = False
@@ -181,31 +185,29 @@ def _step_state(ce, disc, ce_opt, disc_opt, bs: int, weight: float, device) -> _
 
 def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, overlap: bool = False,
                defer_updates: bool = False):
-    """``defer_updates``: stop after the backward passes (the data-parallel step reduces the gradients and applies the
-    updates itself).  ``overlap``: once ``pred`` and the reconstruction gradient exist, the context-encoder backward + update and the
-    discriminator forward / backward / update touch disjoint buffers (each model owns its buffer pool, workspace and
-    optimizer state), so the former is forked onto a second stream; at batch 64 neither fills the chip on its own."""
+    """One step of run_context_encoder.py:225-260.  The discriminator runs ONCE on [X; prediction] (2 B samples, two
+    BatchNorm statistics groups: the moving statistics get the real batch's update first, as with two calls) and its
+    backward pass once on [dL/dD(real); dL/dD(fake)].
+    ``defer_updates``: stop after the backward passes (the data-parallel step reduces the gradients and applies the
+    updates itself).  ``overlap``: once the prediction and the reconstruction gradient exist, the context-encoder
+    backward + update and the discriminator forward / backward / update touch disjoint buffers (each model owns its
+    buffer pool, workspace and optimizer state), so the former is forked onto a second stream; at batch 64 neither
+    fills the chip on its own."""
     mse, bce = MeanSquaredError(), BinaryCrossentropy(from_logits=False)
+    bs = st.mask.shape[0]
     ce.zero_grad_raw()
     disc.zero_grad_raw()
     main = torch.cuda.current_stream()
-    p_real, real_done = None, None
-    if overlap:  # D(real) needs nothing from the context encoder: it runs beside the encoder's forward pass
-        start = torch.cuda.Event()
-        start.record(main)
-        with torch.cuda.stream(st.side):
-            st.side.wait_event(start)
-            p_real = disc.forward_raw(st.X, True)
-            real_done = torch.cuda.Event()
-            real_done.record(st.side)
+    if st.X is not st.both and st.X.data_ptr() != st.both.data_ptr():  # bf16 policy: the real half in the models' type
+        ops.cast(st.X, st.both[:bs])
     ops.mask_input(st.X, st.mask, st.Xm)  # X * (1 - mask)
     pred = ce.forward_raw(st.Xm, True)
     # l2 = MSE(X, pred, sample_weight = mask[..., 0] * 10): channel 0 of the NHWC mask is read with stride C
     mse.value_and_grad(st.X, pred, st.l2, st.dpred, 1.0, sample_weight=st.mask, weight_scale=10.0,
                        weight_stride=st.mask.shape[-1])
+    ops.copy(pred, st.both[bs:])
     joined = None
-    if overlap:
-        main.wait_event(real_done)  # D(fake) follows D(real): BatchNorm's moving statistics are updated in that order
+    if overlap and not defer_updates:
         forked = torch.cuda.Event()
         forked.record(main)
         with torch.cuda.stream(st.side):
@@ -214,9 +216,8 @@ def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, ove
             ce_opt.apply_model(ce, 1.0)
             joined = torch.cuda.Event()
             joined.record(st.side)
-    else:
-        p_real = disc.forward_raw(st.X, True)
-    p_fake = disc.forward_raw(pred, True)
+    p = disc.forward_raw(st.both, True, bn_groups=2)
+    p_real, p_fake = p[:bs], p[bs:]
     bce.value_and_grad(1.0, p_real, st.lt, st.d_real, 0.5)
     bce.value_and_grad(0.0, p_fake, st.lf, st.d_fake, 0.5)
     ops.fill(st.disc_loss, 0.0)
@@ -226,8 +227,7 @@ def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, ove
     ops.axpy(st.total, st.l2, l2_weight)
     ops.axpy(st.total, st.disc_loss, 1.0 - l2_weight)
     # discriminator update: gradient of disc_loss w.r.t. the discriminator's weights only
-    disc.backward_raw(st.d_real, 0, need_dx=False)
-    disc.backward_raw(st.d_fake, 1, need_dx=False)
+    disc.backward_raw(st.d_both, 0, need_dx=False)
     if not defer_updates:
         disc_opt.apply_model(disc, 1.0)
     # context-encoder update: gradient of the masked reconstruction loss only
@@ -268,7 +268,7 @@ def train_step(context_encoder, discriminator, ce_opt, disc_opt, X, mask, l2_wei
         if st.graph is None:
             torch.cuda.synchronize()
             st.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.graph):
+            with recording(st.graph):
                 _step_body(ce, disc, ce_opt, disc_opt, st, l2_weight, overlap=True)
         st.graph.replay()
     return (as_dtensor(st.disc_loss.view(()).clone()), as_dtensor(st.l2.view(()).clone()),

@@ -17,7 +17,7 @@ import torch
 
 from . import global_vars, ops, parallel, unet
 from .losses import BinaryCrossentropy, MeanAbsoluteError, MeanSquaredError, to_device_f32
-from .nn import as_dtensor, default_device
+from .nn import as_dtensor, default_device, recording
 from .optimizers import Adam, ExponentialDecay
 
 
@@ -71,8 +71,11 @@ class _StepState:
         cy = gen.output_shape_[-1]
         self.X, self.y = f(bs, h, w, cx), f(bs, h, w, cy)  # float32: what the caller hands over, and the loss targets
         self.Xa, self.ya = (self.X, self.y) if adt == torch.float32 else (a(bs, h, w, cx), a(bs, h, w, cy))
-        self.cat_real, self.cat_fake = a(bs, h, w, cx + cy), a(bs, h, w, cx + cy)
-        self.d_real, self.d_fake, self.d_gan = a(bs, 1), a(bs, 1), a(bs, 1)
+        # the discriminator sees [real pair; generated pair] as ONE batch of 2 bs (two BatchNorm statistics groups)
+        self.cat_both = a(2 * bs, h, w, cx + cy)
+        self.cat_real, self.cat_fake = self.cat_both[:bs], self.cat_both[bs:]
+        self.d_both = a(2 * bs, 1)
+        self.d_real, self.d_fake, self.d_gan = self.d_both[:bs], self.d_both[bs:], a(bs, 1)
         self.dgen = a(bs, h, w, cy)       # lambda * dMAE/dgen
         self.dgen_gan = a(bs, h, w, cy)   # gradient of the GAN term w.r.t. the generated image
         self.dX_unused = a(bs, h, w, cx)
@@ -98,10 +101,14 @@ def _step_state(gen, disc, gen_opt, disc_opt, bs: int, weight: float, device) ->
 
 def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: float, overlap: bool = False,
                defer_updates: bool = False):
-    """``defer_updates``: stop after the backward passes (the data-parallel step reduces the gradients and applies the
-    updates itself).  ``overlap``: once the GAN term's gradient has come back through the discriminator, the generator backward +
-    update and the discriminator backward + update touch disjoint buffers (each model owns its buffer pool, workspace
-    and optimizer state), so the former is forked onto a second stream; at batch 32 neither fills the chip alone."""
+    """One step of run_unet.py:164-203.  The discriminator runs ONCE on [[X, y]; [X, G(X)]] (2 B samples, two BatchNorm
+    statistics groups: the moving statistics get the real batch's update first, as with two calls); the GAN term goes
+    back to the generated image through the second group alone, the discriminator's own gradients come from one
+    backward pass over both groups.
+    ``defer_updates``: stop after the backward passes (the data-parallel step reduces the gradients and applies the
+    updates itself).  ``overlap``: once the GAN term's gradient has come back through the discriminator, the generator
+    backward + update and the discriminator backward + update touch disjoint buffers (each model owns its buffer pool,
+    workspace and optimizer state), so the former is forked onto a second stream; at batch 32 neither fills the chip."""
     bce, mae = BinaryCrossentropy(from_logits=True), MeanAbsoluteError()
     n, h, w, cx = st.X.shape
     cy = st.y.shape[-1]
@@ -111,25 +118,11 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
     if st.Xa is not st.X:  # bf16 policy: the models read bf16 copies of the inputs
         ops.cast(st.X, st.Xa)
         ops.cast(st.y, st.ya)
-    main0 = torch.cuda.current_stream()
-    z_real = None
-    if overlap:  # D([X, y]) needs nothing from the generator: it runs beside the generator's forward pass
-        start = torch.cuda.Event()
-        start.record(main0)
-        with torch.cuda.stream(st.side):
-            st.side.wait_event(start)
-            ops.concat_channels_fwd(st.Xa, st.ya, st.cat_real, rows, cx, cy)
-            z_real = disc.forward_raw(st.cat_real, True)   # call 0
-            real_done = torch.cuda.Event()
-            real_done.record(st.side)
+    ops.concat_channels_fwd(st.Xa, st.ya, st.cat_real, rows, cx, cy)
     gen_out = gen.forward_raw(st.Xa, True)
-    if overlap:
-        main0.wait_event(real_done)  # D(fake) follows D(real): BatchNorm's moving statistics are updated in that order
-    else:
-        ops.concat_channels_fwd(st.Xa, st.ya, st.cat_real, rows, cx, cy)
-        z_real = disc.forward_raw(st.cat_real, True)   # call 0
     ops.concat_channels_fwd(st.Xa, gen_out, st.cat_fake, rows, cx, cy)
-    z_fake = disc.forward_raw(st.cat_fake, True)   # call 1
+    z = disc.forward_raw(st.cat_both, True, bn_groups=2)   # call 0
+    z_real, z_fake = z[:n], z[n:]
     # generator loss: BCE(1, D(fake)) + lambda * MAE(y, gen_out)
     bce.value_and_grad(1.0, z_fake, st.l_gan, st.d_gan, 1.0)
     mae.value_and_grad(st.y, gen_out, st.l_l1, st.dgen, float(lambda_weight))
@@ -142,13 +135,12 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
     ops.fill(st.disc_loss, 0.0)
     ops.axpy(st.disc_loss, st.l_real, 1.0)
     ops.axpy(st.disc_loss, st.l_fake, 1.0)
-    # (1) GAN term back through the discriminator's second call to the generated image; the discriminator's
-    #     own gradients are not touched (param_grads off), its weights are still those of the forward pass
-    ctx_fake = disc._calls[1]
+    # (1) GAN term back through the generated half of the discriminator's call to the generated image; the
+    #     discriminator's own gradients are not touched (param_grads off), its weights are still those of the forward
+    ctx_fake = disc._calls[0].group_view(1)
     ctx_fake.param_grads = False
     d_cat = disc.backward(ctx_fake, st.d_gan, need_dx=True)
     ops.concat_channels_bwd(d_cat, st.dX_unused, st.dgen_gan, rows, cx, cy)
-    ctx_fake.param_grads = True
 
     def generator_update():  # (3) dL/dgen = lambda * dMAE + dGAN
         ops.axpy(st.dgen, st.dgen_gan, 1.0)
@@ -157,7 +149,7 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
             gen_opt.apply_model(gen, 1.0)
 
     main, joined = torch.cuda.current_stream(), None
-    if overlap:
+    if overlap and not defer_updates:
         forked = torch.cuda.Event()
         forked.record(main)
         with torch.cuda.stream(st.side):
@@ -165,9 +157,8 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
             generator_update()
             joined = torch.cuda.Event()
             joined.record(st.side)
-    # (2) discriminator update
-    disc.backward_raw(st.d_real, 0, need_dx=False)
-    disc.backward_raw(st.d_fake, 1, need_dx=False)
+    # (2) discriminator update: one backward pass over both groups
+    disc.backward_raw(st.d_both, 0, need_dx=False)
     if not defer_updates:
         disc_opt.apply_model(disc, 1.0)
     if joined is not None:
@@ -203,7 +194,7 @@ def train_step(generator, discriminator, ce_opt, disc_opt, X, y, lambda_weight: 
         if st.graph is None:
             torch.cuda.synchronize()
             st.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st.graph):
+            with recording(st.graph):
                 _step_body(gen, disc, ce_opt, disc_opt, st, lambda_weight, overlap=True)
         st.graph.replay()
     c = lambda t: as_dtensor(t.view(()).clone())  # noqa: E731

@@ -367,6 +367,125 @@ def test_batchnorm(shape):
     close(db, db_o, what="bn dbeta")
 
 
+@pytest.mark.parametrize("shape,groups", [((6, 8, 8, 64), 2), ((4, 4, 4, 300), 2), ((12, 5, 3, 7), 3), ((8, 16, 16, 64), 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_groups_and_neighbouring_activations(shape, groups, dtype):
+    """BatchNorm over ``groups`` independent parts of the batch with (a) the LeakyReLU that follows it and (b) the
+    activation + bias gradient of the conv that feeds it folded into its launches, against the numpy restatement run
+    group by group with the activations as separate steps.  bf16: the same arithmetic on bf16-rounded inputs, compared
+    at bf16 resolution."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(131)
+    c = shape[-1]
+    rows = int(np.prod(shape[:-1]))
+    n = shape[0]
+    lp = dtype == torch.bfloat16
+    tol = 2.0 ** -7 if lp else RTOL
+
+    def q(a):  # what the kernels read
+        return dev(a, dtype).float().cpu().numpy().astype(np.float64) if lp else a
+
+    pre = rng.standard_normal(shape) * 2 + 1     # the producing conv's pre-activation
+    x = q(np_ops.act_fwd(pre, "lrelu", 0.2))            # ... its output, the layer's input
+    gamma, beta = rng.standard_normal(c), rng.standard_normal(c)
+    mm, mv = rng.standard_normal(c), rng.random(c) + 0.5
+    dy = q(rng.standard_normal(shape))
+    per = n // groups
+    unb = True
+    y_o, dx_o = np.empty(shape), np.empty(shape)
+    mean_o, inv_o = np.empty((groups, c)), np.empty((groups, c))
+    dg_o, db_o, dbias_o = np.zeros(c), np.zeros(c), np.zeros(c)
+    mm_o, mv_o = mm.copy(), mv.copy()
+    for g in range(groups):
+        sl = slice(g * per, (g + 1) * per)
+        bn, mean_o[g], var = np_ops.batchnorm_train(x[sl], gamma, beta)
+        inv_o[g] = 1 / np.sqrt(var + 1e-3)
+        mm_o, mv_o = np_ops.batchnorm_moving_update(mm_o, mv_o, mean_o[g], var, rows // groups, unbiased_var=unb)
+        y_o[sl] = np_ops.act_fwd(bn, "lrelu", 0.2)
+        gin = dy[sl] * np.where(y_o[sl] > 0, 1.0, 0.2)          # the following LeakyReLU's backward
+        dxg, dgg, dbg = np_ops.batchnorm_train_bwd(x[sl], gamma, gin)
+        dz = dxg * np.where(x[sl] > 0, 1.0, 0.2)                # the producing conv's activation backward
+        dx_o[sl] = dz
+        dg_o += dgg
+        db_o += dbg
+        dbias_o += dz.reshape(-1, c).sum(0)
+    ws = torch.empty(ops.batchnorm_workspace(rows, c, groups), dtype=torch.uint8, device="cuda")
+    xd, y = dev(x, dtype), torch.empty(shape, device="cuda", dtype=dtype)
+    sm, si = torch.empty(groups, c, device="cuda"), torch.empty(groups, c, device="cuda")
+    dmm, dmv = dev(mm), dev(mv)
+    ops.batchnorm_act_fwd_train(xd, dev(gamma), dev(beta), y, sm, si, dmm, dmv, rows, c, 1e-3, 0.99, unb, groups, "lrelu",
+                                0.2, ws)
+    close(y.float(), y_o, tol=tol, what="bn+act train")
+    close(sm, mean_o, what="bn group means")
+    close(si, inv_o, tol=2e-4, what="bn group invstd")
+    close(dmm, mm_o, what="moving mean after all groups")
+    close(dmv, mv_o, what="moving var after all groups")
+    dx = torch.empty(shape, device="cuda", dtype=dtype)
+    dg, db, dbias = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.full((c,), 2.0, device="cuda")
+    # the oracle's sign tests use its own y; where the device's rounded y disagrees in sign the element is a tie
+    ops.batchnorm_act_bwd(xd, dev(dy, dtype), y, "lrelu", 0.2, dev(gamma), sm, si, dx, dg, db, True, "lrelu", 0.2, dbias,
+                          True, rows, c, groups, ws)
+    gtol = 2.0 ** -5 if lp else 2e-4
+    close(dx.float(), dx_o, tol=gtol, what="bn+act dx")
+    close(dg, dg_o, tol=gtol, what="bn+act dgamma")
+    close(db, db_o, tol=gtol, what="bn+act dbeta")
+    close(dbias, 2.0 + dbias_o, tol=gtol, what="producer's bias gradient")
+    yi = torch.empty(shape, device="cuda", dtype=dtype)
+    ops.batchnorm_act_fwd_infer(xd, dev(gamma), dev(beta), dev(mm), dev(mv), yi, rows, c, 1e-3, "lrelu", 0.2)
+    close(yi.float(), np_ops.act_fwd(np_ops.batchnorm_infer(x, gamma, beta, mm, mv), "lrelu", 0.2), tol=tol,
+          what="bn+act infer")
+
+
+def test_deferred_reductions_equal_immediate_ones():
+    """Kernel / bias gradient slab sums queued between begin and flush and run as one launch give the per-call
+    reductions' values; a dropped queue (flush(False)) launches nothing and later calls reduce at once again."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(132)
+    jobs = []
+    for (n, h, w, cin, k, s, pad, cout) in [(16, 16, 16, 64, 4, 2, "same", 64), (16, 4, 4, 128, 4, 1, "valid", 200),
+                                             (16, 8, 8, 64, 4, 2, "same", 128)]:
+        g = ops.conv_geom(n, h, w, cin, k, k, s, s, pad, cout)
+        x = dev(rng.standard_normal((n, h, w, cin)))
+        dz = dev(rng.standard_normal((n, g.Ho, g.Wo, cout)))
+        jobs.append((g, x, dz, (k, k, cin, cout)))
+    def run(deferred):
+        outs = []
+        if deferred:
+            ops.deferred_reduce_begin()
+        for g, x, dz, wshape in jobs:
+            dw = torch.full(wshape, 0.5, device="cuda")
+            db = torch.full((wshape[-1],), 0.25, device="cuda")
+            ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 256), dtype=torch.uint8, device="cuda")  # one per job
+            ops.conv2d_wgrad(g, x, dz, dw, True, ws)
+            rows = dz.numel() // wshape[-1]
+            ws2 = torch.empty(ops.colreduce_workspace(rows, wshape[-1]), dtype=torch.uint8, device="cuda")
+            ops.bias_grad(dz, db, True, rows, wshape[-1], ws2)
+            outs.append((dw, db, ws, ws2))
+        if deferred:
+            before = [o[0].clone() for o in outs]
+            ops.deferred_reduce_flush(True)
+            assert any(not torch.equal(b, o[0]) for b, o in zip(before, outs))  # the sums ran in the flush, not before
+        return outs
+    imm, dfr = run(False), run(True)
+    for (a, b, _, _), (c2, d, _, _) in zip(imm, dfr):
+        assert torch.equal(a, c2)      # the same summation order as the per-call kernel-gradient reduction
+        assert rel_close(d, b, 1e-6)   # bias sums: the same terms, associated differently from the per-call fold
+    ops.deferred_reduce_begin()
+    g, x, dz, wshape = jobs[0]
+    dw = torch.zeros(wshape, device="cuda")
+    ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 256), dtype=torch.uint8, device="cuda")
+    ops.conv2d_wgrad(g, x, dz, dw, False, ws)
+    ops.deferred_reduce_flush(False)
+    torch.cuda.synchronize()
+    dw2 = torch.zeros(wshape, device="cuda")
+    ops.conv2d_wgrad(g, x, dz, dw2, False, ws)
+    assert torch.equal(dw2, imm[0][0] - 0.5) or rel_close(dw2, imm[0][0] - 0.5)
+
+
+def rel_close(a, b, tol=1e-5):
+    return float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
 def test_concat_and_misc():
     from spectrum_vae_amd import ops
     rng = np.random.default_rng(14)
