@@ -159,6 +159,10 @@ __device__ __forceinline__ float u01(uint64_t seed, uint64_t ctr) {
     return (float)(mix64(seed ^ mix64(ctr)) >> 40) * (1.0f / 16777216.0f);
 }
 
+// conv_small.hip: input gradient / transposed forward with an image side of <= 4 channels (1: geometry not covered)
+int launch_convt_small(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                       float alpha, hipStream_t st);
+
 // Deferred reductions (conv_direct.hip): true when the "dst (+)= sum of `slabs` rows of n floats at src" step was queued
 // for the flush instead of being launched now.
 bool defer_reduce(const float* src, float* dst, int64_t n, int slabs, int accumulate);

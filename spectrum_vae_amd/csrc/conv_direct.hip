@@ -346,6 +346,10 @@ int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, con
 
 int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx,
                         int act, float alpha, hipStream_t st, void* ws, size_t ws_bytes) {
+    {  // image side of <= 4 channels: LDS-tiled kernel (as a GEMM of <= 4 columns the gathers are re-read per pixel)
+        const int rc = launch_convt_small(g, dz, w, bias, dx, act, alpha, st);
+        if (rc <= 0) return rc;
+    }
     if (conv_gemm_worthwhile(g, 1)) return launch_conv_gemm_dgrad(g, dz, w, bias, dx, act, alpha, ws, ws_bytes, st);
     const int64_t npix = (int64_t)g.N * (g.H / g.up_h) * (g.W / g.up_w);
     const int cit = g.Cin >= 16 ? 16 : (g.Cin > 4 ? 8 : 4);

@@ -1,0 +1,139 @@
+// Input gradient of a strided conv / forward of a Conv2DTranspose whose image side has at most 4 channels: the output
+// layers of the context encoder (context_encoder.py:296-304, Conv2DTranspose(3, 4x4, stride 2, same, tanh)) and of the
+// U-Net (unet.py:104-112, Conv2DTranspose(3, 2x2, stride 2)).
+//
+// As an implicit GEMM these layers have 3 columns: every output pixel gathers its taps x channels row again (1 KB per
+// pixel, 1 GB of L2 reads per launch at batch 1024 for 67 MB of input).  Here a workgroup stages a 16 x 16 tile of the
+// channel-rich (small-extent) tensor with its halo into LDS once, 16 channels at a time; a thread owns one of its pixels
+// and computes the S x S image pixels above it for all (<= 4) image channels.  The filter index depends on loop counters
+// only, so the filters arrive through scalar loads (uniform across the wave) and cost no LDS or vector-memory traffic.
+//
+// Geometry follows sv_conv_geom of the MIRRORED conv: (H, W, Cin) is the image side (Cin <= 4), (Ho, Wo, Cout) the
+// channel-rich side, filters [KH][KW][Cin][Cout].  Covered: KH = KW = K, SH = SW = S, K a multiple of S, H = S Ho,
+// W = S Wo, pad_t = pad_l = (K - S) / 2, Cout a multiple of 4.
+#include "common.h"
+
+namespace sv {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kSmallCib = 16;           // channels staged per pass (small: several workgroups per CU hide the scalar loads)
+constexpr int kSmallPitch = kSmallCib + 4;  // floats per staged pixel: 16-byte reads of 16 neighbouring pixels hit 64 banks
+
+template <int K, int S, int CB>
+__global__ __launch_bounds__(256) void convt_small_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int Hs, int Ws,
+                                                     int Cs, int act, float alpha, int tiles_w, int tiles_per_img) {
+    constexpr int Q = K / S, PT = (K - S) / 2, HB = Q - 1, HA = (S - 1 + PT) / S, WIN = HB + 1 + HA, TP = 16 + HB + HA;
+    extern __shared__ float4 smem4[];
+    float* sm = reinterpret_cast<float*>(smem4);
+    const int n = blockIdx.x / tiles_per_img, t = blockIdx.x - n * tiles_per_img;
+    const int th0 = (t / tiles_w) * 16, tw0 = (t % tiles_w) * 16;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    // running sums as (even channels, odd channels) pairs: one packed FMA takes two consecutive channels of the staged
+    // pixel and two consecutive filter values (an SGPR pair straight from the scalar load)
+    v2f acc[S][S][CB];
+#pragma unroll
+    for (int r = 0; r < S; ++r)
+#pragma unroll
+        for (int c = 0; c < S; ++c)
+#pragma unroll
+            for (int co = 0; co < CB; ++co) acc[r][c][co] = v2f{0.f, 0.f};
+    for (int c0 = 0; c0 < Cs; c0 += kSmallCib) {
+        const int cq = (Cs - c0 < kSmallCib ? Cs - c0 : kSmallCib) >> 2;  // 16-byte pieces in this pass
+        __syncthreads();  // the previous pass has been consumed
+        for (int u = threadIdx.x; u < TP * TP * (kSmallCib / 4); u += 256) {
+            const int p = u / (kSmallCib / 4), v = u - p * (kSmallCib / 4);
+            const int ph = p / TP, pw = p - ph * TP;
+            const int ih = th0 + ph - HB, iw = tw0 + pw - HB;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < cq && ih >= 0 && ih < Hs && iw >= 0 && iw < Ws)
+                val = *reinterpret_cast<const float4*>(x + (((int64_t)n * Hs + ih) * Ws + iw) * Cs + c0 + 4 * v);
+            *reinterpret_cast<float4*>(sm + p * kSmallPitch + 4 * v) = val;
+        }
+        __syncthreads();
+        for (int v = 0; v < cq; ++v) {
+            float4 xq[WIN][WIN];
+#pragma unroll
+            for (int dh = 0; dh < WIN; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < WIN; ++dw)
+                    xq[dh][dw] = *reinterpret_cast<const float4*>(sm + ((ty + dh) * TP + tx + dw) * kSmallPitch + 4 * v);
+            const float* wv = w + c0 + 4 * v;  // wave-uniform: the filter reads below are scalar loads
+#pragma unroll
+            for (int r = 0; r < S; ++r)
+#pragma unroll
+                for (int jh = 0; jh < Q; ++jh)
+#pragma unroll
+                    for (int c = 0; c < S; ++c)
+#pragma unroll
+                        for (int jw = 0; jw < Q; ++jw) {
+                            // image row S m + r takes tap a = (r + PT) % S + S jh from channel-rich row m + (r + PT) / S - jh
+                            const int a = (r + PT) % S + S * jh, b = (c + PT) % S + S * jw;
+                            const float4 xv = xq[HB + (r + PT) / S - jh][HB + (c + PT) / S - jw];
+                            const v2f xlo{xv.x, xv.y}, xhi{xv.z, xv.w};
+#pragma unroll
+                            for (int co = 0; co < CB; ++co) {
+                                const float* wp = wv + (int64_t)((a * K + b) * CB + co) * Cs;
+                                const v2f wlo{wp[0], wp[1]}, whi{wp[2], wp[3]};
+                                acc[r][c][co] = __builtin_elementwise_fma(xlo, wlo, acc[r][c][co]);
+                                acc[r][c][co] = __builtin_elementwise_fma(xhi, whi, acc[r][c][co]);
+                            }
+                        }
+        }
+    }
+    const int m = th0 + ty, q = tw0 + tx;
+    if (m >= Hs || q >= Ws) return;
+    const int Hb = Hs * S, Wb = Ws * S;
+#pragma unroll
+    for (int r = 0; r < S; ++r)
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+            float* o = y + (((int64_t)n * Hb + S * m + r) * Wb + S * q + c) * CB;
+#pragma unroll
+            for (int co = 0; co < CB; ++co) {
+                const float z = (acc[r][c][co].x + acc[r][c][co].y) + (bias != nullptr ? bias[co] : 0.f);
+                o[co] = act_apply(z, act, alpha);
+            }
+        }
+}
+
+template <int K, int S>
+static int launch_small_ks(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                           float alpha, hipStream_t st) {
+    constexpr int Q = K / S, PT = (K - S) / 2, TP = 16 + (Q - 1) + (S - 1 + PT) / S;
+    const int tiles_h = (int)ceil_div(g.Ho, 16), tiles_w = (int)ceil_div(g.Wo, 16);
+    const int64_t blocks = (int64_t)g.N * tiles_h * tiles_w;
+    if (blocks > (1ll << 30)) return 1;
+    const size_t lds = (size_t)TP * TP * kSmallPitch * sizeof(float);
+    const dim3 grid((unsigned)blocks), block(256);
+    switch (g.Cin) {
+        case 1: hipLaunchKernelGGL((convt_small_k<K, S, 1>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
+        case 2: hipLaunchKernelGGL((convt_small_k<K, S, 2>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
+        case 3: hipLaunchKernelGGL((convt_small_k<K, S, 3>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
+        default: hipLaunchKernelGGL((convt_small_k<K, S, 4>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
+    }
+    return check_launch("convt_small");
+}
+
+bool convt_small_ok(const sv_conv_geom& g) {
+    if (g.Cin < 1 || g.Cin > 4 || g.Cout < 16 || (g.Cout & 3)) return false;
+    if (g.KH != g.KW || g.SH != g.SW || g.up_h != 1 || g.up_w != 1) return false;
+    if (!((g.KH == 4 && g.SH == 2) || (g.KH == 2 && g.SH == 2) || (g.KH == 4 && g.SH == 1))) return false;
+    if (g.H != g.Ho * g.SH || g.W != g.Wo * g.SW) return false;
+    const int pt = (g.KH - g.SH) / 2;
+    return g.pad_t == pt && g.pad_l == pt;
+}
+
+// Returns 1 when the geometry is not covered (the caller takes its general path), 0 on success, < 0 on error.
+// x: [N][Ho][Wo][Cout] (the channel-rich tensor), y: [N][H][W][Cin].
+int launch_convt_small(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                       float alpha, hipStream_t st) {
+    if (!convt_small_ok(g)) return 1;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return 1;
+    if (g.KH == 4 && g.SH == 1) return launch_small_ks<4, 1>(g, x, w, bias, y, act, alpha, st);
+    if (g.KH == 4) return launch_small_ks<4, 2>(g, x, w, bias, y, act, alpha, st);
+    return launch_small_ks<2, 2>(g, x, w, bias, y, act, alpha, st);
+}
+
+}  // namespace sv

@@ -2,6 +2,8 @@
 // batching helpers.  All f32, NHWC, grid-stride with 16-byte accesses where the channel count allows.
 #include <stdarg.h>
 
+#include <initializer_list>
+
 #include "common.h"
 
 namespace sv {
@@ -29,16 +31,102 @@ __global__ void act_fwd_k(const T* __restrict__ x, T* __restrict__ y, int64_t n,
         y[i] = (T)act_apply((float)x[i], act, alpha);
 }
 
+// ---- vectorised row sweeps (the column-reduction kernels below when C is a multiple of a 16-byte piece) -------------
+// A thread owns VN = 16 / sizeof(T) consecutive channels - one 16-byte piece per row - of every rif-th row of the block's
+// row range (rif = 256 / (C / VN) rows in flight); NQ running sums per channel are folded over the row phases through
+// LDS (NQ * 256 * VN floats) and leave as part[(block * NQ + q) * C + c].  Two bytes per lane (bf16 through the scalar
+// paths) leave most of a wave's load width unused; this form moves 16 bytes per lane for both storage types.
+template <typename T>
+__device__ __forceinline__ void ld16(const T* __restrict__ p, float (&v)[16 / sizeof(T)]) {
+    const Pack16<T> q = *reinterpret_cast<const Pack16<T>*>(p);
+#pragma unroll
+    for (int e = 0; e < Pack16<T>::N; ++e) v[e] = (float)q.v[e];
+}
+
+template <typename T, int NQ, typename Op>
+__device__ __forceinline__ void row_sweep_vec(Op& op, float* __restrict__ part, int64_t r0, int64_t r1, int C,
+                                              float* __restrict__ sm) {
+    constexpr int VN = 16 / sizeof(T);
+    const int cgs = C / VN, rif = blockDim.x / cgs;
+    const int cg = threadIdx.x % cgs, rr = threadIdx.x / cgs;
+    float acc[NQ][VN];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[q][e] = 0.f;
+    if (rr < rif) {
+        op.begin(cg * VN);
+#pragma unroll 2
+        for (int64_t r = r0 + rr; r < r1; r += rif) op.row(r * C + cg * VN, acc);
+    }
+    if (part == nullptr) return;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) sm[((int64_t)q * blockDim.x + threadIdx.x) * VN + e] = acc[q][e];  // 0 for idle lanes
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / VN, e = c - g * VN;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float t = 0.f;
+            for (int k = 0; k < rif; ++k) t += sm[((int64_t)q * blockDim.x + k * cgs + g) * VN + e];
+            part[((int64_t)blockIdx.x * NQ + q) * C + c] = t;
+        }
+    }
+}
+
+template <typename T>
+struct ActBwdOp {
+    static constexpr int VN = 16 / sizeof(T);
+    const T* dy;
+    const T* y;
+    T* dz;
+    int act;
+    float alpha;
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void row(int64_t i, float (&acc)[1][VN]) {
+        float g[VN], yv[VN];
+        ld16(dy + i, g);
+        ld16(y + i, yv);
+        Pack16<T> o;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            o.v[e] = (T)(g[e] * act_grad_from_y(yv[e], act, alpha));
+            acc[0][e] += (float)o.v[e];
+        }
+        *reinterpret_cast<Pack16<T>*>(dz + i) = o;
+    }
+};
+
+template <typename T>
+struct ColsumOp {
+    static constexpr int VN = 16 / sizeof(T);
+    const T* z;
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void row(int64_t i, float (&acc)[1][VN]) {
+        float v[VN];
+        ld16(z + i, v);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[0][e] += v[e];
+    }
+};
+
 // dz = dy * act'(y); optional per-channel column sums of dz into part[block][C] (C <= 1024).
 // Rows are dealt to blocks in contiguous chunks; thread t of a block owns channel (t % C) of rows t/C, ...
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_k(const T* __restrict__ dy, const T* __restrict__ y,
                                                   T* __restrict__ dz, float* __restrict__ part, int64_t rows,
-                                                  int C, int act, float alpha, int64_t rows_per_block) {
+                                                  int C, int act, float alpha, int64_t rows_per_block, int vec) {
     extern __shared__ float sm[];  // [rows_in_flight][C] partial sums when part != nullptr
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
+    if (vec) {
+        ActBwdOp<T> op{dy, y, dz, act, alpha};
+        row_sweep_vec<T, 1>(op, part, r0, r1, C, sm);
+        return;
+    }
     const int rif = blockDim.x / C > 0 ? blockDim.x / C : 1;  // rows handled per sweep (C <= 256) else 1
     if (C <= (int)blockDim.x) {
         const int c = threadIdx.x % C;
@@ -80,11 +168,16 @@ __global__ __launch_bounds__(256) void act_bwd_k(const T* __restrict__ dy, const
 // column sums only
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ z, float* __restrict__ part, int64_t rows,
-                                                 int C, int64_t rows_per_block) {
+                                                 int C, int64_t rows_per_block, int vec) {
     extern __shared__ float sm[];
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
+    if (vec) {
+        ColsumOp<T> op{z};
+        row_sweep_vec<T, 1>(op, part, r0, r1, C, sm);
+        return;
+    }
     if (C <= (int)blockDim.x) {
         const int rif = blockDim.x / C;
         const int c = threadIdx.x % C, rr = threadIdx.x / C;
@@ -255,12 +348,36 @@ __global__ void upsample_bwd_k(const float* __restrict__ dy, float* __restrict__
 // pass 1: per-block partial (sum, sum of squares about a per-channel pivot) -> part[block][2][C].
 // The pivot (first row of the tensor) keeps the one-pass variance well conditioned.
 template <typename T>
+struct BnStatsOp {
+    static constexpr int VN = 16 / sizeof(T);
+    const T* x;
+    float piv[VN];
+    __device__ __forceinline__ void begin(int c0) { ld16(x + c0, piv); }
+    __device__ __forceinline__ void row(int64_t i, float (&acc)[2][VN]) {
+        float v[VN];
+        ld16(x + i, v);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            const float d = v[e] - piv[e];
+            acc[0][e] += d;
+            acc[1][e] = fmaf(d, d, acc[1][e]);
+        }
+    }
+};
+
+template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_k(const T* __restrict__ x, float* __restrict__ part,
-                                                   int64_t rows, int C, int64_t rows_per_block) {
+                                                   int64_t rows, int C, int64_t rows_per_block, int vec) {
     extern __shared__ float sm[];  // 2 * blockDim.x
     // blockIdx.y = statistics group: `rows` consecutive rows with statistics (and a pivot row) of their own
     x += (int64_t)blockIdx.y * rows * C;
     part += (int64_t)blockIdx.y * gridDim.x * 2 * C;
+    if (vec) {
+        const int64_t v0 = (int64_t)blockIdx.x * rows_per_block;
+        BnStatsOp<T> op{x};
+        row_sweep_vec<T, 2>(op, part, v0, v0 + rows_per_block < rows ? v0 + rows_per_block : rows, C, sm);
+        return;
+    }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
@@ -341,7 +458,27 @@ template <typename T>
 __global__ void bn_apply_k(const T* __restrict__ x, const float* __restrict__ gamma,
                            const float* __restrict__ beta, const float* __restrict__ mean,
                            const float* __restrict__ var_or_invstd, int is_var, float eps, T* __restrict__ y,
-                           int64_t total, int C, int act, float alpha, int64_t group_elems) {
+                           int64_t total, int C, int act, float alpha, int64_t group_elems, int vec) {
+    if (vec) {  // 16-byte pieces (C is a multiple of the piece, so a piece never straddles two rows)
+        constexpr int VN = 16 / sizeof(T);
+        const int64_t nv = total / VN;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t b = i * VN;
+            const int c0 = (int)(b % C);
+            const int s0 = group_elems >= total ? c0 : (int)(b / group_elems) * C + c0;
+            float v[VN];
+            ld16(x + b, v);
+            Pack16<T> o;
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                const float inv = is_var ? rsqrtf(var_or_invstd[s0 + e] + eps) : var_or_invstd[s0 + e];
+                const T t = (T)((v[e] - mean[s0 + e]) * inv * gamma[c0 + e] + beta[c0 + e]);
+                o.v[e] = act == SV_ACT_NONE ? t : (T)act_apply((float)t, act, alpha);
+            }
+            *reinterpret_cast<Pack16<T>*>(y + b) = o;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int sc = group_elems >= total ? c : (int)(i / group_elems) * C + c;  // the row's statistics group
@@ -361,13 +498,50 @@ __device__ __forceinline__ float bn_incoming_grad(const T* __restrict__ dy, cons
     return (float)(T)(g * act_grad_from_y((float)yact[i], act_out, alpha_out));
 }
 
+template <typename T>
+struct BnBwdStatsOp {
+    static constexpr int VN = 16 / sizeof(T);
+    const T* x;
+    const T* dy;
+    const T* yact;
+    const float* mean;
+    const float* invstd;
+    int act_out;
+    float alpha_out;
+    float mu[VN], inv[VN];
+    __device__ __forceinline__ void begin(int c0) {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            mu[e] = mean[c0 + e];
+            inv[e] = invstd[c0 + e];
+        }
+    }
+    __device__ __forceinline__ void row(int64_t i, float (&acc)[2][VN]) {
+        float xv[VN], g[VN];
+        ld16(x + i, xv);
+        ld16(dy + i, g);
+        if (yact != nullptr) {
+            float yv[VN];
+            ld16(yact + i, yv);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) g[e] = (float)(T)(g[e] * act_grad_from_y(yv[e], act_out, alpha_out));
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            acc[0][e] += g[e];
+            acc[1][e] = fmaf(g[e], (xv[e] - mu[e]) * inv[e], acc[1][e]);
+        }
+    }
+};
+
 // backward pass 1: per-block partial (sum dy, sum dy*xhat) -> part[block][2][C]
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_stats_k(const T* __restrict__ x, const T* __restrict__ dy,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float* __restrict__ part,
                                                        int64_t rows, int C, int64_t rows_per_block,
-                                                       const T* __restrict__ yact, int act_out, float alpha_out) {
+                                                       const T* __restrict__ yact, int act_out, float alpha_out,
+                                                       int vec) {
     extern __shared__ float sm[];
     {  // blockIdx.y = statistics group
         const int64_t go = (int64_t)blockIdx.y * rows * C;
@@ -377,6 +551,12 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_k(const T* __restrict__ x, c
         mean += blockIdx.y * C;
         invstd += blockIdx.y * C;
         part += (int64_t)blockIdx.y * gridDim.x * 2 * C;
+    }
+    if (vec) {
+        const int64_t v0 = (int64_t)blockIdx.x * rows_per_block;
+        BnBwdStatsOp<T> op{x, dy, yact, mean, invstd, act_out, alpha_out};
+        row_sweep_vec<T, 2>(op, part, v0, v0 + rows_per_block < rows ? v0 + rows_per_block : rows, C, sm);
+        return;
     }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
@@ -445,9 +625,31 @@ template <typename T>
 __global__ void bn_bwd_apply_k(const T* __restrict__ x, const T* __restrict__ dy,
                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ stats2,
-                               T* __restrict__ dx, int64_t rows, int C, int groups) {
+                               T* __restrict__ dx, int64_t rows, int C, int groups, int vec) {
     const int64_t total = rows * C * groups, group_elems = rows * C;  // rows: per statistics group
     const float invm = 1.f / (float)rows;
+    if (vec) {
+        constexpr int VN = 16 / sizeof(T);
+        const int64_t nv = total / VN;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t b = i * VN;
+            const int c0 = (int)(b % C);
+            const int g = groups == 1 ? 0 : (int)(b / group_elems);
+            float xv[VN], gv[VN];
+            ld16(x + b, xv);
+            ld16(dy + b, gv);
+            Pack16<T> o;
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                const float inv = invstd[g * C + c0 + e];
+                const float xh = (xv[e] - mean[g * C + c0 + e]) * inv;
+                o.v[e] = (T)(gamma[c0 + e] * inv *
+                             (gv[e] - invm * (stats2[2 * g * C + c0 + e] + xh * stats2[(2 * g + 1) * C + c0 + e])));
+            }
+            *reinterpret_cast<Pack16<T>*>(dx + b) = o;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int g = groups == 1 ? 0 : (int)(i / group_elems);
@@ -456,6 +658,56 @@ __global__ void bn_bwd_apply_k(const T* __restrict__ x, const T* __restrict__ dy
         dx[i] = (T)(gamma[c] * inv * ((float)dy[i] - invm * (stats2[2 * g * C + c] + xh * stats2[(2 * g + 1) * C + c])));
     }
 }
+
+template <typename T>
+struct BnBwdApplyOp {
+    static constexpr int VN = 16 / sizeof(T);
+    const T* x;
+    const T* dy;
+    const T* yact;
+    T* dx;
+    const float* gamma;
+    const float* mean;
+    const float* invstd;
+    const float* stats2;
+    int act_out;
+    float alpha_out;
+    int act_in;
+    float alpha_in, invm;
+    int C;
+    float mu[VN], inv[VN], ga[VN], s1[VN], s2[VN];
+    __device__ __forceinline__ void begin(int c0) {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            mu[e] = mean[c0 + e];
+            inv[e] = invstd[c0 + e];
+            ga[e] = gamma[c0 + e];
+            s1[e] = stats2[c0 + e];
+            s2[e] = stats2[C + c0 + e];
+        }
+    }
+    __device__ __forceinline__ void row(int64_t i, float (&acc)[1][VN]) {
+        float xv[VN], g[VN];
+        ld16(x + i, xv);
+        ld16(dy + i, g);
+        if (yact != nullptr) {
+            float yv[VN];
+            ld16(yact + i, yv);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) g[e] = (float)(T)(g[e] * act_grad_from_y(yv[e], act_out, alpha_out));
+        }
+        Pack16<T> o;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            const float xh = (xv[e] - mu[e]) * inv[e];
+            T d = (T)(ga[e] * inv[e] * (g[e] - invm * (s1[e] + xh * s2[e])));
+            if (act_in != SV_ACT_NONE) d = (T)((float)d * act_grad_from_y(xv[e], act_in, alpha_in));
+            o.v[e] = d;
+            acc[0][e] += (float)d;
+        }
+        *reinterpret_cast<Pack16<T>*>(dx + i) = o;
+    }
+};
 
 // The same with the neighbouring activations folded in, one workgroup per block of rows (the layout of the statistics
 // pass).  yact: output of the activation layer that followed (its derivative scales the incoming gradient).  act_in: the
@@ -469,7 +721,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ stats2, T* __restrict__ dx,
                                                             int act_in, float alpha_in, float* __restrict__ partb,
-                                                            int64_t rows, int C, int64_t rows_per_block) {
+                                                            int64_t rows, int C, int64_t rows_per_block, int vec) {
     extern __shared__ float sm[];
     {  // blockIdx.y = statistics group
         const int64_t go = (int64_t)blockIdx.y * rows * C;
@@ -486,6 +738,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     const float invm = 1.f / (float)rows;
+    if (vec) {
+        BnBwdApplyOp<T> op{x, dy, yact, dx, gamma, mean, invstd, stats2, act_out, alpha_out, act_in, alpha_in, invm, C};
+        row_sweep_vec<T, 1>(op, partb, r0, r1, C, sm);
+        return;
+    }
     auto one = [&](int64_t i, float mu, float inv, float ga, float s1, float s2) -> float {
         const float xv = (float)x[i];
         const float g = bn_incoming_grad(dy, yact, i, act_out, alpha_out);
@@ -708,6 +965,19 @@ ColPlan col_plan(int64_t rows, int C) {
 }
 
 constexpr int kMaxC = 4096;
+
+// Whether the vectorised row sweep applies: C a multiple of the 16-byte piece, at most 256 pieces per row, every tensor
+// 16-byte aligned.  *lds = dynamic LDS bytes of the launch (the larger of the scalar and the vector form's needs).
+static int row_vec(int dtype, int C, int nq, size_t scalar_lds, size_t* lds, std::initializer_list<const void*> ptrs) {
+    const int vn = dtype == SV_F32 ? 4 : 8;
+    *lds = scalar_lds;
+    if (C % vn != 0 || C / vn > 256) return 0;
+    for (const void* p : ptrs)
+        if (p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15) != 0) return 0;
+    const size_t need = (size_t)nq * 256 * vn * sizeof(float);
+    if (need > *lds) *lds = need;
+    return 1;
+}
 // Workspace layout of a column reduction: [nblocks][2][C] partial slabs followed by [2][C] folded sums.
 size_t col_ws_bytes(int64_t rows, int C) {
     ColPlan p = col_plan(rows, C);
@@ -762,8 +1032,10 @@ int sv_act_bwd(const void* dy, const void* y, void* dz, void* db, int db_accumul
         int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_act_bwd");
         if (rc) return rc;
     }
-    SV_WITH_T(dtype, hipLaunchKernelGGL(act_bwd_k<T>, dim3(p.nblocks), dim3(256), 256 * sizeof(float), to_stream(stream),
-                                        (const T*)dy, (const T*)y, (T*)dz, part, rows, C, act, alpha, p.rows_per_block););
+    size_t lds;
+    const int vec = row_vec(dtype, C, 1, 256 * sizeof(float), &lds, {dy, y, dz});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(act_bwd_k<T>, dim3(p.nblocks), dim3(256), lds, to_stream(stream), (const T*)dy,
+                                        (const T*)y, (T*)dz, part, rows, C, act, alpha, p.rows_per_block, vec););
     int rc = check_launch("sv_act_bwd");
     if (rc || db == nullptr) return rc;
     if (defer_reduce(part, (float*)db, C, p.nblocks, db_accumulate)) return SV_OK;
@@ -780,8 +1052,10 @@ int sv_bias_grad(const void* dz, void* db, int accumulate, int64_t rows, int C, 
     float *part = nullptr, *folded = nullptr;
     int rc = col_ws(workspace, workspace_bytes, rows, C, &part, &folded, "sv_bias_grad");
     if (rc) return rc;
-    SV_WITH_T(dtype, hipLaunchKernelGGL(colsum_k<T>, dim3(p.nblocks), dim3(256), 256 * sizeof(float), to_stream(stream),
-                                        (const T*)dz, part, rows, C, p.rows_per_block););
+    size_t lds;
+    const int vec = row_vec(dtype, C, 1, 256 * sizeof(float), &lds, {dz});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(colsum_k<T>, dim3(p.nblocks), dim3(256), lds, to_stream(stream), (const T*)dz, part,
+                                        rows, C, p.rows_per_block, vec););
     rc = check_launch("sv_bias_grad");
     if (rc) return rc;
     if (defer_reduce(part, (float*)db, C, p.nblocks, accumulate)) return SV_OK;
@@ -889,8 +1163,10 @@ int sv_batchnorm_act_fwd_train(const void* x, const float* gamma, const float* b
     int rc = bn_ws(workspace, workspace_bytes, rows_g, C, groups, &part, &folded, &partb, "sv_batchnorm_fwd_train");
     if (rc) return rc;
     hipStream_t st = to_stream(stream);
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_stats_k<T>, dim3(p.nblocks, groups), dim3(256), 512 * sizeof(float), st,
-                                        (const T*)x, part, rows_g, C, p.rows_per_block););
+    size_t lds;
+    const int vec = row_vec(dtype, C, 2, 512 * sizeof(float), &lds, {x});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_stats_k<T>, dim3(p.nblocks, groups), dim3(256), lds, st, (const T*)x, part, rows_g,
+                                        C, p.rows_per_block, vec););
     rc = check_launch("bn_stats");
     if (rc) return rc;
     SV_WITH_T(dtype, hipLaunchKernelGGL(bn_finalize_k<T>, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st, (const T*)x, part,
@@ -899,8 +1175,11 @@ int sv_batchnorm_act_fwd_train(const void* x, const float* gamma, const float* b
     rc = check_launch("bn_finalize");
     if (rc) return rc;
     const int64_t total = rows * C;
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, st, (const T*)x, gamma,
-                                        beta, save_mean, save_invstd, 0, eps, (T*)y, total, C, act, alpha, rows_g * C););
+    size_t unused;
+    const int vec_a = row_vec(dtype, C, 0, 0, &unused, {x, y});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total / 4 + 1, 256, 8192)), dim3(256), 0, st, (const T*)x,
+                                        gamma, beta, save_mean, save_invstd, 0, eps, (T*)y, total, C, act, alpha, rows_g * C,
+                                        vec_a););
     return check_launch("bn_apply");
 }
 
@@ -926,9 +1205,11 @@ int sv_batchnorm_act_fwd_infer(const void* x, const float* gamma, const float* b
     SV_REQUIRE(x && gamma && beta && moving_mean && moving_var && y && rows > 0 && C > 0,
                "sv_batchnorm_fwd_infer: bad arguments");
     const int64_t total = rows * C;
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total, 256, 8192)), dim3(256), 0, to_stream(stream),
+    size_t unused;
+    const int vec = row_vec(dtype, C, 0, 0, &unused, {x, y});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total / 4 + 1, 256, 8192)), dim3(256), 0, to_stream(stream),
                                         (const T*)x, gamma, beta, moving_mean, moving_var, 1, eps, (T*)y, total, C, act, alpha,
-                                        total););
+                                        total, vec););
     return check_launch("sv_batchnorm_fwd_infer");
 }
 
@@ -956,9 +1237,11 @@ int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int a
     int rc = bn_ws(workspace, workspace_bytes, rows_g, C, groups, &part, &stats2, &partb, "sv_batchnorm_bwd");
     if (rc) return rc;
     hipStream_t st = to_stream(stream);
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_stats_k<T>, dim3(p.nblocks, groups), dim3(256), 512 * sizeof(float), st,
-                                        (const T*)x, (const T*)dy, save_mean, save_invstd, part, rows_g, C, p.rows_per_block,
-                                        (const T*)y_act, act_out, alpha_out););
+    size_t lds;
+    const int vec = row_vec(dtype, C, 2, 512 * sizeof(float), &lds, {x, dy, y_act, dx});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_stats_k<T>, dim3(p.nblocks, groups), dim3(256), lds, st, (const T*)x,
+                                        (const T*)dy, save_mean, save_invstd, part, rows_g, C, p.rows_per_block,
+                                        (const T*)y_act, act_out, alpha_out, vec););
     rc = check_launch("bn_bwd_stats");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_fold_k, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
@@ -966,16 +1249,18 @@ int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int a
     rc = check_launch("bn_bwd_fold");
     if (rc) return rc;
     if (y_act == nullptr && act_in == SV_ACT_NONE && dbias_in == nullptr) {
-        SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_grid(rows * C, 256, 8192)), dim3(256), 0, st,
+        SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_grid(rows * C / 4 + 1, 256, 8192)), dim3(256), 0, st,
                                             (const T*)x, (const T*)dy, gamma, save_mean, save_invstd, stats2, (T*)dx, rows_g, C,
-                                            groups););
+                                            groups, vec););
         return check_launch("bn_bwd_apply");
     }
     const ColPlan pa = bn_apply_plan(rows_g, C);
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_rows_k<T>, dim3(pa.nblocks, groups), dim3(256), 256 * sizeof(float), st,
-                                        (const T*)x, (const T*)dy, (const T*)y_act, act_out, alpha_out, gamma, save_mean,
-                                        save_invstd, stats2, (T*)dx, act_in, alpha_in, dbias_in ? partb : nullptr, rows_g, C,
-                                        pa.rows_per_block););
+    size_t lds_a;
+    const int vec_a = row_vec(dtype, C, 1, 256 * sizeof(float), &lds_a, {x, dy, y_act, dx});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_rows_k<T>, dim3(pa.nblocks, groups), dim3(256), lds_a, st, (const T*)x,
+                                        (const T*)dy, (const T*)y_act, act_out, alpha_out, gamma, save_mean, save_invstd,
+                                        stats2, (T*)dx, act_in, alpha_in, dbias_in ? partb : nullptr, rows_g, C,
+                                        pa.rows_per_block, vec_a););
     rc = check_launch("bn_bwd_apply_rows");
     if (rc || dbias_in == nullptr) return rc;
     const int slabs = groups * pa.nblocks;

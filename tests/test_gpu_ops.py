@@ -95,6 +95,33 @@ def test_conv2d_transpose(case, ch):
     close(dw, dw_o, what="convT wgrad")
 
 
+@pytest.mark.parametrize("k,s", [(4, 2), (2, 2), (4, 1)])
+@pytest.mark.parametrize("cimg,crich,hs,ws", [(3, 64, 16, 16), (1, 16, 5, 40), (4, 40, 24, 9), (2, 128, 33, 17)])
+def test_small_image_channel_input_gradient(k, s, cimg, crich, hs, ws):
+    """The LDS-tiled kernel for an image side of <= 4 channels (output layers of the context encoder and the U-Net):
+    as the input gradient of the mirrored conv, and as a Conv2DTranspose forward with bias and tanh; extents that leave
+    tiles partly empty, channel counts that leave the last staging pass short."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(zlib.crc32(repr((k, s, cimg, crich, hs, ws)).encode()))
+    n = 2
+    H, W = hs * s, ws * s
+    g = ops.conv_geom(n, H, W, cimg, k, k, s, s, "same", crich)
+    assert (g.Ho, g.Wo) == (hs, ws)
+    x = rng.standard_normal((n, H, W, cimg))
+    w = rng.standard_normal((k, k, cimg, crich)) * 0.2
+    dz = rng.standard_normal((n, hs, ws, crich))
+    dx_o, _, _ = np_ops.conv2d_grads(x, w, dz, (s, s), "same")
+    dx = torch.full((n, H, W, cimg), 9.0, device="cuda")
+    ops.conv2d_dgrad(g, dev(dz), dev(w), dx)
+    close(dx, dx_o, what="input gradient")
+    if s > 1:  # the same launch as a transposed conv's forward, with its epilogue
+        b = rng.standard_normal(cimg)
+        gt = ops.deconv_geom(n, hs, ws, crich, k, k, s, s, "same", cimg)
+        y = torch.empty((n, H, W, cimg), device="cuda")
+        ops.conv2d_transpose_fwd(gt, dev(dz), dev(w), dev(b), y, "tanh", 1.0)
+        close(y, np.tanh(np_ops.conv2d_transpose(dz, w, b, (s, s), "same")), what="transposed forward")
+
+
 @pytest.mark.parametrize("cfg", [
     # (kh, kw, s, padding, H, W, cin, cout, n): few result tiles, reductions of hundreds to thousands of terms
     (4, 4, 2, "same", 8, 8, 128, 96, 2), (4, 4, 1, "valid", 4, 4, 128, 200, 5), (4, 4, 2, "same", 4, 4, 256, 64, 3),

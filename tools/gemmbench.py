@@ -26,7 +26,7 @@ GEOMS = {
     "ce.enc4": ("conv", 4, 4, 256, 4, 2, "same", 512), "ce.bottleneck": ("conv", 4, 4, 128, 4, 1, "valid", 1000),
     "ce.dec1": ("convT", 1, 1, 1000, 4, 1, "valid", 512), "ce.dec2": ("convT", 4, 4, 512, 4, 2, "same", 256),
     "ce.dec3": ("convT", 8, 8, 256, 4, 2, "same", 128), "ce.dec4": ("convT", 16, 16, 128, 4, 2, "same", 64),
-    "ce.out": ("convT", 32, 32, 64, 4, 1, "same", 3),
+    "ce.out": ("convT", 32, 32, 64, 4, 1, "same", 3), "ce.out_s2": ("convT", 16, 16, 64, 4, 2, "same", 3),
     "disc.c2": ("conv", 16, 16, 64, 4, 2, "same", 128), "disc.head": ("conv", 4, 4, 256, 4, 1, "valid", 1),
 }
 
