@@ -162,6 +162,8 @@ __device__ __forceinline__ float u01(uint64_t seed, uint64_t ctr) {
 // conv_small.hip: input gradient / transposed forward with an image side of <= 4 channels (1: geometry not covered)
 int launch_convt_small(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
                        float alpha, hipStream_t st);
+int launch_convt_small_bf16(const sv_conv_geom& g, const void* x, const void* w, const float* bias, void* y, int act,
+                            float alpha, hipStream_t st);
 
 // Deferred reductions (conv_direct.hip): true when the "dst (+)= sum of `slabs` rows of n floats at src" step was queued
 // for the flush instead of being launched now.

@@ -423,6 +423,10 @@ int launch_fwd_bf16(const sv_conv_geom& g, const void* x, const void* w, const f
 
 int launch_dgrad_bf16(const sv_conv_geom& g, const void* dz, const void* w, const float* bias, void* dx, int act,
                       float alpha, hipStream_t st, void* ws, size_t ws_bytes) {
+    {
+        const int rc = launch_convt_small_bf16(g, dz, w, bias, dx, act, alpha, st);
+        if (rc <= 0) return rc;
+    }
     if (conv_gemm_bf16_ok(g, 1))
         return launch_conv_gemm_bf16_dgrad(g, dz, w, bias, dx, act, alpha, ws, ws_bytes, st);
     const int64_t npix = (int64_t)g.N * (g.H / g.up_h) * (g.W / g.up_w);

@@ -11,6 +11,8 @@
 // Geometry follows sv_conv_geom of the MIRRORED conv: (H, W, Cin) is the image side (Cin <= 4), (Ho, Wo, Cout) the
 // channel-rich side, filters [KH][KW][Cin][Cout].  Covered: KH = KW = K, SH = SW = S, K a multiple of S, H = S Ho,
 // W = S Wo, pad_t = pad_l = (K - S) / 2, Cout a multiple of 4.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace sv {
@@ -20,10 +22,25 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kSmallCib = 16;           // channels staged per pass (small: several workgroups per CU hide the scalar loads)
 constexpr int kSmallPitch = kSmallCib + 4;  // floats per staged pixel: 16-byte reads of 16 neighbouring pixels hit 64 banks
 
-template <int K, int S, int CB>
-__global__ __launch_bounds__(256) void convt_small_k(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ y, int Hs, int Ws,
+// Four consecutive filter values at a wave-uniform address, as two pairs.  bf16: read as two dwords (sub-dword reads
+// would leave the scalar path) and widened with shifts / masks, which stay on the scalar unit for uniform values.
+__device__ __forceinline__ void load_w4(const float* __restrict__ p, v2f& lo, v2f& hi) {
+    lo = v2f{p[0], p[1]};
+    hi = v2f{p[2], p[3]};
+}
+__device__ __forceinline__ void load_w4(const __bf16* __restrict__ p, v2f& lo, v2f& hi) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    const uint32_t a = q[0], b = q[1];
+    lo = v2f{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u)};
+    hi = v2f{__builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xffff0000u)};
+}
+
+// T: storage type of x, w and y (float or bf16); the staged tile, the sums and the bias are f32.
+template <int K, int S, int CB, typename T>
+__global__ __launch_bounds__(256) void convt_small_k(const T* __restrict__ x, const T* __restrict__ w,
+                                                     const float* __restrict__ bias, T* __restrict__ y, int Hs, int Ws,
                                                      int Cs, int act, float alpha, int tiles_w, int tiles_per_img) {
+    constexpr int VN = 16 / sizeof(T);  // channels per 16-byte piece of x
     constexpr int Q = K / S, PT = (K - S) / 2, HB = Q - 1, HA = (S - 1 + PT) / S, WIN = HB + 1 + HA, TP = 16 + HB + HA;
     extern __shared__ float4 smem4[];
     float* sm = reinterpret_cast<float*>(smem4);
@@ -40,16 +57,22 @@ __global__ __launch_bounds__(256) void convt_small_k(const float* __restrict__ x
 #pragma unroll
             for (int co = 0; co < CB; ++co) acc[r][c][co] = v2f{0.f, 0.f};
     for (int c0 = 0; c0 < Cs; c0 += kSmallCib) {
-        const int cq = (Cs - c0 < kSmallCib ? Cs - c0 : kSmallCib) >> 2;  // 16-byte pieces in this pass
+        const int cq = (Cs - c0 < kSmallCib ? Cs - c0 : kSmallCib) >> 2;  // channel quads in this pass
         __syncthreads();  // the previous pass has been consumed
-        for (int u = threadIdx.x; u < TP * TP * (kSmallCib / 4); u += 256) {
-            const int p = u / (kSmallCib / 4), v = u - p * (kSmallCib / 4);
+        for (int u = threadIdx.x; u < TP * TP * (kSmallCib / VN); u += 256) {
+            const int p = u / (kSmallCib / VN), v = u - p * (kSmallCib / VN);
             const int ph = p / TP, pw = p - ph * TP;
             const int ih = th0 + ph - HB, iw = tw0 + pw - HB;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < cq && ih >= 0 && ih < Hs && iw >= 0 && iw < Ws)
-                val = *reinterpret_cast<const float4*>(x + (((int64_t)n * Hs + ih) * Ws + iw) * Cs + c0 + 4 * v);
-            *reinterpret_cast<float4*>(sm + p * kSmallPitch + 4 * v) = val;
+            struct alignas(16) Piece { T v[VN]; } val;
+#pragma unroll
+            for (int e = 0; e < VN; ++e) val.v[e] = (T)0.f;
+            if (v * VN < 4 * cq && ih >= 0 && ih < Hs && iw >= 0 && iw < Ws)
+                val = *reinterpret_cast<const Piece*>(x + (((int64_t)n * Hs + ih) * Ws + iw) * Cs + c0 + VN * v);
+#pragma unroll
+            for (int e4 = 0; e4 < VN / 4; ++e4)
+                *reinterpret_cast<float4*>(sm + p * kSmallPitch + VN * v + 4 * e4) =
+                    make_float4((float)val.v[4 * e4], (float)val.v[4 * e4 + 1], (float)val.v[4 * e4 + 2],
+                                (float)val.v[4 * e4 + 3]);
         }
         __syncthreads();
         for (int v = 0; v < cq; ++v) {
@@ -59,7 +82,7 @@ __global__ __launch_bounds__(256) void convt_small_k(const float* __restrict__ x
 #pragma unroll
                 for (int dw = 0; dw < WIN; ++dw)
                     xq[dh][dw] = *reinterpret_cast<const float4*>(sm + ((ty + dh) * TP + tx + dw) * kSmallPitch + 4 * v);
-            const float* wv = w + c0 + 4 * v;  // wave-uniform: the filter reads below are scalar loads
+            const T* wv = w + c0 + 4 * v;  // wave-uniform: the filter reads below are scalar loads
 #pragma unroll
             for (int r = 0; r < S; ++r)
 #pragma unroll
@@ -74,8 +97,8 @@ __global__ __launch_bounds__(256) void convt_small_k(const float* __restrict__ x
                             const v2f xlo{xv.x, xv.y}, xhi{xv.z, xv.w};
 #pragma unroll
                             for (int co = 0; co < CB; ++co) {
-                                const float* wp = wv + (int64_t)((a * K + b) * CB + co) * Cs;
-                                const v2f wlo{wp[0], wp[1]}, whi{wp[2], wp[3]};
+                                v2f wlo, whi;
+                                load_w4(wv + (int64_t)((a * K + b) * CB + co) * Cs, wlo, whi);
                                 acc[r][c][co] = __builtin_elementwise_fma(xlo, wlo, acc[r][c][co]);
                                 acc[r][c][co] = __builtin_elementwise_fma(xhi, whi, acc[r][c][co]);
                             }
@@ -89,18 +112,18 @@ __global__ __launch_bounds__(256) void convt_small_k(const float* __restrict__ x
     for (int r = 0; r < S; ++r)
 #pragma unroll
         for (int c = 0; c < S; ++c) {
-            float* o = y + (((int64_t)n * Hb + S * m + r) * Wb + S * q + c) * CB;
+            T* o = y + (((int64_t)n * Hb + S * m + r) * Wb + S * q + c) * CB;
 #pragma unroll
             for (int co = 0; co < CB; ++co) {
                 const float z = (acc[r][c][co].x + acc[r][c][co].y) + (bias != nullptr ? bias[co] : 0.f);
-                o[co] = act_apply(z, act, alpha);
+                o[co] = (T)act_apply(z, act, alpha);
             }
         }
 }
 
-template <int K, int S>
-static int launch_small_ks(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
-                           float alpha, hipStream_t st) {
+template <int K, int S, typename T>
+static int launch_small_ks(const sv_conv_geom& g, const T* x, const T* w, const float* bias, T* y, int act, float alpha,
+                           hipStream_t st) {
     constexpr int Q = K / S, PT = (K - S) / 2, TP = 16 + (Q - 1) + (S - 1 + PT) / S;
     const int tiles_h = (int)ceil_div(g.Ho, 16), tiles_w = (int)ceil_div(g.Wo, 16);
     const int64_t blocks = (int64_t)g.N * tiles_h * tiles_w;
@@ -108,16 +131,16 @@ static int launch_small_ks(const sv_conv_geom& g, const float* x, const float* w
     const size_t lds = (size_t)TP * TP * kSmallPitch * sizeof(float);
     const dim3 grid((unsigned)blocks), block(256);
     switch (g.Cin) {
-        case 1: hipLaunchKernelGGL((convt_small_k<K, S, 1>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
-        case 2: hipLaunchKernelGGL((convt_small_k<K, S, 2>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
-        case 3: hipLaunchKernelGGL((convt_small_k<K, S, 3>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
-        default: hipLaunchKernelGGL((convt_small_k<K, S, 4>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
+        case 1: hipLaunchKernelGGL((convt_small_k<K, S, 1, T>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
+        case 2: hipLaunchKernelGGL((convt_small_k<K, S, 2, T>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
+        case 3: hipLaunchKernelGGL((convt_small_k<K, S, 3, T>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
+        default: hipLaunchKernelGGL((convt_small_k<K, S, 4, T>), grid, block, lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout, act, alpha, tiles_w, tiles_h * tiles_w); break;
     }
     return check_launch("convt_small");
 }
 
-bool convt_small_ok(const sv_conv_geom& g) {
-    if (g.Cin < 1 || g.Cin > 4 || g.Cout < 16 || (g.Cout & 3)) return false;
+bool convt_small_ok(const sv_conv_geom& g, int vn) {
+    if (g.Cin < 1 || g.Cin > 4 || g.Cout < 16 || (g.Cout % vn)) return false;
     if (g.KH != g.KW || g.SH != g.SW || g.up_h != 1 || g.up_w != 1) return false;
     if (!((g.KH == 4 && g.SH == 2) || (g.KH == 2 && g.SH == 2) || (g.KH == 4 && g.SH == 1))) return false;
     if (g.H != g.Ho * g.SH || g.W != g.Wo * g.SW) return false;
@@ -125,15 +148,31 @@ bool convt_small_ok(const sv_conv_geom& g) {
     return g.pad_t == pt && g.pad_l == pt;
 }
 
-// Returns 1 when the geometry is not covered (the caller takes its general path), 0 on success, < 0 on error.
+template <typename T>
+static int launch_small_any(const sv_conv_geom& g, const T* x, const T* w, const float* bias, T* y, int act, float alpha,
+                            hipStream_t st) {
+    if (!convt_small_ok(g, 16 / (int)sizeof(T))) return 1;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return 1;
+    static const bool off = [] {  // SPECTRUM_SMALL_CONVT=0: the general (implicit GEMM) path, for A/B measurements
+        const char* e = std::getenv("SPECTRUM_SMALL_CONVT");
+        return e != nullptr && e[0] == '0';
+    }();
+    if (off) return 1;
+    if (g.KH == 4 && g.SH == 1) return launch_small_ks<4, 1, T>(g, x, w, bias, y, act, alpha, st);
+    if (g.KH == 4) return launch_small_ks<4, 2, T>(g, x, w, bias, y, act, alpha, st);
+    return launch_small_ks<2, 2, T>(g, x, w, bias, y, act, alpha, st);
+}
+
+// Return 1 when the geometry is not covered (the caller takes its general path), 0 on success, < 0 on error.
 // x: [N][Ho][Wo][Cout] (the channel-rich tensor), y: [N][H][W][Cin].
 int launch_convt_small(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
                        float alpha, hipStream_t st) {
-    if (!convt_small_ok(g)) return 1;
-    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return 1;
-    if (g.KH == 4 && g.SH == 1) return launch_small_ks<4, 1>(g, x, w, bias, y, act, alpha, st);
-    if (g.KH == 4) return launch_small_ks<4, 2>(g, x, w, bias, y, act, alpha, st);
-    return launch_small_ks<2, 2>(g, x, w, bias, y, act, alpha, st);
+    return launch_small_any<float>(g, x, w, bias, y, act, alpha, st);
+}
+
+int launch_convt_small_bf16(const sv_conv_geom& g, const void* x, const void* w, const float* bias, void* y, int act,
+                            float alpha, hipStream_t st) {
+    return launch_small_any<__bf16>(g, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, act, alpha, st);
 }
 
 }  // namespace sv

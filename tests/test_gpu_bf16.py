@@ -98,6 +98,8 @@ T_CASES = [
     (4, 4, 1, "valid", 1, 1, 200, 128, 5),    # context-encoder decoder head: 1x1 -> 4x4
     (4, 4, 2, "same", 4, 4, 128, 64, 3),
     (4, 4, 2, "same", 16, 16, 64, 3, 2),      # context-encoder output layer
+    (4, 4, 2, "same", 9, 21, 40, 4, 2),       # <= 4 image channels, ragged tiles, a short last staging pass
+    (4, 4, 1, "same", 20, 7, 24, 1, 3),
     (3, 3, 2, "same", 5, 6, 24, 10, 1),
     (4, 4, 2, "same", 8, 8, 128, 128, 195),   # 4 row classes x 128-row tiles
     (2, 2, 2, "same", 8, 8, 128, 64, 770),
