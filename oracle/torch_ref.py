@@ -49,7 +49,8 @@ def conv2d_nchw(x, w_hwio, b, stride, padding):
         _, pl, pr = np_ops.same_pads(wd, kw, sw)
         if pt or pb or pl or pr:
             x = F.pad(x, (pl, pr, pt, pb))
-    w = w_hwio.permute(3, 2, 0, 1)
+    # a materialised OIHW copy: torch's float64 CPU conv backward rejects the permuted view when Cout == 1
+    w = w_hwio.permute(3, 2, 0, 1).contiguous()
     return F.conv2d(x, w, b, stride=stride)
 
 
