@@ -233,7 +233,13 @@ def main():
         ops.gather_rows(X, idx, b["x"])
         model.train_on_device_batch(b, True, float(bs))
 
-    for i in range(max(args.warmup, 3)):  # step 0 is eager (allocates), step 1 captures the graphs
+    # set-up, before the W warm-up steps: step 0 runs eagerly (allocates every buffer), step 1 records the HIP graphs, and
+    # a further 100 replays (about 30 ms) bring the clocks to their steady state - with the driver's W = 5 the timed region
+    # would otherwise start on a GPU that has been busy for a millisecond
+    setup_steps = 2 + (0 if args.no_graph else 100)
+    for i in range(setup_steps):
+        step(i)
+    for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -331,6 +337,7 @@ def main():
             "config": {"workload": "CAEPadded run_model.py defaults (12035 weights), MSE + Keras Adam, "
                                    f"per-GPU batch {bs}, 32x32x3 inputs", "global_batch": bs * world,
                        "parallelism": f"dp{world}", "hip_graph": bool(model.use_graphs or not args.no_graph),
+                       "setup_steps": setup_steps,
                        "conv_flops_per_sample_fwd_bwd": fl["fwd_bwd"]},
             "model_tflops": round(fl["fwd_bwd"] * samples / elapsed / 1e12, 3),
             "final_loss": final_loss,
