@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ theta, fl
 
 // ------------------------------------------------------------------------------------------------ GEMM (Dense)
 // C[m,n] (+)= epi( sum_k A(m,k) * B(k,n) ), element (m,k) of A at a[m*am + k*ak], (k,n) of B at b[k*bk + n*bn].
-// 64x64 tile, BK = 16, 256 threads with a 4x4 register tile each.
+// 64x64 tile, BK = 16, 256 threads; the products run on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
+typedef float v4f __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void gemm_k(const float* __restrict__ a, int64_t am, int64_t ak,
                                                const float* __restrict__ b, int64_t bk, int64_t bn,
                                                const float* __restrict__ bias, float* __restrict__ c, int M, int N,
@@ -239,8 +240,15 @@ __global__ __launch_bounds__(256) void gemm_k(const float* __restrict__ a, int64
     __shared__ float As[16][64 + 4];
     __shared__ float Bs[16][64 + 4];
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float acc[4][4] = {};
+    // 4 waves as 2 x 2, each 32 x 32 of the tile = 2 x 2 matrix-core tiles of 16 x 16 (k step 4)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    v4f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < K; k0 += 16) {
         // 1024 elements per tile, 4 per thread; make the unit-stride dimension the fastest-varying one
 #pragma unroll
@@ -269,34 +277,36 @@ __global__ __launch_bounds__(256) void gemm_k(const float* __restrict__ a, int64
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float av[4], bv[4];
+        for (int kk = 0; kk < 16; kk += 4) {
+            float av[2], bv[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
+            for (int i = 0; i < 2; ++i) av[i] = As[kk + lk][wm + 16 * i + li];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
+            for (int j = 0; j < 2; ++j) bv[j] = Bs[kk + lk][wn + 16 * j + li];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
+    // lane (li, lk) holds rows 4 lk .. 4 lk + 3, column li of each 16 x 16 tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + ty * 4 + i;
-        if (gm >= M) continue;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gn = n0 + tx * 4 + j;
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n0 + wn + 16 * j + li;
             if (gn >= N) continue;
-            float v = acc[i][j];
-            if (bias != nullptr) v += bias[gn];
-            v = act_apply(v, act, alpha);
-            float* cp = c + (int64_t)gm * N + gn;
-            *cp = accumulate ? *cp + v : v;
+            const float bb = bias != nullptr ? bias[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm + 16 * i + 4 * lk + r;
+                if (gm >= M) continue;
+                const float v = act_apply(acc[i][j][r] + bb, act, alpha);
+                float* cp = c + (int64_t)gm * N + gn;
+                *cp = accumulate ? *cp + v : v;
+            }
         }
-    }
 }
 
 int launch_gemm(const float* a, int64_t am, int64_t ak, const float* b, int64_t bk, int64_t bn, const float* bias,
