@@ -132,9 +132,13 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     } else if (MODE == GEMM_DGRAD) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
+            // a row of a class reaches output pixel (r_h - jh, r_w - jw) through the class's tap (jh, jw): the divisions by the
+            // strides are exact by construction of the class and done once here, not once per reduction step
             const int rl = VA ? (t >> 2) : (t >> 4) + 16 * i;
-            r_img[i] = row_img[rl]; r_h[i] = row_h[rl]; r_w[i] = row_w[rl];
+            r_img[i] = row_img[rl];
             r_ok[i] = r_img[i] >= 0;
+            r_h[i] = p.one_out ? 0 : (row_h[rl] + g.pad_t - kh0) / g.SH;
+            r_w[i] = p.one_out ? 0 : (row_w[rl] + g.pad_l - kw0) / g.SW;
         }
     } else {
 #pragma unroll
@@ -187,13 +191,11 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             const bool kok = kt < kend;
             const int kk = kok ? kt : 0;
             const int j = fd(kk, p.f_ck), co = kk - j * g.Cout;  // j: index among the class's taps
-            const int jh = fd(j, f_nkw), jw = j - jh * nkw;
-            const int kh = p.one_out ? kh0 : kh0 + jh * g.SH, kw = p.one_out ? kw0 : kw0 + jw * g.SW;
+            const int jh = p.one_out ? 0 : fd(j, f_nkw), jw = p.one_out ? 0 : j - jh * nkw;
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
-                const int oh = th / g.SH, ow = tw / g.SW;  // exact by construction of the class
-                const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo;
+                const int oh = r_h[i] - jh, ow = r_w[i] - jw;
+                const bool ok = kok && r_ok[i] && oh >= 0 && ow >= 0 && oh < g.Ho && ow < g.Wo;
                 const float* q = p.a + (((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co;
                 if (VA) ld4(q, ok, av);
                 else av[i] = ok ? *q : 0.f;

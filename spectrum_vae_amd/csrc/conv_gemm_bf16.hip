@@ -89,7 +89,7 @@ __device__ __forceinline__ void put_elem(uint4& v, int e, unsigned short bits) {
 // BBM x BNT: the result tile.  BNT >= 64: the waves sit 2 x 2, each on (BBM / 2) x (BNT / 2);  BNT == 16: 4 x 1, each on
 // (BBM / 4) x 16.  Images wider than 64 columns are kept as side-by-side 64-column images.
 template <int MODE, int BBM, int BNT>
-__global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
+__global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGemmBf16Args p) {
     constexpr int WAVES_N = BNT >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int TI = BBM / WAVES_M / 16, TJ = BNT / WAVES_N / 16;
     constexpr int NAQ = BBM / 32;                   // 16-byte A pieces per thread and step
@@ -178,11 +178,15 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
             r_img[i] = img; r_h[i] = hh; r_w[i] = rem - hh * p.f_wo.d;
         }
     } else if (MODE == BGEMM_DGRAD) {
+        // A row of a class reaches output pixel (ohb - jh, owb - jw) through the class's tap (jh, jw): the divisions by the
+        // strides are exact by construction of the class and done once here, not once per reduction step
 #pragma unroll
         for (int i = 0; i < NAQ; ++i) {
             const int rl = (t >> 3) + 32 * i;
-            r_img[i] = row_img[rl]; r_h[i] = row_h[rl]; r_w[i] = row_w[rl];
+            r_img[i] = row_img[rl];
             r_ok[i] = r_img[i] >= 0;
+            r_h[i] = p.one_out ? 0 : (row_h[rl] + g.pad_t - kh0) / g.SH;
+            r_w[i] = p.one_out ? 0 : (row_w[rl] + g.pad_l - kw0) / g.SW;
         }
     }
     // WGRAD: piece i of this thread covers reduction row (t >> 3) + 32 (i & 1) and the 8 result rows
@@ -215,12 +219,13 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
         kh = fd(tap, p.f_kw);
         kw = tap - kh * g.KW;
     };
-    auto dgrad_tap = [&](int k, int& kh, int& kw, int& co) {
+    auto dgrad_tap = [&](int k, int& kh, int& kw, int& co, int& jh, int& jw) {
         const int j = fd(k, p.f_ck);
         co = k - j * g.Cout;
-        const int jh = fd(j, f_nkw), jw = j - jh * nkw;
-        kh = p.one_out ? kh0 : kh0 + jh * g.SH;
-        kw = p.one_out ? kw0 : kw0 + jw * g.SW;
+        jh = p.one_out ? 0 : fd(j, f_nkw);
+        jw = p.one_out ? 0 : j - jh * nkw;
+        kh = kh0 + jh * g.SH;
+        kw = kw0 + jw * g.SW;
     };
 
     // global -> registers for one reduction step (issued one step ahead of its use)
@@ -259,13 +264,12 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
             const int kt = k0 + 8 * qc;
             if (p.va) {
                 const bool kok = kt < kend;
-                int kh, kw, co;
-                dgrad_tap(kok ? kt : 0, kh, kw, co);
+                int kh, kw, co, jh, jw;
+                dgrad_tap(kok ? kt : 0, kh, kw, co, jh, jw);
 #pragma unroll
                 for (int i = 0; i < NAQ; ++i) {
-                    const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
-                    const int oh = th / g.SH, ow = tw / g.SW;  // exact by construction of the class
-                    const bool ok = kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo;
+                    const int oh = r_h[i] - jh, ow = r_w[i] - jw;
+                    const bool ok = kok && r_ok[i] && oh >= 0 && ow >= 0 && oh < g.Ho && ow < g.Wo;
                     av[i] = ld16(p.a + (((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co, ok);
                 }
             } else {
@@ -274,13 +278,12 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const bool kok = kt + e < kend;
-                    int kh, kw, co;
-                    dgrad_tap(kok ? kt + e : 0, kh, kw, co);
+                    int kh, kw, co, jh, jw;
+                    dgrad_tap(kok ? kt + e : 0, kh, kw, co, jh, jw);
 #pragma unroll
                     for (int i = 0; i < NAQ; ++i) {
-                        const int th = r_h[i] + g.pad_t - kh, tw = r_w[i] + g.pad_l - kw;
-                        const int oh = th / g.SH, ow = tw / g.SW;
-                        if (kok && r_ok[i] && th >= 0 && tw >= 0 && oh < g.Ho && ow < g.Wo)
+                        const int oh = r_h[i] - jh, ow = r_w[i] - jw;
+                        if (kok && r_ok[i] && oh >= 0 && ow >= 0 && oh < g.Ho && ow < g.Wo)
                             put_elem(av[i], e, bf_bits(p.a[(((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co]));
                     }
                 }
@@ -320,8 +323,8 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
             const int kt = k0 + 8 * qc;
             if (p.vb) {
                 const bool kok = kt < kend;
-                int kh, kw, co;
-                dgrad_tap(kok ? kt : 0, kh, kw, co);
+                int kh, kw, co, jh, jw;
+                dgrad_tap(kok ? kt : 0, kh, kw, co, jh, jw);
                 const int tap = kh * g.KW + kw;
 #pragma unroll
                 for (int i = 0; i < NBQ; ++i) {
@@ -335,8 +338,8 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16(ConvGemmBf16Args p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const bool kok = kt + e < kend;
-                    int kh, kw, co;
-                    dgrad_tap(kok ? kt + e : 0, kh, kw, co);
+                    int kh, kw, co, jh, jw;
+                    dgrad_tap(kok ? kt + e : 0, kh, kw, co, jh, jw);
                     const int tap = kh * g.KW + kw;
 #pragma unroll
                     for (int i = 0; i < NBQ; ++i) {

@@ -614,8 +614,12 @@ NetPlan plan_net_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int
     NetPlan p{};
     p.ok = false;
     p.nt = 256;
+    static const int s_cap = [] {  // SPECTRUM_NETFWD_S=1|2|4: cap on the samples a workgroup carries (measurements)
+        const char* e = std::getenv("SPECTRUM_NETFWD_S");
+        return e != nullptr ? std::atoi(e) : 4;
+    }();
     for (int S = 4; S >= 1; --S) {
-        if (S == 3) continue;
+        if (S == 3 || S > s_cap) continue;
         size_t fl = 0;
         NetFwdArgs a{};
         net_fill(a, layers, n_layers, N, H, W, S, p.nt, &fl);
@@ -630,7 +634,11 @@ NetPlan plan_net_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int
     }
     if (!p.ok) return p;
     const int passes = (N + p.S - 1) / p.S;
-    p.grid = passes < 512 ? passes : 512;
+    static const int g_cap = [] {  // SPECTRUM_NETFWD_GRID: cap on the workgroups of the launch (measurements)
+        const char* e = std::getenv("SPECTRUM_NETFWD_GRID");
+        return e != nullptr ? std::atoi(e) : 512;
+    }();
+    p.grid = passes < g_cap ? passes : g_cap;
     p.args.N = N; p.args.S = p.S; p.args.n_layers = n_layers;
     return p;
 }
