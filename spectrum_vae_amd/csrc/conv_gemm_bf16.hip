@@ -89,7 +89,7 @@ __device__ __forceinline__ void put_elem(uint4& v, int e, unsigned short bits) {
 // BBM x BNT: the result tile.  BNT >= 64: the waves sit 2 x 2, each on (BBM / 2) x (BNT / 2);  BNT == 16: 4 x 1, each on
 // (BBM / 4) x 16.  Images wider than 64 columns are kept as side-by-side 64-column images.
 template <int MODE, int BBM, int BNT>
-__global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGemmBf16Args p) {
+__global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3) void conv_gemm_bf16(ConvGemmBf16Args p) {
     constexpr int WAVES_N = BNT >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int TI = BBM / WAVES_M / 16, TJ = BNT / WAVES_N / 16;
     constexpr int NAQ = BBM / 32;                   // 16-byte A pieces per thread and step
@@ -164,7 +164,10 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGem
     // ROW images (FWD / DGRAD A): image row = result row;  TR images (WGRAD A, B; FWD B): image row = reduction index.
     const int qc = t & 7;  // chunk of every piece of this thread
     constexpr int NRW = MODE == BGEMM_WGRAD ? 1 : NAQ;  // result rows this thread gathers A for
+    // r_base: element offset of the row's tap-(0, 0), channel-0 operand element (it may lie outside the tensor: only
+    // addresses whose bounds test passes are dereferenced); a reduction step then adds one offset shared by all rows
     int r_img[NRW], r_h[NRW], r_w[NRW];
+    int64_t r_base[NRW];
     bool r_ok[NRW];
     if (MODE == BGEMM_FWD) {
 #pragma unroll
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGem
             const int img = fd(mm, p.f_howo);
             const int rem = mm - img * p.f_howo.d;
             const int hh = fd(rem, p.f_wo);
-            r_img[i] = img; r_h[i] = hh; r_w[i] = rem - hh * p.f_wo.d;
+            r_img[i] = img; r_h[i] = hh * g.SH - g.pad_t; r_w[i] = (rem - hh * p.f_wo.d) * g.SW - g.pad_l;
+            r_base[i] = (((int64_t)img * g.H + r_h[i]) * g.W + r_w[i]) * g.Cin;
         }
     } else if (MODE == BGEMM_DGRAD) {
         // A row of a class reaches output pixel (ohb - jh, owb - jw) through the class's tap (jh, jw): the divisions by the
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGem
             r_ok[i] = r_img[i] >= 0;
             r_h[i] = p.one_out ? 0 : (row_h[rl] + g.pad_t - kh0) / g.SH;
             r_w[i] = p.one_out ? 0 : (row_w[rl] + g.pad_l - kw0) / g.SW;
+            r_base[i] = (((int64_t)r_img[i] * g.Ho + r_h[i]) * g.Wo + r_w[i]) * g.Cout;
         }
     }
     // WGRAD: piece i of this thread covers reduction row (t >> 3) + 32 (i & 1) and the 8 result rows
@@ -237,11 +242,11 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGem
                 const bool kok = kt < kend;
                 int kh, kw, ci;
                 fwd_tap(kok ? kt : 0, kh, kw, ci);
+                const int koff = (kh * g.W + kw) * g.Cin + ci;
 #pragma unroll
                 for (int i = 0; i < NAQ; ++i) {
-                    const int ih = r_h[i] * g.SH - g.pad_t + kh, iw = r_w[i] * g.SW - g.pad_l + kw;
-                    const bool ok = kok && r_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                    av[i] = ld16(p.a + (((int64_t)r_img[i] * g.H + ih) * g.W + iw) * g.Cin + ci, ok);
+                    const bool ok = kok && r_ok[i] && (unsigned)(r_h[i] + kh) < (unsigned)g.H && (unsigned)(r_w[i] + kw) < (unsigned)g.W;
+                    av[i] = ld16(p.a + (r_base[i] + koff), ok);
                 }
             } else {
 #pragma unroll
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGem
                     fwd_tap(kok ? k : 0, kh, kw, ci);
 #pragma unroll
                     for (int i = 0; i < NAQ; ++i) {
-                        const int ih = r_h[i] * g.SH - g.pad_t + kh, iw = r_w[i] * g.SW - g.pad_l + kw;
+                        const int ih = r_h[i] + kh, iw = r_w[i] + kw;
                         const bool ok = kok && r_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
                         if (ok) put_elem(av[i], e, bf_bits(p.a[(((int64_t)r_img[i] * g.H + ih) * g.W + iw) * g.Cin + ci]));
                     }
@@ -266,11 +271,11 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGem
                 const bool kok = kt < kend;
                 int kh, kw, co, jh, jw;
                 dgrad_tap(kok ? kt : 0, kh, kw, co, jh, jw);
+                const int koff = co - (jh * g.Wo + jw) * g.Cout;
 #pragma unroll
                 for (int i = 0; i < NAQ; ++i) {
-                    const int oh = r_h[i] - jh, ow = r_w[i] - jw;
-                    const bool ok = kok && r_ok[i] && oh >= 0 && ow >= 0 && oh < g.Ho && ow < g.Wo;
-                    av[i] = ld16(p.a + (((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co, ok);
+                    const bool ok = kok && r_ok[i] && (unsigned)(r_h[i] - jh) < (unsigned)g.Ho && (unsigned)(r_w[i] - jw) < (unsigned)g.Wo;
+                    av[i] = ld16(p.a + (r_base[i] + koff), ok);
                 }
             } else {
 #pragma unroll
@@ -325,12 +330,12 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGem
                 const bool kok = kt < kend;
                 int kh, kw, co, jh, jw;
                 dgrad_tap(kok ? kt : 0, kh, kw, co, jh, jw);
-                const int tap = kh * g.KW + kw;
+                const int boff = (kh * g.KW + kw) * g.Cin * g.Cout + co;  // the filter tensor is far below 2^31 elements
 #pragma unroll
                 for (int i = 0; i < NBQ; ++i) {
                     const int nl = (t >> 3) + 32 * i;
                     const int n = n0 + nl;
-                    bv[i] = ld16(p.b + ((int64_t)tap * g.Cin + n) * g.Cout + co, kok && nl < BNT && n < p.N);
+                    bv[i] = ld16(p.b + (boff + n * g.Cout), kok && nl < BNT && n < p.N);
                 }
             } else {
 #pragma unroll
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void conv_gemm_bf16(ConvGem
                 const int n = n0 + 8 * c8;
                 const bool live = (BNT >= 64 || t < 128) && k < kend;
                 if (p.vb) {
-                    bv[i] = ld16(p.b + (int64_t)k * p.N + n, live && n + 8 <= p.N);
+                    bv[i] = ld16(p.b + ((int64_t)k0 * p.N + (kr * p.N + n)), live && n + 8 <= p.N);
                 } else {
                     bv[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -514,7 +519,10 @@ static bool aligned16b(const void* q) { return (reinterpret_cast<uintptr_t>(q) &
 
 // Every geometry the index decoding covers runs on this kernel, short reductions and odd channel counts included (their
 // operands are gathered element by element): the direct kernels' 2-byte loads through the vector path are slower still.
-bool conv_gemm_bf16_ok(const sv_conv_geom& g, int mode) { return conv_gemm_shape_ok(g, mode, 1); }
+bool conv_gemm_bf16_ok(const sv_conv_geom& g, int mode) {
+    // filter offsets are formed in 32 bits
+    return (int64_t)g.KH * g.KW * g.Cin * g.Cout < (1ll << 31) && conv_gemm_shape_ok(g, mode, 1);
+}
 
 // Result tile for `rows` x `ncols` results in `zmult` independent groups (row classes, reduction splits): the largest
 // tile that still leaves every CU more than one workgroup.
