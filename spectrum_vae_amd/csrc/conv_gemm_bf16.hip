@@ -46,6 +46,7 @@ struct ConvGemmBf16Args {
     int splits;         // FWD / DGRAD: > 1 cuts the reduction over blockIdx.z, raw partial sums go to cf
     int accumulate;     // WGRAD with a single split: cf is dw itself and the tile is added to it when set
     int va, vb;         // the A / B operand can be gathered in 16-byte pieces (channel count % 8 == 0, 16-byte aligned base)
+    unsigned a_bytes, b_bytes;  // sizes of the A / B tensors: the 16-byte gathers are range-checked buffer loads
 };
 
 constexpr int BBK = 64;
@@ -77,8 +78,12 @@ __device__ __forceinline__ v8bf tr_frag(const unsigned char* img, int kk, int lk
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__device__ __forceinline__ uint4 ld16(const bf16_t* q, bool ok) {
-    return ok ? *reinterpret_cast<const uint4*>(q) : make_uint4(0u, 0u, 0u, 0u);
+// 16 bytes at element offset `elem` of a tensor, zeros when !ok: a buffer load whose offset is pushed out of the
+// descriptor's range for the dead pieces (the hardware answers those with zeros), so the gather has no branches.
+typedef unsigned int v4u_b __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16(__amdgpu_buffer_rsrc_t rs, int elem, bool ok) {
+    const v4u_b v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? elem * 2 : (int)0x80000000, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ unsigned short bf_bits(bf16_t v) { return __builtin_bit_cast(unsigned short, v); }
 __device__ __forceinline__ void put_elem(uint4& v, int e, unsigned short bits) {
@@ -101,6 +106,8 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
     unsigned char* As = smem;
     unsigned char* Bs = smem + A_BYTES;
     const sv_conv_geom& g = p.g;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.b), 0, p.b_bytes, 0x00020000);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
     // r_base: element offset of the row's tap-(0, 0), channel-0 operand element (it may lie outside the tensor: only
     // addresses whose bounds test passes are dereferenced); a reduction step then adds one offset shared by all rows
     int r_img[NRW], r_h[NRW], r_w[NRW];
-    int64_t r_base[NRW];
+    int r_base[NRW];
     bool r_ok[NRW];
     if (MODE == BGEMM_FWD) {
 #pragma unroll
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
             const int rem = mm - img * p.f_howo.d;
             const int hh = fd(rem, p.f_wo);
             r_img[i] = img; r_h[i] = hh * g.SH - g.pad_t; r_w[i] = (rem - hh * p.f_wo.d) * g.SW - g.pad_l;
-            r_base[i] = (((int64_t)img * g.H + r_h[i]) * g.W + r_w[i]) * g.Cin;
+            r_base[i] = ((img * g.H + r_h[i]) * g.W + r_w[i]) * g.Cin;
         }
     } else if (MODE == BGEMM_DGRAD) {
         // A row of a class reaches output pixel (ohb - jh, owb - jw) through the class's tap (jh, jw): the divisions by the
@@ -191,13 +198,13 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
             r_ok[i] = r_img[i] >= 0;
             r_h[i] = p.one_out ? 0 : (row_h[rl] + g.pad_t - kh0) / g.SH;
             r_w[i] = p.one_out ? 0 : (row_w[rl] + g.pad_l - kw0) / g.SW;
-            r_base[i] = (((int64_t)r_img[i] * g.Ho + r_h[i]) * g.Wo + r_w[i]) * g.Cout;
+            r_base[i] = ((r_img[i] * g.Ho + r_h[i]) * g.Wo + r_w[i]) * g.Cout;
         }
     }
     // WGRAD: piece i of this thread covers reduction row (t >> 3) + 32 (i & 1) and the 8 result rows
     // m = m0 + 64 (i >> 1) + 8 qc .. + 7, which share a tap when the A operand is vectorised
     constexpr int NAM = MODE == BGEMM_WGRAD ? BBM / 64 : 1;
-    int a_kh[NAM], a_kw[NAM], a_ci[NAM];
+    int a_kh[NAM], a_kw[NAM], a_ci[NAM], a_off[NAM];
     bool a_ok[NAM];
     if (MODE == BGEMM_WGRAD) {
 #pragma unroll
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
             a_ci[s] = a_ok[s] ? m - tap * g.Cin : 0;
             a_kh[s] = fd(tap, p.f_kw);
             a_kw[s] = tap - a_kh[s] * g.KW;
+            a_off[s] = (a_kh[s] * g.W + a_kw[s]) * g.Cin + a_ci[s];
         }
     }
 
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
 #pragma unroll
                 for (int i = 0; i < NAQ; ++i) {
                     const bool ok = kok && r_ok[i] && (unsigned)(r_h[i] + kh) < (unsigned)g.H && (unsigned)(r_w[i] + kw) < (unsigned)g.W;
-                    av[i] = ld16(p.a + (r_base[i] + koff), ok);
+                    av[i] = ld16(rs_a, r_base[i] + koff, ok);
                 }
             } else {
 #pragma unroll
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
 #pragma unroll
                 for (int i = 0; i < NAQ; ++i) {
                     const bool ok = kok && r_ok[i] && (unsigned)(r_h[i] - jh) < (unsigned)g.Ho && (unsigned)(r_w[i] - jw) < (unsigned)g.Wo;
-                    av[i] = ld16(p.a + (r_base[i] + koff), ok);
+                    av[i] = ld16(rs_a, r_base[i] + koff, ok);
                 }
             } else {
 #pragma unroll
@@ -293,21 +301,39 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
                     }
                 }
             }
+        } else if (p.va) {
+            // the two reduction rows of this thread: pixel decode and the offset of the pixel's window once per row
+            int h0[2], w0[2], rb[2];
+            bool rok[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = k0 + (t >> 3) + 32 * j;
+                rok[j] = r < kend;
+                const int rr = rok[j] ? r : 0;
+                const int img = fd(rr, p.f_howo);
+                const int rem = rr - img * p.f_howo.d;
+                const int oh = fd(rem, p.f_wo), ow = rem - oh * p.f_wo.d;
+                h0[j] = oh * g.SH - g.pad_t; w0[j] = ow * g.SW - g.pad_l;
+                rb[j] = ((img * g.H + h0[j]) * g.W + w0[j]) * g.Cin;
+            }
+#pragma unroll
+            for (int i = 0; i < NAQ; ++i) {
+                const int j = i & 1, sm = i >> 1;  // sm: which 64-row group of the tile
+                const bool ok = rok[j] && a_ok[sm] && (unsigned)(h0[j] + a_kh[sm]) < (unsigned)g.H &&
+                                (unsigned)(w0[j] + a_kw[sm]) < (unsigned)g.W;
+                av[i] = ld16(rs_a, rb[j] + a_off[sm], ok);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NAQ; ++i) {
                 const int r = k0 + (t >> 3) + 32 * (i & 1);
-                const int sm = i >> 1;  // which 64-row group of the tile
+                const int sm = i >> 1;
                 const bool rok = r < kend;
                 const int rr = rok ? r : 0;
                 const int img = fd(rr, p.f_howo);
                 const int rem = rr - img * p.f_howo.d;
                 const int oh = fd(rem, p.f_wo), ow = rem - oh * p.f_wo.d;
-                if (p.va) {
-                    const int ih = oh * g.SH - g.pad_t + a_kh[sm], iw = ow * g.SW - g.pad_l + a_kw[sm];
-                    const bool ok = rok && a_ok[sm] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                    av[i] = ld16(p.a + (((int64_t)img * g.H + ih) * g.W + iw) * g.Cin + a_ci[sm], ok);
-                } else {
+                {
                     av[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -335,7 +361,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
                 for (int i = 0; i < NBQ; ++i) {
                     const int nl = (t >> 3) + 32 * i;
                     const int n = n0 + nl;
-                    bv[i] = ld16(p.b + (boff + n * g.Cout), kok && nl < BNT && n < p.N);
+                    bv[i] = ld16(rs_b, boff + n * g.Cout, kok && nl < BNT && n < p.N);
                 }
             } else {
 #pragma unroll
@@ -354,7 +380,16 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
                     }
                 }
             }
-        } else {  // TR image [k][n]: FWD w[k][n], WGRAD dz[r][n]; n contiguous in memory
+        } else if (p.vb) {  // TR image [k][n]: FWD w[k][n], WGRAD dz[r][n]; n contiguous in memory
+#pragma unroll
+            for (int i = 0; i < NBQ; ++i) {
+                const int kr = BNT >= 64 ? (t >> 3) + 32 * (i & 1) : (t >> 1);
+                const int c8 = BNT >= 64 ? 8 * (i >> 1) + qc : (t & 1);
+                const int n = n0 + 8 * c8;
+                const bool live = (BNT >= 64 || t < 128) && k0 + kr < kend;
+                bv[i] = ld16(rs_b, k0 * p.N + (kr * p.N + n), live && n + 8 <= p.N);
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < NBQ; ++i) {
                 const int kr = BNT >= 64 ? (t >> 3) + 32 * (i & 1) : (t >> 1);
@@ -362,14 +397,10 @@ __global__ __launch_bounds__(256, (MODE == 2 || BBM * BNT >= 128 * 128) ? 2 : 3)
                 const int k = k0 + kr;
                 const int n = n0 + 8 * c8;
                 const bool live = (BNT >= 64 || t < 128) && k < kend;
-                if (p.vb) {
-                    bv[i] = ld16(p.b + ((int64_t)k0 * p.N + (kr * p.N + n)), live && n + 8 <= p.N);
-                } else {
-                    bv[i] = make_uint4(0u, 0u, 0u, 0u);
+                bv[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (live && n + e < p.N) put_elem(bv[i], e, bf_bits(p.b[(int64_t)k * p.N + n + e]));
-                }
+                for (int e = 0; e < 8; ++e)
+                    if (live && n + e < p.N) put_elem(bv[i], e, bf_bits(p.b[(int64_t)k * p.N + n + e]));
             }
         }
     };
@@ -520,9 +551,14 @@ static bool aligned16b(const void* q) { return (reinterpret_cast<uintptr_t>(q) &
 // Every geometry the index decoding covers runs on this kernel, short reductions and odd channel counts included (their
 // operands are gathered element by element): the direct kernels' 2-byte loads through the vector path are slower still.
 bool conv_gemm_bf16_ok(const sv_conv_geom& g, int mode) {
-    // filter offsets are formed in 32 bits
-    return (int64_t)g.KH * g.KW * g.Cin * g.Cout < (1ll << 31) && conv_gemm_shape_ok(g, mode, 1);
+    // the gathers address all three tensors with 32-bit byte offsets, 2^31 being the "no such piece" offset
+    const int64_t lim = 1ll << 30;
+    return (int64_t)g.KH * g.KW * g.Cin * g.Cout < lim && (int64_t)g.N * g.H * g.W * g.Cin < lim &&
+           (int64_t)g.N * g.Ho * g.Wo * g.Cout < lim && conv_gemm_shape_ok(g, mode, 1);
 }
+static unsigned bytes_x(const sv_conv_geom& g) { return (unsigned)((int64_t)g.N * g.H * g.W * g.Cin * 2); }
+static unsigned bytes_z(const sv_conv_geom& g) { return (unsigned)((int64_t)g.N * g.Ho * g.Wo * g.Cout * 2); }
+static unsigned bytes_w(const sv_conv_geom& g) { return (unsigned)((int64_t)g.KH * g.KW * g.Cin * g.Cout * 2); }
 
 // Result tile for `rows` x `ncols` results in `zmult` independent groups (row classes, reduction splits): the largest
 // tile that still leaves every CU more than one workgroup.
@@ -575,6 +611,7 @@ int launch_conv_gemm_bf16_fwd(const sv_conv_geom& g, const void* x, const void* 
     fill_common_b(p, g, BGEMM_FWD);
     p.a = (const bf16_t*)x; p.b = (const bf16_t*)w; p.bias = bias; p.c = (bf16_t*)y; p.act = act; p.alpha = alpha;
     p.M = g.N * g.Ho * g.Wo; p.N = g.Cout; p.K = g.KH * g.KW * g.Cin;
+    p.a_bytes = bytes_x(g); p.b_bytes = bytes_w(g);
     p.va = (g.Cin & 7) == 0 && aligned16b(x);
     p.vb = (g.Cout & 7) == 0 && aligned16b(w);
     p.splits = 1;
@@ -597,6 +634,7 @@ int launch_conv_gemm_bf16_dgrad(const sv_conv_geom& g, const void* dz, const voi
     p.a = (const bf16_t*)dz; p.b = (const bf16_t*)w; p.bias = bias; p.c = (bf16_t*)dx; p.act = act; p.alpha = alpha;
     p.M = g.N * g.H * g.W; p.N = g.Cin; p.K = g.KH * g.KW * g.Cout;
     p.one_out = g.Ho == 1 && g.Wo == 1;
+    p.a_bytes = bytes_z(g); p.b_bytes = bytes_w(g);
     p.va = (g.Cout & 7) == 0 && aligned16b(dz);
     p.vb = (g.Cout & 7) == 0 && aligned16b(w);
     int classes, rows;
@@ -670,6 +708,7 @@ int launch_conv_gemm_bf16_wgrad(const sv_conv_geom& g, const void* x, const void
     p.a = (const bf16_t*)x; p.b = (const bf16_t*)dz; p.cf = slabs; p.act = SV_ACT_NONE;
     p.accumulate = splits == 1 && accumulate;
     p.M = g.KH * g.KW * g.Cin; p.N = g.Cout; p.K = g.N * g.Ho * g.Wo;
+    p.a_bytes = bytes_x(g); p.b_bytes = bytes_z(g);
     p.va = (g.Cin & 7) == 0 && aligned16b(x);
     p.vb = (g.Cout & 7) == 0 && aligned16b(dz);
     p.k_per_split = (int)(ceil_div(ceil_div(p.K, splits), BBK) * BBK);
