@@ -405,8 +405,10 @@ int conv_gemm_splits(const sv_conv_geom& g, int mode) {
         blocks = ceil_div(rows, BM) * ceil_div(g.Cin, tile_cols(g.Cin)) * classes;
         zbase = classes;
     }
-    if (blocks >= 192) return 1;
-    int64_t s = ceil_div(512, blocks);
+    // 192 .. 511 workgroups (about one per CU, one wave per SIMD): each walks its reduction at the latency of a lone
+    // global -> LDS -> MFMA chain, and from 64 steps on a cut into about 1024 workgroups wins over the extra finish pass
+    if (blocks >= 512 || (blocks >= 192 && kdim < 64 * BK)) return 1;
+    int64_t s = ceil_div(blocks >= 192 ? 1024 : 512, blocks);
     const int64_t maxs = kdim / (4 * BK);
     if (s > maxs) s = maxs;
     if (s > 256) s = 256;
