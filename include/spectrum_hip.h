@@ -358,6 +358,13 @@ int sv_adam_keras_step(float* theta, float* grad, float* m, float* v, int64_t n,
 /* out[0] = [out[0] +] scale * sum(partials[0..n)) in a fixed order (one workgroup); running as above. */
 int sv_fold_scalar(const float* partials, int n, float scale, float* out, int accumulate, float* running,
                    float running_weight, sv_stream_t stream);
+/* Loss bookkeeping of the GAN steps in one launch (run_context_encoder.py:246-251: disc_loss = 0.5 * (true + fake),
+ * total = w * l2 + (1 - w) * disc_loss; run_unet.py:175-187): n_statements (1..4) scalar statements, run in order,
+ *   outs[s][0] = [outs[s][0] +] sum_k weights[.] * terms[.][0],   n_terms[s] (0..3) terms each,
+ * `terms` / `weights` listing all statements' terms back to back.  A later statement may read an earlier one's result.
+ * Each term enters through one fused multiply-add: the same bits as sv_fill_f32 + one sv_axpy_f32 per term. */
+int sv_scalar_program(int n_statements, float* const* outs, const int* accumulate, const int* n_terms,
+                      const float* const* terms, const float* weights, sv_stream_t stream);
 int sv_adam_keras_prepare(int64_t* step_state, float lr0, float beta1, float beta2, int decay_steps,
                           float decay_rate, int staircase, sv_stream_t stream);
 int sv_adam_keras_apply(float* theta, float* grad, float* m, float* v, int64_t n, const int64_t* step_state,

@@ -119,6 +119,7 @@ SIGNATURES = {
     "sv_deferred_reduce_begin": (_i, []),
     "sv_deferred_reduce_flush": (_i, [_i, _p]),
     "sv_fold_scalar": (_i, [_p, _i, _f, _p, _i, _p, _f, _p]),
+    "sv_scalar_program": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "sv_adam_keras_prepare": (_i, [_p, _f, _f, _f, _i, _f, _i, _p]),
     "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),
     "sv_gather_rows": (_i, [_p, _i, _p, _p, _i64, _i64, _p]),

@@ -11,11 +11,15 @@ constexpr int kLossBlocks = 1024;
 // mode 0: squared error, weight per pixel optional;  mode 1: absolute error;
 // mode 2: BCE on probabilities against constant label; mode 3: BCE on logits against constant label.
 // value_i is summed and scaled by inv_count; dpred_i = loss_scale * d(value_i)/dpred * inv_count.
+// A launch of ONE workgroup (a discriminator's logits) writes the loss itself, rounded as loss_fold_k rounds a single
+// partial sum; larger launches leave partials[blockIdx.x] for loss_fold_k.
 template <int MODE, typename T>
 __global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const T* __restrict__ p,
                                                const float* __restrict__ weight, int wstride, float wscale, int C,
                                                float label, float inv_count, T* __restrict__ dpred,
-                                               float loss_scale, int64_t n, float* __restrict__ partials) {
+                                               float loss_scale, int64_t n, float* __restrict__ partials,
+                                               float* __restrict__ out, int accumulate, float* __restrict__ running,
+                                               float running_weight) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -44,7 +48,15 @@ __global__ __launch_bounds__(256) void loss_k(const float* __restrict__ t, const
         if (dpred != nullptr) dpred[i] = (T)(loss_scale * g * inv_count);
     }
     const float s = block_sum_256(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    if (threadIdx.x != 0) return;
+    if (gridDim.x > 1) {
+        partials[blockIdx.x] = s;
+        return;
+    }
+    const float v = (float)((double)s * (double)inv_count);
+    const float r = accumulate ? out[0] + v : v;
+    out[0] = r;
+    if (running != nullptr) running[0] += running_weight * r;
 }
 
 // A scalar fold some later launch of the same stream carries out on behalf of a kernel that left per-workgroup partial sums
@@ -84,6 +96,27 @@ __global__ __launch_bounds__(256) void loss_fold_k(const float* __restrict__ par
                                                     float* __restrict__ out, int accumulate,
                                                     float* __restrict__ running = nullptr, float running_weight = 0.f) {
     fold_scalar_256(partials, nblocks, inv_count, out, accumulate, running, running_weight);
+}
+
+// A few scalar statements out_s = [out_s +] sum_k w_sk * in_sk, run in order by one lane: the loss bookkeeping of a GAN step
+// (disc_loss = 0.5 lt + 0.5 lf; total = w l2 + (1 - w) disc_loss) in one launch instead of a fill and an axpy per term.
+// Each term enters through one fused multiply-add, as in the axpy launches this replaces (bit-equal results).
+constexpr int kScalarStatements = 4, kScalarTerms = 3;
+struct ScalarProgram {
+    int n;
+    float* out[kScalarStatements];
+    int accumulate[kScalarStatements];
+    int n_in[kScalarStatements];
+    const float* in[kScalarStatements][kScalarTerms];
+    float w[kScalarStatements][kScalarTerms];
+};
+__global__ void scalar_program_k(ScalarProgram pr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int s = 0; s < pr.n; ++s) {
+        float acc = pr.accumulate[s] ? pr.out[s][0] : 0.f;
+        for (int k = 0; k < pr.n_in[s]; ++k) acc = fmaf(pr.w[s][k], pr.in[s][k][0], acc);
+        pr.out[s][0] = acc;
+    }
 }
 
 template <typename T>
@@ -392,12 +425,35 @@ int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int
     const float inv = 1.f / (float)n;
     SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<0, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
                                         (const T*)y_pred, weight, weight_stride, weight_scale, C, 0.f, inv, (T*)dpred,
-                                        loss_scale, n, partials););
+                                        loss_scale, n, partials, loss_out, accumulate, running, running_weight););
     int rc = check_launch("sv_loss_mse");
-    if (rc) return rc;
+    if (rc || nb == 1) return rc;
     hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate,
                        running, running_weight);
     return check_launch("sv_loss_mse/fold");
+}
+
+int sv_scalar_program(int n_statements, float* const* outs, const int* accumulate, const int* n_terms,
+                      const float* const* terms, const float* weights, sv_stream_t stream) {
+    SV_REQUIRE(n_statements >= 1 && n_statements <= kScalarStatements && outs && accumulate && n_terms && terms && weights,
+               "sv_scalar_program: 1..4 statements, non-null tables");
+    ScalarProgram pr{};
+    pr.n = n_statements;
+    int at = 0;
+    for (int s = 0; s < n_statements; ++s) {
+        SV_REQUIRE(outs[s] != nullptr && n_terms[s] >= 0 && n_terms[s] <= kScalarTerms,
+                   "sv_scalar_program: a statement has a null result or more than 3 terms");
+        pr.out[s] = outs[s];
+        pr.accumulate[s] = accumulate[s];
+        pr.n_in[s] = n_terms[s];
+        for (int k = 0; k < n_terms[s]; ++k, ++at) {
+            SV_REQUIRE(terms[at] != nullptr, "sv_scalar_program: null term");
+            pr.in[s][k] = terms[at];
+            pr.w[s][k] = weights[at];
+        }
+    }
+    hipLaunchKernelGGL(scalar_program_k, dim3(1), dim3(64), 0, to_stream(stream), pr);
+    return check_launch("sv_scalar_program");
 }
 
 int sv_loss_mse_map(const void* y_true, const void* y_pred, const float* weight, int weight_stride,
@@ -418,9 +474,9 @@ int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int acc
     const float inv = 1.f / (float)n;
     SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<1, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)y_true,
                                         (const T*)y_pred, (const float*)nullptr, 1, 1.f, 1, 0.f, inv, (T*)dpred, loss_scale,
-                                        n, partials););
+                                        n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
     int rc = check_launch("sv_loss_mae");
-    if (rc) return rc;
+    if (rc || nb == 1) return rc;
     hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
     return check_launch("sv_loss_mae/fold");
 }
@@ -434,13 +490,13 @@ int sv_loss_bce(const void* pred, float label, int from_logits, float* loss_out,
     if (from_logits)
         SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<3, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
                                             (const T*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (T*)dpred,
-                                            loss_scale, n, partials););
+                                            loss_scale, n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
     else
         SV_WITH_T(dtype, hipLaunchKernelGGL((loss_k<2, T>), dim3(nb), dim3(256), 0, to_stream(stream), (const float*)nullptr,
                                             (const T*)pred, (const float*)nullptr, 1, 1.f, 1, label, inv, (T*)dpred,
-                                            loss_scale, n, partials););
+                                            loss_scale, n, partials, loss_out, accumulate, (float*)nullptr, 0.f););
     int rc = check_launch("sv_loss_bce");
-    if (rc) return rc;
+    if (rc || nb == 1) return rc;
     hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, to_stream(stream), partials, nb, inv, loss_out, accumulate);
     return check_launch("sv_loss_bce/fold");
 }

@@ -184,6 +184,20 @@ def fold_scalar(partials, n: int, scale: float, out, accumulate=False, running=N
                              float(running_weight), _stream()), "sv_fold_scalar")
 
 
+def scalar_program(statements):
+    """``statements``: [(out, accumulate, [(term, weight), ...]), ...] - up to 4 scalar statements
+    out = [out +] sum weight * term, run in order by ONE launch (a GAN step's loss bookkeeping)."""
+    import ctypes as C
+    n = len(statements)
+    flat = [tw for _, _, terms in statements for tw in terms]
+    outs = (C.c_void_p * n)(*[_ptr(o) for o, _, _ in statements])
+    acc = (C.c_int * n)(*[int(bool(a)) for _, a, _ in statements])
+    nt = (C.c_int * n)(*[len(t) for _, _, t in statements])
+    terms = (C.c_void_p * max(len(flat), 1))(*[_ptr(t) for t, _ in flat])
+    weights = (C.c_float * max(len(flat), 1))(*[float(w) for _, w in flat])
+    check(lib.sv_scalar_program(n, outs, acc, nt, terms, weights, _stream()), "sv_scalar_program")
+
+
 def convnet_bwd_workspace(arr, n: int, h: int, w: int, n_params: int) -> int:
     return int(lib.sv_convnet_bwd_workspace_bytes(arr, len(arr), n, h, w, n_params))
 

@@ -9,6 +9,7 @@ computed and returned but, as in the reference, never differentiated.
 from __future__ import annotations
 
 import argparse
+import os
 from typing import Tuple
 
 import numpy as np
@@ -19,6 +20,9 @@ from .data import sort_min_diff
 from .losses import BinaryCrossentropy, MeanSquaredError, to_device_f32
 from .nn import as_dtensor, default_device, recording
 from .optimizers import Adam, ExponentialDecay
+
+# A/B switch: fork the two models' updates onto two streams inside the recorded step (default) or keep one chain
+_OVERLAP = os.environ.get("SPECTRUM_GAN_OVERLAP", "1") != "0"
 
 
 # ------------------------------------------------------------------------------------------------ masks
@@ -220,12 +224,8 @@ def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, ove
     p_real, p_fake = p[:bs], p[bs:]
     bce.value_and_grad(1.0, p_real, st.lt, st.d_real, 0.5)
     bce.value_and_grad(0.0, p_fake, st.lf, st.d_fake, 0.5)
-    ops.fill(st.disc_loss, 0.0)
-    ops.axpy(st.disc_loss, st.lt, 0.5)
-    ops.axpy(st.disc_loss, st.lf, 0.5)
-    ops.fill(st.total, 0.0)
-    ops.axpy(st.total, st.l2, l2_weight)
-    ops.axpy(st.total, st.disc_loss, 1.0 - l2_weight)
+    ops.scalar_program([(st.disc_loss, False, [(st.lt, 0.5), (st.lf, 0.5)]),
+                        (st.total, False, [(st.l2, l2_weight), (st.disc_loss, 1.0 - l2_weight)])])
     # discriminator update: gradient of disc_loss w.r.t. the discriminator's weights only
     disc.backward_raw(st.d_both, 0, need_dx=False)
     if not defer_updates:
@@ -269,7 +269,7 @@ def train_step(context_encoder, discriminator, ce_opt, disc_opt, X, mask, l2_wei
             torch.cuda.synchronize()
             st.graph = torch.cuda.CUDAGraph()
             with recording(st.graph):
-                _step_body(ce, disc, ce_opt, disc_opt, st, l2_weight, overlap=True)
+                _step_body(ce, disc, ce_opt, disc_opt, st, l2_weight, overlap=_OVERLAP)
         st.graph.replay()
     return (as_dtensor(st.disc_loss.view(()).clone()), as_dtensor(st.l2.view(()).clone()),
             as_dtensor(st.total.view(()).clone()))

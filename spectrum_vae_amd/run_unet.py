@@ -10,6 +10,7 @@ training tensor as the 1-channel input and the full tensor as the 3-channel targ
 from __future__ import annotations
 
 import argparse
+import os
 from typing import Tuple
 
 import numpy as np
@@ -19,6 +20,9 @@ from . import global_vars, ops, parallel, unet
 from .losses import BinaryCrossentropy, MeanAbsoluteError, MeanSquaredError, to_device_f32
 from .nn import as_dtensor, default_device, recording
 from .optimizers import Adam, ExponentialDecay
+
+# A/B switch: fork the two models' updates onto two streams inside the recorded step (default) or keep one chain
+_OVERLAP = os.environ.get("SPECTRUM_GAN_OVERLAP", "1") != "0"
 
 
 def build_model(input_shape: Tuple[int] = (1, global_vars.NUM_HAPLOTYPES, global_vars.NUM_SNPS,
@@ -126,15 +130,11 @@ def _step_body(gen, disc, gen_opt, disc_opt, st: _StepState, lambda_weight: floa
     # generator loss: BCE(1, D(fake)) + lambda * MAE(y, gen_out)
     bce.value_and_grad(1.0, z_fake, st.l_gan, st.d_gan, 1.0)
     mae.value_and_grad(st.y, gen_out, st.l_l1, st.dgen, float(lambda_weight))
-    ops.fill(st.gen_total, 0.0)
-    ops.axpy(st.gen_total, st.l_gan, 1.0)
-    ops.axpy(st.gen_total, st.l_l1, float(lambda_weight))
     # discriminator loss: BCE(1, D(real)) + BCE(0, D(fake))
     bce.value_and_grad(1.0, z_real, st.l_real, st.d_real, 1.0)
     bce.value_and_grad(0.0, z_fake, st.l_fake, st.d_fake, 1.0)
-    ops.fill(st.disc_loss, 0.0)
-    ops.axpy(st.disc_loss, st.l_real, 1.0)
-    ops.axpy(st.disc_loss, st.l_fake, 1.0)
+    ops.scalar_program([(st.gen_total, False, [(st.l_gan, 1.0), (st.l_l1, float(lambda_weight))]),
+                        (st.disc_loss, False, [(st.l_real, 1.0), (st.l_fake, 1.0)])])
     # (1) GAN term back through the generated half of the discriminator's call to the generated image; the
     #     discriminator's own gradients are not touched (param_grads off), its weights are still those of the forward
     ctx_fake = disc._calls[0].group_view(1)
@@ -195,7 +195,7 @@ def train_step(generator, discriminator, ce_opt, disc_opt, X, y, lambda_weight: 
             torch.cuda.synchronize()
             st.graph = torch.cuda.CUDAGraph()
             with recording(st.graph):
-                _step_body(gen, disc, ce_opt, disc_opt, st, lambda_weight, overlap=True)
+                _step_body(gen, disc, ce_opt, disc_opt, st, lambda_weight, overlap=_OVERLAP)
         st.graph.replay()
     c = lambda t: as_dtensor(t.view(()).clone())  # noqa: E731
     return c(st.disc_loss), c(st.gen_total), c(st.l_gan), c(st.l_l1)

@@ -614,6 +614,32 @@ def test_losses():
     run = torch.full((1,), 3.0, device="cuda")
     ops.loss_mse(dev(t), dev(p), out, part, running=run, running_weight=7.0)
     close(run, np.array([3.0 + 7.0 * np_ops.mse(t, p)]), what="running sum")
+    # a launch of one workgroup finishes the loss itself (no fold launch): accumulate and the running sum as above
+    t1, p1 = t[:1], p[:1]
+    ops.loss_mse(dev(t1), dev(p1), out, part)
+    ops.loss_mse(dev(t1), dev(p1), out, part, accumulate=True, running=run, running_weight=2.0)
+    close(out, np.array([2 * np_ops.mse(t1, p1)]), what="one-workgroup accumulate")
+    close(run, np.array([3.0 + 7.0 * np_ops.mse(t, p) + 4.0 * np_ops.mse(t1, p1)]), what="one-workgroup running sum")
+
+
+def test_scalar_program_equals_fill_and_axpy():
+    """The GAN steps' loss bookkeeping (run_context_encoder.py:246-251) as one launch: the same bits as a fill and an
+    axpy per term, later statements reading earlier results."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(3)
+    lt, lf, l2 = (dev(rng.standard_normal(1)) for _ in range(3))
+    w = 0.999
+    d_ref, t_ref = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+    ops.fill(d_ref, 0.0); ops.axpy(d_ref, lt, 0.5); ops.axpy(d_ref, lf, 0.5)
+    ops.fill(t_ref, 0.0); ops.axpy(t_ref, l2, w); ops.axpy(t_ref, d_ref, 1.0 - w)
+    d, tot = torch.full((1,), 9.0, device="cuda"), torch.full((1,), 9.0, device="cuda")
+    ops.scalar_program([(d, False, [(lt, 0.5), (lf, 0.5)]), (tot, False, [(l2, w), (d, 1.0 - w)])])
+    assert torch.equal(d, d_ref) and torch.equal(tot, t_ref)
+    ops.scalar_program([(tot, True, [(lt, 2.0)])])
+    ops.axpy(t_ref, lt, 2.0)
+    assert torch.equal(tot, t_ref)
+    with pytest.raises(Exception):
+        ops.scalar_program([(d, False, [(lt, 1.0)] * 4)])
 
 
 def test_adam_keras_and_schedule():
