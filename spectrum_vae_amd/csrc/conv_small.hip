@@ -121,6 +121,101 @@ __global__ __launch_bounds__(256) void convt_small_k(const T* __restrict__ x, co
         }
 }
 
+
+// Small launches (fewer 16 x 16 tiles than CUs: the GAN drivers' batch sizes): a thread's chain of scalar filter loads and
+// dependent FMAs is then the whole duration, with nothing else on the CU to hide it.  This form cuts the chain in four:
+// tiles of 8 x 8 pixels (4 x the workgroups), one wave per tile position set, wave v taking channel quad v of every staged
+// pass; the four partial sums of an output meet in LDS.
+template <int K, int S, int CB, typename T>
+__global__ __launch_bounds__(256) void convt_small_split_k(const T* __restrict__ x, const T* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ y, int Hs, int Ws,
+                                                           int Cs, int act, float alpha, int tiles_w, int tiles_per_img) {
+    constexpr int VN = 16 / sizeof(T);
+    constexpr int Q = K / S, PT = (K - S) / 2, HB = Q - 1, HA = (S - 1 + PT) / S, WIN = HB + 1 + HA, TP = 8 + HB + HA;
+    constexpr int NOUT = S * S * CB;  // results per pixel of the tile
+    extern __shared__ float4 smem4[];
+    float* sm = reinterpret_cast<float*>(smem4);
+    const int n = blockIdx.x / tiles_per_img, t = blockIdx.x - n * tiles_per_img;
+    const int th0 = (t / tiles_w) * 8, tw0 = (t % tiles_w) * 8;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ty = lane >> 3, tx = lane & 7;
+    v2f acc[S][S][CB];
+#pragma unroll
+    for (int r = 0; r < S; ++r)
+#pragma unroll
+        for (int c = 0; c < S; ++c)
+#pragma unroll
+            for (int co = 0; co < CB; ++co) acc[r][c][co] = v2f{0.f, 0.f};
+    for (int c0 = 0; c0 < Cs; c0 += kSmallCib) {
+        const int cq = (Cs - c0 < kSmallCib ? Cs - c0 : kSmallCib) >> 2;
+        __syncthreads();
+        for (int u = threadIdx.x; u < TP * TP * (kSmallCib / VN); u += 256) {
+            const int p = u / (kSmallCib / VN), v = u - p * (kSmallCib / VN);
+            const int ph = p / TP, pw = p - ph * TP;
+            const int ih = th0 + ph - HB, iw = tw0 + pw - HB;
+            struct alignas(16) Piece { T v[VN]; } val;
+#pragma unroll
+            for (int e = 0; e < VN; ++e) val.v[e] = (T)0.f;
+            if (v * VN < 4 * cq && ih >= 0 && ih < Hs && iw >= 0 && iw < Ws)
+                val = *reinterpret_cast<const Piece*>(x + (((int64_t)n * Hs + ih) * Ws + iw) * Cs + c0 + VN * v);
+#pragma unroll
+            for (int e4 = 0; e4 < VN / 4; ++e4)
+                *reinterpret_cast<float4*>(sm + p * kSmallPitch + VN * v + 4 * e4) =
+                    make_float4((float)val.v[4 * e4], (float)val.v[4 * e4 + 1], (float)val.v[4 * e4 + 2],
+                                (float)val.v[4 * e4 + 3]);
+        }
+        __syncthreads();
+        const int v = __builtin_amdgcn_readfirstlane(wv);  // wave-uniform by construction: keeps the filter loads scalar
+        if (v < cq) {
+            float4 xq[WIN][WIN];
+#pragma unroll
+            for (int dh = 0; dh < WIN; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < WIN; ++dw)
+                    xq[dh][dw] = *reinterpret_cast<const float4*>(sm + ((ty + dh) * TP + tx + dw) * kSmallPitch + 4 * v);
+            const T* wvp = w + c0 + 4 * v;
+#pragma unroll
+            for (int r = 0; r < S; ++r)
+#pragma unroll
+                for (int jh = 0; jh < Q; ++jh)
+#pragma unroll
+                    for (int c = 0; c < S; ++c)
+#pragma unroll
+                        for (int jw = 0; jw < Q; ++jw) {
+                            const int a = (r + PT) % S + S * jh, b = (c + PT) % S + S * jw;
+                            const float4 xv = xq[HB + (r + PT) / S - jh][HB + (c + PT) / S - jw];
+                            const v2f xlo{xv.x, xv.y}, xhi{xv.z, xv.w};
+#pragma unroll
+                            for (int co = 0; co < CB; ++co) {
+                                v2f wlo, whi;
+                                load_w4(wvp + (int64_t)((a * K + b) * CB + co) * Cs, wlo, whi);
+                                acc[r][c][co] = __builtin_elementwise_fma(xlo, wlo, acc[r][c][co]);
+                                acc[r][c][co] = __builtin_elementwise_fma(xhi, whi, acc[r][c][co]);
+                            }
+                        }
+        }
+    }
+    __syncthreads();  // the last pass has been consumed: the staging area becomes red[wave][result][lane]
+#pragma unroll
+    for (int r = 0; r < S; ++r)
+#pragma unroll
+        for (int c = 0; c < S; ++c)
+#pragma unroll
+            for (int co = 0; co < CB; ++co)
+                sm[(wv * NOUT + (r * S + c) * CB + co) * 64 + lane] = acc[r][c][co].x + acc[r][c][co].y;
+    __syncthreads();
+    const int Hb = Hs * S, Wb = Ws * S;
+    for (int idx = threadIdx.x; idx < 64 * NOUT; idx += 256) {
+        const int o = idx >> 6, l = idx & 63;
+        const int m = th0 + (l >> 3), q = tw0 + (l & 7);
+        if (m >= Hs || q >= Ws) continue;
+        const int co = o % CB, rc = o / CB, r = rc / S, c = rc - r * S;
+        const float z = ((sm[o * 64 + l] + sm[(NOUT + o) * 64 + l]) + (sm[(2 * NOUT + o) * 64 + l] + sm[(3 * NOUT + o) * 64 + l])) +
+                        (bias != nullptr ? bias[co] : 0.f);
+        y[(((int64_t)n * Hb + S * m + r) * Wb + S * q + c) * CB + co] = (T)act_apply(z, act, alpha);
+    }
+}
+
 template <int K, int S, typename T>
 static int launch_small_ks(const sv_conv_geom& g, const T* x, const T* w, const float* bias, T* y, int act, float alpha,
                            hipStream_t st) {
@@ -128,6 +223,26 @@ static int launch_small_ks(const sv_conv_geom& g, const T* x, const T* w, const 
     const int tiles_h = (int)ceil_div(g.Ho, 16), tiles_w = (int)ceil_div(g.Wo, 16);
     const int64_t blocks = (int64_t)g.N * tiles_h * tiles_w;
     if (blocks > (1ll << 30)) return 1;
+    if (blocks < 256) {  // about one workgroup per CU or less: the split form
+        constexpr int TPS = 8 + (Q - 1) + (S - 1 + PT) / S;
+        const int th8 = (int)ceil_div(g.Ho, 8), tw8 = (int)ceil_div(g.Wo, 8);
+        const size_t stage = (size_t)TPS * TPS * kSmallPitch * sizeof(float);
+        const dim3 grid8((unsigned)((int64_t)g.N * th8 * tw8)), block8(256);
+#define SV_SMALL_SPLIT(CBV)                                                                                             \
+    do {                                                                                                                \
+        const size_t red = (size_t)4 * S * S * CBV * 64 * sizeof(float);                                                \
+        hipLaunchKernelGGL((convt_small_split_k<K, S, CBV, T>), grid8, block8, stage > red ? stage : red, st, x, w, bias, \
+                           y, g.Ho, g.Wo, g.Cout, act, alpha, tw8, th8 * tw8);                                          \
+    } while (0)
+        switch (g.Cin) {
+            case 1: SV_SMALL_SPLIT(1); break;
+            case 2: SV_SMALL_SPLIT(2); break;
+            case 3: SV_SMALL_SPLIT(3); break;
+            default: SV_SMALL_SPLIT(4); break;
+        }
+#undef SV_SMALL_SPLIT
+        return check_launch("convt_small_split");
+    }
     const size_t lds = (size_t)TP * TP * kSmallPitch * sizeof(float);
     const dim3 grid((unsigned)blocks), block(256);
     switch (g.Cin) {

@@ -122,6 +122,27 @@ def test_small_image_channel_input_gradient(k, s, cimg, crich, hs, ws):
         close(y, np.tanh(np_ops.conv2d_transpose(dz, w, b, (s, s), "same")), what="transposed forward")
 
 
+@pytest.mark.parametrize("k,s", [(4, 2), (2, 2)])
+def test_small_image_channel_kernel_forms_agree(k, s):
+    """Launches with fewer 16 x 16 tiles than CUs take the form that splits the channels over the four waves of 8 x 8
+    tiles; larger ones the one-pixel-per-thread form.  Same data through both (the first images of a batch of 300 and a
+    batch of those images alone), and the oracle."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(5 + k)
+    n, hs, ws, crich, cimg = 300, 16, 16, 64, 3
+    dz = rng.standard_normal((n, hs, ws, crich)).astype(np.float32)
+    w = (rng.standard_normal((k, k, cimg, crich)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(cimg).astype(np.float32)
+    outs = []
+    for m in (n, 3):
+        gt = ops.deconv_geom(m, hs, ws, crich, k, k, s, s, "same", cimg)
+        y = torch.empty((m, hs * s, ws * s, cimg), device="cuda")
+        ops.conv2d_transpose_fwd(gt, dev(dz[:m]), dev(w), dev(b), y, "tanh", 1.0)
+        outs.append(y.cpu().numpy())
+    np.testing.assert_allclose(outs[0][:3], outs[1], rtol=0, atol=1e-5)  # different summation orders
+    close(torch.from_numpy(outs[1]), np.tanh(np_ops.conv2d_transpose(dz[:3], w, b, (s, s), "same")), what="split form")
+
+
 @pytest.mark.parametrize("cfg", [
     # (kh, kw, s, padding, H, W, cin, cout, n): few result tiles, reductions of hundreds to thousands of terms
     (4, 4, 2, "same", 8, 8, 128, 96, 2), (4, 4, 1, "valid", 4, 4, 128, 200, 5), (4, 4, 2, "same", 4, 4, 256, 64, 3),
