@@ -34,8 +34,10 @@ struct ConvGemmArgs {
     int splits;         // FWD / DGRAD: > 1 cuts the reduction into `splits` ranges over blockIdx.z; raw partial sums go to
     float* slabs;       //              slabs[split][M][N] (indexed like c) and splitk_finish_k applies bias + activation
     int accumulate;     // WGRAD with a single split: c is dw itself and the tile is added to it when set
+    unsigned a_bytes, b_bytes;  // sizes of the A / B tensors: the gathers are range-checked buffer loads
 };
 
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
 constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS row pitch (floats): 64 + 4
 
 // BNT: columns of the result tile.  64: the 4 waves sit 2 x 2, each on 32 x 32 (2 x 2 accumulators);  16 (results with at
@@ -53,6 +55,10 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     __shared__ __attribute__((aligned(16))) float As[BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
     const sv_conv_geom& g = p.g;
+    // Gathers go through buffer descriptors: a dead element (padding, tile edge, end of the reduction) gets an offset
+    // beyond the tensor and comes back as zero, so no load sits behind a branch.
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -118,27 +124,31 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     // ---- per-thread bookkeeping of the A gather (fixed over the reduction loop)
     // 4-byte gathers: FWD / DGRAD thread loads k = t & 15 of rows (t >> 4) + 16 i;  WGRAD: row m = t & 63, reduction (t >> 6) + 4 i
     // 16-byte gathers: FWD / DGRAD thread loads k = 4 (t & 3) .. + 3 of row t >> 2;  WGRAD: rows m = 4 (t & 15) .. + 3, reduction t >> 4
-    int r_img[NR], r_h[NR], r_w[NR];
+    // r_base: element offset of the row's tap-(0, 0), channel-0 operand element (possibly outside the tensor: only
+    // offsets whose bounds test passes are used); a reduction step adds one offset shared by all rows of the thread
+    int r_h[NR], r_w[NR], r_base[NR];
     bool r_ok[NR];
-    int a_kh = 0, a_kw = 0, a_ci = 0;
+    int a_kh = 0, a_kw = 0, a_off = 0;
     bool a_ok = true;
     if (MODE == GEMM_WGRAD) {
         const int m = m0 + (VA ? (t & 15) * 4 : (t & 63));
         a_ok = m < p.M;
         const int tap = a_ok ? fd(m, p.f_ck) : 0;
-        a_ci = a_ok ? m - tap * g.Cin : 0;
+        const int a_ci = a_ok ? m - tap * g.Cin : 0;
         a_kh = fd(tap, p.f_kw);
         a_kw = tap - a_kh * g.KW;
+        a_off = (a_kh * g.W + a_kw) * g.Cin + a_ci;
     } else if (MODE == GEMM_DGRAD) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             // a row of a class reaches output pixel (r_h - jh, r_w - jw) through the class's tap (jh, jw): the divisions by the
             // strides are exact by construction of the class and done once here, not once per reduction step
             const int rl = VA ? (t >> 2) : (t >> 4) + 16 * i;
-            r_img[i] = row_img[rl];
-            r_ok[i] = r_img[i] >= 0;
+            const int img = row_img[rl];
+            r_ok[i] = img >= 0;
             r_h[i] = p.one_out ? 0 : (row_h[rl] + g.pad_t - kh0) / g.SH;
             r_w[i] = p.one_out ? 0 : (row_w[rl] + g.pad_l - kw0) / g.SW;
+            r_base[i] = ((img * g.Ho + r_h[i]) * g.Wo + r_w[i]) * g.Cout;
         }
     } else {
 #pragma unroll
@@ -149,7 +159,8 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             const int img = fd(mm, p.f_howo);
             const int rem = mm - img * p.f_howo.d;
             const int hh = fd(rem, p.f_wo);
-            r_img[i] = img; r_h[i] = hh; r_w[i] = rem - hh * p.f_wo.d;
+            r_h[i] = hh * g.SH - g.pad_t; r_w[i] = (rem - hh * p.f_wo.d) * g.SW - g.pad_l;
+            r_base[i] = ((img * g.H + r_h[i]) * g.W + r_w[i]) * g.Cin;
         }
     }
 
@@ -159,13 +170,19 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = v4f_t{0.f, 0.f, 0.f, 0.f};
 
-    auto ld4 = [](const float* q, bool ok, float* dst) {
-        const float4 v = ok ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    // 16 / 4 bytes at element offset `e` of a tensor, zeros when !ok
+    auto ld4 = [](__amdgpu_buffer_rsrc_t rs, int e, bool ok, float* dst) {
+        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? e * 4 : (int)0x80000000, 0, 0);
+        // the whole vector at once: element-wise bit casts of v.x .. v.w make hipcc (ROCm 7.2) load one dword only
+        const v4f_t f = __builtin_bit_cast(v4f_t, v);
+        dst[0] = f[0]; dst[1] = f[1]; dst[2] = f[2]; dst[3] = f[3];
+    };
+    auto ld1 = [](__amdgpu_buffer_rsrc_t rs, int e, bool ok) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? e * 4 : (int)0x80000000, 0, 0));
     };
     const bool b_lane = BNT == 64 || t < 64;  // 16-byte B gathers of a 16-column tile need 64 threads only
 
-    // global -> registers for one reduction step (issued one step ahead of its use, so the round trip overlaps the MFMAs)
+    // global -> registers for one reduction step (issued ahead of its use, so the round trip overlaps the MFMAs)
     auto gather = [&](int k0, float (&av)[4], float (&bv)[NBR]) {
         // ---- the reduction index this thread decodes (FWD / DGRAD)
         const int kt = k0 + (VA ? (t & 3) * 4 : (t & 15));
@@ -175,30 +192,24 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             const int kk = kok ? kt : 0;
             const int tap = fd(kk, p.f_ck), ci = kk - tap * g.Cin;
             const int kh = fd(tap, p.f_kw), kw = tap - kh * g.KW;
-            if (VA) {
-                const int ih = r_h[0] * g.SH - g.pad_t + kh, iw = r_w[0] * g.SW - g.pad_l + kw;
-                const bool ok = kok && r_ok[0] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                ld4(p.a + (((int64_t)r_img[0] * g.H + ih) * g.W + iw) * g.Cin + ci, ok, av);
-            } else {
+            const int koff = (kh * g.W + kw) * g.Cin + ci;
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    const int ih = r_h[i] * g.SH - g.pad_t + kh, iw = r_w[i] * g.SW - g.pad_l + kw;
-                    const bool ok = kok && r_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                    av[i] = ok ? p.a[(((int64_t)r_img[i] * g.H + ih) * g.W + iw) * g.Cin + ci] : 0.f;
-                }
+            for (int i = 0; i < NR; ++i) {
+                const bool ok = kok && r_ok[i] && (unsigned)(r_h[i] + kh) < (unsigned)g.H && (unsigned)(r_w[i] + kw) < (unsigned)g.W;
+                if (VA) ld4(rs_a, r_base[i] + koff, ok, av);
+                else av[i] = ld1(rs_a, r_base[i] + koff, ok);
             }
         } else if (MODE == GEMM_DGRAD) {
             const bool kok = kt < kend;
             const int kk = kok ? kt : 0;
             const int j = fd(kk, p.f_ck), co = kk - j * g.Cout;  // j: index among the class's taps
             const int jh = p.one_out ? 0 : fd(j, f_nkw), jw = p.one_out ? 0 : j - jh * nkw;
+            const int koff = co - (jh * g.Wo + jw) * g.Cout;
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                const int oh = r_h[i] - jh, ow = r_w[i] - jw;
-                const bool ok = kok && r_ok[i] && oh >= 0 && ow >= 0 && oh < g.Ho && ow < g.Wo;
-                const float* q = p.a + (((int64_t)r_img[i] * g.Ho + oh) * g.Wo + ow) * g.Cout + co;
-                if (VA) ld4(q, ok, av);
-                else av[i] = ok ? *q : 0.f;
+                const bool ok = kok && r_ok[i] && (unsigned)(r_h[i] - jh) < (unsigned)g.Ho && (unsigned)(r_w[i] - jw) < (unsigned)g.Wo;
+                if (VA) ld4(rs_a, r_base[i] + koff, ok, av);
+                else av[i] = ld1(rs_a, r_base[i] + koff, ok);
             }
         } else {
 #pragma unroll
@@ -209,11 +220,11 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
                 const int img = fd(rr, p.f_howo);
                 const int rem = rr - img * p.f_howo.d;
                 const int oh = fd(rem, p.f_wo), ow = rem - oh * p.f_wo.d;
-                const int ih = oh * g.SH - g.pad_t + a_kh, iw = ow * g.SW - g.pad_l + a_kw;
-                const bool ok = rok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                const float* q = p.a + (((int64_t)img * g.H + ih) * g.W + iw) * g.Cin + a_ci;
-                if (VA) ld4(q, ok, av);
-                else av[i] = ok ? *q : 0.f;
+                const int h0 = oh * g.SH - g.pad_t, w0 = ow * g.SW - g.pad_l;
+                const bool ok = rok && (unsigned)(h0 + a_kh) < (unsigned)g.H && (unsigned)(w0 + a_kw) < (unsigned)g.W;
+                const int e = ((img * g.H + h0) * g.W + w0) * g.Cin + a_off;
+                if (VA) ld4(rs_a, e, ok, av);
+                else av[i] = ld1(rs_a, e, ok);
             }
         }
         // ---- gather B
@@ -224,27 +235,27 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             const int j = fd(kk, p.f_ck), co = kk - j * g.Cout;
             const int jh = fd(j, f_nkw), jw = j - jh * nkw;
             const int kh = p.one_out ? kh0 : kh0 + jh * g.SH, kw = p.one_out ? kw0 : kw0 + jw * g.SW;
-            const int tap = kh * g.KW + kw;
+            const int boff = (kh * g.KW + kw) * g.Cin * g.Cout + co;
             if (VB) {
                 const int n = n0 + (t >> 2);
-                ld4(p.b + ((int64_t)tap * g.Cin + n) * g.Cout + co, b_lane && kok && n < p.N, bv);
+                ld4(rs_b, boff + n * g.Cout, b_lane && kok && n < p.N, bv);
             } else {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const int n = n0 + (t >> 4) + 16 * i;
-                    bv[i] = (kok && n < p.N) ? p.b[((int64_t)tap * g.Cin + n) * g.Cout + co] : 0.f;
+                    bv[i] = ld1(rs_b, boff + n * g.Cout, kok && n < p.N);
                 }
             }
         } else if (VB) {
-            const int k = k0 + (BNT == 64 ? (t >> 4) : (t >> 2));
+            const int kr = BNT == 64 ? (t >> 4) : (t >> 2);
             const int n = n0 + (BNT == 64 ? (t & 15) : (t & 3)) * 4;
-            ld4(p.b + (int64_t)k * p.N + n, b_lane && k < kend && n < p.N, bv);
+            ld4(rs_b, k0 * p.N + (kr * p.N + n), b_lane && k0 + kr < kend && n < p.N, bv);
         } else {
             const int n = n0 + (t & (BNT - 1));
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int k = k0 + (t / BNT) + BROWS * i;
-                bv[i] = (k < kend && n < p.N) ? p.b[(int64_t)k * p.N + n] : 0.f;
+                const int kr = (t / BNT) + BROWS * i;
+                bv[i] = ld1(rs_b, k0 * p.N + (kr * p.N + n), k0 + kr < kend && n < p.N);
             }
         }
     };
@@ -362,6 +373,10 @@ bool conv_gemm_shape_ok(const sv_conv_geom& g, int mode, int min_k) {
     const int64_t rdec = mode == GEMM_WGRAD ? kdim : rows, cdec = mode == GEMM_WGRAD ? rows : kdim;
     if (rdec * sp >= (1ll << 32) || cdec * (g.Cin > g.Cout ? g.Cin : g.Cout) >= (1ll << 32)) return false;
     if ((int64_t)g.SH * g.SW > 65535 || (int64_t)g.H * g.W > 65535) return false;  // row classes ride on grid.z
+    // the gathers address the tensors with 32-bit byte offsets, 2^31 being the "no such element" offset
+    const int64_t lim = 1ll << 29;
+    if ((int64_t)g.N * g.H * g.W * g.Cin >= lim || (int64_t)g.N * g.Ho * g.Wo * g.Cout >= lim ||
+        (int64_t)g.KH * g.KW * g.Cin * g.Cout >= lim) return false;
     return ncols >= 1 && kdim >= min_k && rows < (1ll << 30) && kdim < (1ll << 30);
 }
 
@@ -460,6 +475,10 @@ static void fill_common(ConvGemmArgs& p, const sv_conv_geom& g, int mode) {
         p.f_wo = fd_make(g.Wo); p.f_howo = fd_make(g.Ho * g.Wo); p.f_ck = fd_make(g.Cin);
     }
     p.f_kw = fd_make(g.KW);
+    const unsigned bx = (unsigned)((int64_t)g.N * g.H * g.W * g.Cin * 4), bz = (unsigned)((int64_t)g.N * g.Ho * g.Wo * g.Cout * 4);
+    const unsigned bw = (unsigned)((int64_t)g.KH * g.KW * g.Cin * g.Cout * 4);
+    p.a_bytes = mode == GEMM_DGRAD ? bz : bx;
+    p.b_bytes = mode == GEMM_WGRAD ? bz : bw;
 }
 
 // ws / ws_bytes: optional scratch of conv_gemm_splitk_workspace(g, mode) bytes; without it the reduction is not cut
