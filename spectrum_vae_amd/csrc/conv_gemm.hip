@@ -10,6 +10,8 @@
 // 16; the A / B tiles are gathered straight from the NHWC tensors into LDS (k-major, so the MFMA operand reads are
 // conflict-free), each wave holds a 32 x 32 sub-tile as 2 x 2 MFMA accumulators.
 // Lane l of an MFMA feeds A[row l % 16][k l / 16], B[k l / 16][col l % 16] and receives D[4 * (l / 16) + r][l % 16].
+#include <type_traits>
+
 #include "tile_common.h"
 
 namespace sv {
@@ -260,44 +262,53 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
         }
     };
 
-    float av[4], bv[NBR];
-    if (kbeg < kend) gather(kbeg, av, bv);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // Register ring of PF reduction steps: the gather of step s + PF - 1 is issued while step s is multiplied, so a load
+    // has PF - 1 multiply phases to arrive (one phase is 16 MFMAs per wave, shorter than a trip to L2 / HBM; the small
+    // launches of the GAN drivers' batch sizes leave a SIMD one or two waves and nothing else to cover it).
+    constexpr int PF = 3;
+    float av[PF][4], bv[PF][NBR];
+#pragma unroll
+    for (int d = 0; d < PF - 1; ++d) gather(kbeg + d * BK, av[d], bv[d]);  // beyond kend: all pieces dead, zeros
+    // one reduction step out of ring slot D; GATHER: also issue the gather PF - 1 steps ahead (into the slot this step's
+    // predecessor just freed).  Gathers are issued whether or not that step exists (beyond kend every piece is dead): a
+    // fixed number of loads in flight lets the compiler wait for the oldest slot only instead of draining the ring.
+    auto step = [&](auto slot, int k0, bool do_gather) {
+        constexpr int d = decltype(slot)::value;
         __syncthreads();  // the previous step's MFMA reads are done
         if (MODE == GEMM_WGRAD) {
             if (VA) {
-                *reinterpret_cast<float4*>(&As[t >> 4][(t & 15) * 4]) = make_float4(av[0], av[1], av[2], av[3]);
+                *reinterpret_cast<float4*>(&As[t >> 4][(t & 15) * 4]) = make_float4(av[d][0], av[d][1], av[d][2], av[d][3]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) As[(t >> 6) + 4 * i][t & 63] = av[i];
+                for (int i = 0; i < 4; ++i) As[(t >> 6) + 4 * i][t & 63] = av[d][i];
             }
         } else if (VA) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) As[(t & 3) * 4 + i][t >> 2] = av[i];
+            for (int i = 0; i < 4; ++i) As[(t & 3) * 4 + i][t >> 2] = av[d][i];
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) As[t & 15][(t >> 4) + 16 * i] = av[i];
+            for (int i = 0; i < 4; ++i) As[t & 15][(t >> 4) + 16 * i] = av[d][i];
         }
-        if (MODE == GEMM_DGRAD) {
-            if (VB) {
+        if constexpr (MODE == GEMM_DGRAD) {
+            if constexpr (VB) {
                 if (b_lane) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) Bs[(t & 3) * 4 + i][t >> 2] = bv[i];
+                    for (int i = 0; i < 4; ++i) Bs[(t & 3) * 4 + i][t >> 2] = bv[d][i];
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < NB; ++i) Bs[t & 15][(t >> 4) + 16 * i] = bv[i];
+                for (int i = 0; i < NB; ++i) Bs[t & 15][(t >> 4) + 16 * i] = bv[d][i];
             }
-        } else if (VB) {
+        } else if constexpr (VB) {
             if (b_lane)
                 *reinterpret_cast<float4*>(&Bs[BNT == 64 ? (t >> 4) : (t >> 2)][(BNT == 64 ? (t & 15) : (t & 3)) * 4]) =
-                    make_float4(bv[0], bv[1], bv[2], bv[3]);
+                    make_float4(bv[d][0], bv[d][1], bv[d][2], bv[d][3]);
         } else {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) Bs[(t / BNT) + BROWS * i][t & (BNT - 1)] = bv[i];
+            for (int i = 0; i < NB; ++i) Bs[(t / BNT) + BROWS * i][t & (BNT - 1)] = bv[d][i];
         }
         __syncthreads();
-        if (k0 + BK < kend) gather(k0 + BK, av, bv);
+        if (do_gather) gather(k0 + (PF - 1) * BK, av[(d + PF - 1) % PF], bv[(d + PF - 1) % PF]);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float a[TI], b[TJ];
@@ -310,7 +321,19 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    };
+    const int nsteps = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    int k0 = kbeg;
+    for (int it = nsteps / PF; it > 0; --it) {  // whole turns of the ring, no exits inside
+        step(std::integral_constant<int, 0>{}, k0, true);
+        step(std::integral_constant<int, 1>{}, k0 + BK, true);
+        step(std::integral_constant<int, 2>{}, k0 + 2 * BK, true);
+        k0 += PF * BK;
     }
+    static_assert(PF == 3, "the turn above and the tail below are written out for a ring of three");
+    const int rem = nsteps % PF;  // their gathers are in flight already
+    if (rem >= 1) step(std::integral_constant<int, 0>{}, k0, false);
+    if (rem >= 2) step(std::integral_constant<int, 1>{}, k0 + BK, false);
     // ---- epilogue
     float* out = p.c;
     if (MODE == GEMM_WGRAD) out += (size_t)blockIdx.z * p.M * p.N;
