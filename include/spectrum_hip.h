@@ -322,6 +322,16 @@ int sv_loss_mse(const void* y_true, const void* y_pred, const float* weight, int
 /* per-pixel map, reduction="none" (run_context_encoder.py:493-501; run_model.py:361-362): out[p] = w[p]*mean_c(d^2) */
 int sv_loss_mse_map(const void* y_true, const void* y_pred, const float* weight, int weight_stride,
                     float weight_scale, float* out, int64_t n_pix, int C, int dtype, sv_stream_t stream);
+/* Per-sample reconstruction error of the evaluation after training (run_model.py:356-362:
+ * tf.reduce_mean(losses.mse(reconstructions, data), axis=(1, 2))): out[n] = mean over the sample_elems elements of
+ * sample n of (y_pred - y_true)^2.  y_true and out are f32, y_pred has the storage type `dtype`. */
+int sv_sample_mse(const float* y_true, const void* y_pred, float* out, int64_t n_samples, int64_t sample_elems,
+                  int dtype, sv_stream_t stream);
+/* Pair counts of the ROC AUC (run_model.py:390-398: sklearn.metrics.roc_curve + auc with y_true = 1 for the first score
+ * set and 0 for the second, y_pred = the score): counts[0] = #{(i, j): s1[i] > s0[j]}, counts[1] = #{(i, j): s1[i] ==
+ * s0[j]}, so AUC = (counts[0] + counts[1] / 2) / (n1 n0).  counts is two uint64 on the device, cleared by the call. */
+int sv_roc_auc_counts(const float* scores_label1, int64_t n1, const float* scores_label0, int64_t n0,
+                      uint64_t* counts, sv_stream_t stream);
 /* MeanAbsoluteError (run_unet.py:147) */
 int sv_loss_mae(const void* y_true, const void* y_pred, float* loss_out, int accumulate, void* dpred,
                 float loss_scale, int64_t n, float* partials, int dtype, sv_stream_t stream);

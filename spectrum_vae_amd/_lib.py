@@ -112,6 +112,8 @@ SIGNATURES = {
     "sv_loss_workspace_bytes": (_sz, []),
     "sv_loss_mse": (_i, [_p, _p, _p, _i, _f, _p, _i, _p, _f, _i64, _i, _p, _p, _f, _i, _p]),
     "sv_loss_mse_map": (_i, [_p, _p, _p, _i, _f, _p, _i64, _i, _i, _p]),
+    "sv_sample_mse": (_i, [_p, _p, _p, _i64, _i64, _i, _p]),
+    "sv_roc_auc_counts": (_i, [_p, _i64, _p, _i64, _p, _p]),
     "sv_loss_mae": (_i, [_p, _p, _p, _i, _p, _f, _i64, _p, _i, _p]),
     "sv_loss_bce": (_i, [_p, _f, _i, _p, _i, _p, _f, _i64, _p, _i, _p]),
     "sv_adam_keras_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _f, _i, _f, _i, _p, _p, _i, _f, _p, _p, _f,

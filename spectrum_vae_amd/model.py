@@ -734,6 +734,26 @@ class Model(Layer):
         return out.cpu().numpy()
 
 
+    def reconstruction_scores(self, x, batch_size=32) -> torch.Tensor:
+        """Per-sample reconstruction error of an auto-encoder in inference mode, left on the device:
+        ``tf.reduce_mean(losses.mse(model.predict(x), x), axis=(1, 2))`` (run_model.py:356-362) without the
+        reconstructions leaving HBM."""
+        device = default_device()
+        X = self._to_resident(x, device)
+        if not self.built:
+            self.build((None,) + tuple(X.shape[1:]))
+        self._materialize(device)
+        if tuple(self.output_shape_) != tuple(X.shape[1:]):
+            raise ValueError(f"reconstruction_scores: output {self.output_shape_} is not the input shape {tuple(X.shape[1:])}")
+        n, bs = X.shape[0], int(batch_size)
+        scores = torch.empty((n,), dtype=torch.float32, device=device)
+        for start in range(0, n, bs):
+            cur = min(bs, n - start)
+            xb = self._pool.get(("predict", "x"), (cur,) + self.input_shape_)
+            ops.gather_rows(X[start:start + cur], None, xb)
+            ops.sample_mse(xb, self.forward_raw(xb, False), scores[start:start + cur])
+        return scores
+
 class SequentialModel(Model):
     """A Model that is exactly one Sequential stack."""
 

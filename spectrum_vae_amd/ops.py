@@ -434,6 +434,21 @@ def loss_mse_map(y_true, y_pred, out, weight=None, weight_stride=1, weight_scale
                               y_pred.numel() // c, c, _dt(y_pred), _stream()), "sv_loss_mse_map")
 
 
+def sample_mse(y_true, y_pred, out):
+    """out[n] = mean over sample n of (y_pred - y_true)^2 (run_model.py:361-362)."""
+    n = y_pred.shape[0]
+    if y_true.numel() != y_pred.numel() or out.numel() != n:
+        raise ValueError(f"sample_mse: y_true {tuple(y_true.shape)}, y_pred {tuple(y_pred.shape)}, out {tuple(out.shape)}")
+    check(lib.sv_sample_mse(_ptr(y_true), _aptr(y_pred), _ptr(out), n, y_pred.numel() // n, _dt(y_pred), _stream()),
+          "sv_sample_mse")
+
+
+def roc_auc_counts(scores_label1, scores_label0, counts):
+    """counts[0] = #{s1 > s0}, counts[1] = #{s1 == s0} over all pairs (int64 tensor of 2 on the device)."""
+    check(lib.sv_roc_auc_counts(_ptr(scores_label1), scores_label1.numel(), _ptr(scores_label0), scores_label0.numel(),
+                                _ptr(counts, torch.int64, "counts"), _stream()), "sv_roc_auc_counts")
+
+
 def loss_mae(y_true, y_pred, loss_out, partials, dpred=None, loss_scale=1.0, accumulate=False):
     if y_true.numel() != y_pred.numel():
         raise ValueError(f"MAE: y_true {tuple(y_true.shape)} vs y_pred {tuple(y_pred.shape)}")

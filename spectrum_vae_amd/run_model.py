@@ -138,6 +138,34 @@ def roc_auc(neg_scores: np.ndarray, pos_scores: np.ndarray) -> float:
     return float((ranks[labels == 1].sum() - n1 * (n1 + 1) / 2) / (n1 * n0))
 
 
+def reconstruction_scores_device(model, data, batch_size: int = 32):
+    """``reconstruction_scores`` with the forward pass, the squared error and the per-sample mean all on the device;
+    returns a float32 device tensor of one score per sample."""
+    return model.reconstruction_scores(data, batch_size=batch_size)
+
+
+def roc_auc_device(neg_scores, pos_scores) -> float:
+    """``roc_auc`` for score tensors that live on the device: the pair counts (first set's score above / equal to the
+    second set's) are integers formed on the device, only the two counts come back."""
+    import torch
+
+    from . import ops
+    counts = torch.empty(2, dtype=torch.int64, device=neg_scores.device)
+    ops.roc_auc_counts(neg_scores.contiguous(), pos_scores.contiguous(), counts)
+    gt, eq = (int(v) for v in counts.tolist())
+    return (gt + 0.5 * eq) / (neg_scores.numel() * pos_scores.numel())
+
+
+def evaluate_labeled(model, normal_data: np.ndarray, mutator_data: np.ndarray, conv_layers: int = 3,
+                     batch_size: int = 32) -> dict:
+    """The labelled evaluation at the end of run_model.py:349-398 (arrays as ``data/labeled.npz`` holds them under "neg" /
+    "pos"): pad the height, score both sets by reconstruction error, AUC with the normal set as the positive class."""
+    normal = reconstruction_scores_device(model, pad_height(normal_data, conv_layers), batch_size)
+    mutator = reconstruction_scores_device(model, pad_height(mutator_data, conv_layers), batch_size)
+    return {"auc": roc_auc_device(normal, mutator), "normal_loss": normal.cpu().numpy(),
+            "mutator_loss": mutator.cpu().numpy()}
+
+
 def main(args, n_train: int = 4096, log_path: Optional[str] = None):
     rng = np.random.default_rng(global_vars.DEFAULT_SEED)
     train = synth_training_tensor(n_train, global_vars.DEFAULT_SEED)

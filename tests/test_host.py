@@ -177,6 +177,22 @@ def test_run_model_host_helpers():
     assert run_model.pad_height(x, 3).shape[1] % 8 == 0
 
 
+def test_roc_auc_equals_sklearn_roc_curve_auc():
+    """run_model.py:390-398 calls sklearn.metrics.roc_curve + auc (label 1 = the normal set, score = loss); the rank-sum
+    form must give the same area, ties included."""
+    sklearn_metrics = pytest.importorskip("sklearn.metrics")
+    from spectrum_vae_amd import run_model
+    rng = np.random.default_rng(11)
+    for n1, n0, levels in ((1, 1, 3), (7, 5, 4), (200, 333, 50), (64, 64, 0)):
+        a = rng.random(n1) if levels == 0 else rng.integers(0, levels, n1).astype(np.float64) / levels
+        b = rng.random(n0) if levels == 0 else rng.integers(0, levels, n0).astype(np.float64) / levels
+        y_true = np.concatenate((np.ones(n1), np.zeros(n0)))
+        if len(np.unique(y_true)) < 2:
+            continue
+        fpr, tpr, _ = sklearn_metrics.roc_curve(y_true, np.concatenate((a, b)))
+        assert abs(run_model.roc_auc(a, b) - sklearn_metrics.auc(fpr, tpr)) < 1e-12, (n1, n0, levels)
+
+
 # ------------------------------------------------------------------------------------------------ data preparation
 def test_package_dataprep_matches_reference_golden_vectors():
     from spectrum_vae_amd import data
