@@ -1300,7 +1300,13 @@ static void fill_wgrad_args(WgradArgs& a, const WgradPlan& p, const float* x, co
 }
 
 // Kernel (+ bias) gradients of up to kMaxWgradJobs layers: one launch for the partial sums, one for the reductions.
+int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st);  // wgrad_nhwc.hip
+
 int launch_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, hipStream_t st) {
+    if (reduce) {  // the channel-last matrix-core kernel when every layer of the batch is in its family
+        const int rc = launch_wgrad_nhwc_batch(jobs, n_jobs, st);
+        if (rc <= 0) return rc;
+    }
     WgradMultiArgs m{};
     ReduceMultiArgs rm{};
     m.n_jobs = rm.n_jobs = n_jobs;

@@ -415,8 +415,11 @@ class Model(Layer):
             nb = self.wgrad_batch_blocks if len(ctx.wgrad_jobs) >= 3 else 0
             for j in ctx.wgrad_jobs:  # layers with large images: fewer workgroups, each staging more samples
                 j["blocks"] = (self.wgrad_batch_blocks_large if j["g"].H * j["g"].W >= 256 else nb) if nb else 0
-            ops.conv2d_wgrad_batch(ctx.wgrad_jobs, reduce=False, blocks=nb)
-            ops.conv2d_wgrad_finish(ctx.wgrad_finish + [(j["g"], j["ws"], j["dw"], j["db"], j["blocks"]) for j in ctx.wgrad_jobs])
+            if not ctx.wgrad_finish:  # nothing else waits for the finishing launch: the batch sums its own slabs
+                ops.conv2d_wgrad_batch(ctx.wgrad_jobs, reduce=True, blocks=nb)
+            else:
+                ops.conv2d_wgrad_batch(ctx.wgrad_jobs, reduce=False, blocks=nb)
+                ops.conv2d_wgrad_finish(ctx.wgrad_finish + [(j["g"], j["ws"], j["dw"], j["db"], j["blocks"]) for j in ctx.wgrad_jobs])
             ctx.wgrad_jobs = None
             return dx
         return self.backward(ctx, dy, need_dx=need_dx)
