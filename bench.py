@@ -104,7 +104,7 @@ class OpTimer:
                     q = arr[i].g
                     fl += 2 * q.N * q.Ho * q.Wo * q.Cout * q.KH * q.KW * q.Cin
                 info = {"jobs": nj, "flops": fl, "single_launch": not args[2]}
-            elif name == "sv_convnet_fwd":
+            elif name in ("sv_convnet_fwd", "sv_convnet_fwd_mse"):
                 arr, nl, n, h, w = args[0], args[1], args[2], args[3], args[4]
                 fl = 0
                 for i in range(nl):
@@ -128,9 +128,9 @@ def kernel_of_call(name: str, g):
     """(rocprof kernel name, algorithmic FLOPs) of a C-ABI call that is exactly ONE kernel launch, else None."""
     if g is None:
         return None
-    if name == "sv_convnet_fwd":
+    if name in ("sv_convnet_fwd", "sv_convnet_fwd_mse"):
         return "net_fwd_s1<3>", float(g["flops"])
-    if name == "sv_conv2d_wgrad_batch":
+    if name == "sv_conv2d_wgrad_batch":  # with its own reduction the call is two launches: not a single kernel's time
         return ("wgrad_s1_multi<3>", float(g["flops"])) if g["single_launch"] else None
     if "KH" not in g:
         return None
@@ -139,6 +139,9 @@ def kernel_of_call(name: str, g):
     if name == "sv_conv2d_bwd_partial":
         return f"wgrad_s1_lds<{k}, {8 if (k == 3 and g['Cout'] > 4) else 4}>", fl
     if name == "sv_conv2d_bwd" and g.get("half") == "dgrad":
+        if k == 3 and (g["Cout"], g["Cin"], g["W"]) in ((3, 8, 32), (8, 16, 16), (16, 32, 8), (32, 16, 8), (16, 8, 16)) \
+                and os.environ.get("SPECTRUM_DGRAD_NHWC", "1")[0] != "0":
+            return f"dgrad_nhwc<{g['Cout']}, {g['Cin']}, {g['W']}>", fl
         epi = 2 if g["up_h"] == 2 else 0
         return f"conv_s1_lds<{k}, 1, {8 if g['Cin'] > 4 else 4}, {epi}>", fl
     if name == "sv_conv2d_pool_fwd":

@@ -39,6 +39,8 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
                        float zalpha = 0.f, int defer = 0, int with_bias = 0);
 int launch_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, hipStream_t st);
 int launch_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, hipStream_t st);
+int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
+                      int act, float alpha, hipStream_t st);
 
 // Stride-1 SAME conv with an odd square kernel and an isotropic folded upsampling: the LDS-tiled family.
 static bool tiled_shape(const sv_conv_geom& g) {
@@ -185,6 +187,9 @@ int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const voi
         if (rc) return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: shape not covered") : rc;
     }
     if (dx == nullptr) return SV_OK;
+    rc = launch_dgrad_nhwc(*g, (const float*)w, (const float*)dy, (const float*)y, idx, (float*)dx, act, alpha,
+                           to_stream(stream));  // the channel-last matrix-core kernel for the layer shapes it covers
+    if (rc <= 0) return rc;
     rc = launch_tiled_s1((const float*)dy, (const float*)w, nullptr, (float*)dx, nullptr, g->N, g->H, g->W, g->Cout,
                          g->Cin, g->KH, 1, 1, g->up_h == 2 ? 2 : 0, SV_ACT_NONE, 0.f, to_stream(stream), zmode,
                          (const float*)y, idx, act, alpha);

@@ -1,0 +1,315 @@
+// Input gradients of 3x3 stride-1 SAME convs with few channels on the f32 matrix cores, channel-last LDS image (the
+// activation-gradient chain of the tape in run_model.py:281-289 through the conv stack of autoencoder.py:437-526).
+//
+//   dx[p][ci] = sum over taps (kh, kw) and co of dz[p - (kh - 1, kw - 1)][co] * w[kh][kw][ci][co]
+//
+// as a GEMM with the input channels as rows (the filters are the A operand and stay in registers for the whole
+// launch), 16 pixels (a 2 x 8 patch) as columns and (tap, co) as the reduction.  dz = dy * act'(y), scattered through the
+// pooling argmax where the layer was pooled, is formed while it is copied into an NHWC LDS image with a zero halo; a
+// lane's B operand for 4 (2 for 8-channel dz) consecutive reduction steps is ONE 16-byte (8-byte) read of consecutive
+// channels of its pixel, at a per-tile base plus a compile-time tap offset.  The result tile holds 4 consecutive
+// channels of a pixel per lane: it is stored as 16-byte pieces in NHWC order, after the 2 x 2 sum (two DPP adds) when
+// the conv read its input through nearest upsampling.  No partial sums leave the workgroup: results are exact sums in
+// a fixed order.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "tile_common.h"
+
+namespace sv {
+
+typedef float dn_v4f __attribute__((ext_vector_type(4)));
+
+struct DnArgs {
+    const float* dy;      // zmode 1: [N][H][W][CZ];  zmode 2: [N][H/2][W/2][CZ]
+    const float* zy;      // activation output, extents of dy
+    const uint8_t* zidx;  // zmode 2: argmax slot of every pooling window
+    const float* w;       // [3][3][CX][CZ]: the forward conv's HWIO filters (CX input, CZ output channels)
+    float* dx;            // up == 1: [N][H][W][CX];  up == 2: [N][H/2][W/2][CX], the sums over 2x2 windows
+    int N, H, up, zmode, ns, tps_log;  // tps_log: log2 of the (H / 2) * (W / 8) pixel tiles per sample
+    ActGradCoef zk;
+};
+
+constexpr int kDnUnits = 4;  // 16-byte pieces per thread and pass held in registers between load and store
+
+__device__ __forceinline__ float dn_dpp_xor1(float v) {  // value of lane ^ 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dn_dpp_ror8(float v) {  // value of lane ^ 8 (rotation by 8 inside a row of 16 lanes)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+}
+
+template <int CZ, int CX, int WO>
+__global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
+    constexpr int MT = (CX + 15) / 16;
+    constexpr int VEC = CZ == 3 ? 1 : (CZ == 8 ? 2 : 4);          // dz channels per lane and read
+    constexpr int NH = CZ == 3 ? 1 : CZ / (4 * VEC);              // reads per tap
+    constexpr int NSTEP = CZ == 3 ? 7 : 9 * NH;                   // reads per pixel tile
+    constexpr int SW = WO + 2, TX = WO / 8;
+    constexpr bool PING = NSTEP * VEC <= 36;                      // operand registers of two tiles fit
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int pr = li >> 3, pc = li & 7;
+    const int H = a.H;
+    const int sampleZ = (H + 2) * SW * CZ;
+
+    // ---- staging of dz: source extents, registers of the pass in flight
+    const int zmode = a.zmode;
+    const int s_h = zmode == 2 ? H >> 1 : H, s_w = zmode == 2 ? WO >> 1 : WO;
+    const int s_sample = s_h * s_w * CZ;
+    const FDiv f_hw = fd_make(s_h * s_w), f_w = fd_make(s_w);
+    float4 rv[kDnUnits], ry[kDnUnits];
+    uint32_t rk[kDnUnits];
+    auto load_pass = [&](int n0) {
+        const int ns = min(a.ns, a.N - n0);
+        const int su = (ns * s_sample) >> 2;
+        const size_t sb = (size_t)n0 * s_sample;
+#pragma unroll
+        for (int i = 0; i < kDnUnits; ++i) {
+            const int u = min((int)threadIdx.x + i * 256, su - 1);
+            rv[i] = *reinterpret_cast<const float4*>(a.dy + sb + 4 * (size_t)u);
+            ry[i] = *reinterpret_cast<const float4*>(a.zy + sb + 4 * (size_t)u);
+            rk[i] = zmode == 2 ? *reinterpret_cast<const uint32_t*>(a.zidx + sb + 4 * (size_t)u) : 0u;
+        }
+    };
+    auto store_pass = [&](int ns) {
+        const int su = (ns * s_sample) >> 2;
+#pragma unroll
+        for (int i = 0; i < kDnUnits; ++i) {
+            const int u = threadIdx.x + i * 256;
+            if (u >= su) continue;
+            float4 v = rv[i];
+            v.x *= act_grad_q(ry[i].x, a.zk); v.y *= act_grad_q(ry[i].y, a.zk);
+            v.z *= act_grad_q(ry[i].z, a.zk); v.w *= act_grad_q(ry[i].w, a.zk);
+            const int e = 4 * u;
+            if (CZ % 4 == 0) {
+                const int p = e / CZ, c = e - p * CZ;
+                const int ss = fd(p, f_hw), pp = p - ss * (s_h * s_w);
+                const int row = fd(pp, f_w), col = pp - row * s_w;
+                if (zmode != 2) {
+                    *reinterpret_cast<float4*>(smem + ss * sampleZ + ((row + 1) * SW + col + 1) * CZ + c) = v;
+                } else {
+                    float* q = smem + ss * sampleZ + ((2 * row + 1) * SW + 2 * col + 1) * CZ + c;
+                    const uint32_t k = rk[i];
+                    const uint32_t k0 = k & 0xff, k1 = (k >> 8) & 0xff, k2 = (k >> 16) & 0xff, k3 = k >> 24;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float4 o = make_float4(k0 == (uint32_t)s ? v.x : 0.f, k1 == (uint32_t)s ? v.y : 0.f,
+                                                     k2 == (uint32_t)s ? v.z : 0.f, k3 == (uint32_t)s ? v.w : 0.f);
+                        *reinterpret_cast<float4*>(q + ((s >> 1) * SW + (s & 1)) * CZ) = o;
+                    }
+                }
+            } else {  // 3 channels, never pooled here: the 4 floats of a piece belong to 1 or 2 pixels
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int p = (e + t) / CZ, c = (e + t) - p * CZ;
+                    const int ss = fd(p, f_hw), pp = p - ss * (s_h * s_w);
+                    const int row = fd(pp, f_w), col = pp - row * s_w;
+                    smem[ss * sampleZ + ((row + 1) * SW + col + 1) * CZ + c] = vv[t];
+                }
+            }
+        }
+    };
+
+    // ---- the filters as A operands: row m = mt * 16 + li is input channel ci, reduction slot lk of read (tap, h) and
+    // element j is output channel h * 4 VEC + VEC * lk + j of tap (a, b) = mirrored (kh, kw)
+    float wreg[NSTEP][VEC][MT];
+    int zoff[CZ == 3 ? NSTEP : 1];  // 3 channels: reduction index kk = 4 s + lk walks (a, b, co) flattened
+    if (CZ == 3) {
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int kk = 4 * s + lk;
+            const bool ok = kk < 27;
+            const int k2 = ok ? kk : 0;
+            const int ta = k2 / 9, rem = k2 - ta * 9, tb = rem / 3, co = rem - tb * 3;
+            zoff[s] = ta * SW * CZ + rem;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ci = mt * 16 + li;
+                wreg[s][0][mt] = (ok && ci < CX) ? a.w[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co] : 0.f;
+            }
+        }
+    } else {
+        zoff[0] = 0;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int tap = s / NH, h = s - tap * NH;
+            const int ta = tap / 3, tb = tap - ta * 3;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int ci = mt * 16 + li;
+                    const int co = h * 4 * VEC + VEC * lk + j;
+                    wreg[s][j][mt] = ci < CX ? a.w[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co] : 0.f;
+                }
+        }
+    }
+    const int lz = (pr * SW + pc) * CZ + (CZ == 3 ? 0 : VEC * lk);  // the lane's pixel (and channel group) inside a tile
+
+    int n0 = blockIdx.x * a.ns;
+    if (n0 < a.N) load_pass(n0);
+    {
+        const int total = (a.ns * sampleZ + 3 + 16) >> 2;
+        for (int i = threadIdx.x; i < total; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int tps_log = a.tps_log, tps_mask = (1 << tps_log) - 1;
+    for (; n0 < a.N; n0 += gridDim.x * a.ns) {
+        const int ns = min(a.ns, a.N - n0);
+        __syncthreads();
+        store_pass(ns);
+        __syncthreads();
+        if (n0 + (int)gridDim.x * a.ns < a.N) load_pass(n0 + gridDim.x * a.ns);
+
+        const int ntile = (ns << tps_log) >> 2;  // tiles of this wave: tps is a multiple of 4
+        float zv0[NSTEP][VEC], zv1[NSTEP][VEC];
+        auto tile_pos = [&](int i, int& ss, int& oh, int& ow0) {
+            const int t = wave + 4 * i;
+            ss = t >> tps_log;
+            const int q = t & tps_mask;
+            oh = (q / TX) * 2;
+            ow0 = (q % TX) * 8;
+        };
+        auto load_tile = [&](float (&zv)[NSTEP][VEC], int i) {
+            int ss, oh, ow0;
+            tile_pos(i, ss, oh, ow0);
+            const float* zq = smem + ss * sampleZ + (oh * SW + ow0) * CZ + lz;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (CZ == 3) {
+                    zv[s][0] = zq[zoff[s]];
+                } else {
+                    const int tap = s / NH, h = s - tap * NH;
+                    const float* q = zq + ((tap / 3) * SW + tap % 3) * CZ + h * 4 * VEC;
+                    if (VEC == 2) {
+                        const float2 v = *reinterpret_cast<const float2*>(q);
+                        zv[s][0] = v.x; zv[s][VEC - 1] = v.y;
+                    } else {
+                        const float4 v = *reinterpret_cast<const float4*>(q);
+                        zv[s][0] = v.x; zv[s][1 % VEC] = v.y; zv[s][2 % VEC] = v.z; zv[s][3 % VEC] = v.w;
+                    }
+                }
+            }
+        };
+        auto mfma_tile = [&](const float (&zv)[NSTEP][VEC], int i, bool live) {
+            dn_v4f acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = dn_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][j][mt], zv[s][j], acc[mt], 0, 0, 0);
+            int ss, oh, ow0;
+            tile_pos(i, ss, oh, ow0);
+            if (!live) return;  // the second tile of the last pair when a wave's tile count is odd
+            // lane (li, lk) holds input channels mt * 16 + 4 lk .. + 3 of pixel (oh + pr, ow0 + pc)
+            if (a.up == 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[mt][r];
+                        v += dn_dpp_xor1(v);
+                        v += dn_dpp_ror8(v);
+                        acc[mt][r] = v;
+                    }
+                if (pr == 0 && (pc & 1) == 0) {
+                    float* o = a.dx + (((size_t)(n0 + ss) * (H >> 1) + (oh >> 1)) * (WO >> 1) + ((ow0 + pc) >> 1)) * CX;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        if (mt * 16 + 4 * lk < CX)
+                            *reinterpret_cast<float4*>(o + mt * 16 + 4 * lk) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+                }
+            } else {
+                float* o = a.dx + (((size_t)(n0 + ss) * H + oh + pr) * WO + ow0 + pc) * CX;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (mt * 16 + 4 * lk < CX)
+                        *reinterpret_cast<float4*>(o + mt * 16 + 4 * lk) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+            }
+        };
+        if constexpr (PING) {
+            // tiles in pairs, the reads of the next tile issued before the current tile's matrix instructions; an odd
+            // count repeats the last tile's arithmetic and drops its stores, so the loop body has no branch before them
+            load_tile(zv0, 0);
+            for (int i = 0; i < ntile; i += 2) {
+                const bool two = i + 1 < ntile;
+                load_tile(zv1, two ? i + 1 : i);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(zv0, i, true);
+                __builtin_amdgcn_sched_barrier(0);
+                load_tile(zv0, min(i + 2, ntile - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(zv1, two ? i + 1 : i, two);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int i = 0; i < ntile; ++i) {
+                load_tile(zv0, i);
+                mfma_tile(zv0, i, true);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- host side
+template <int CZ, int CX, int WO>
+static int dn_launch(const DnArgs& a, int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    return check_launch("dgrad_nhwc");
+}
+
+// dx of the conv described by g (its input gradient), dz formed from (dy, y, idx).  1: shape outside this family (the
+// caller takes the planar kernels); 0: launched; < 0: error.
+int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
+                      int act, float alpha, hipStream_t st) {
+    if (const char* e = std::getenv("SPECTRUM_DGRAD_NHWC"))
+        if (e[0] == '0') return 1;
+    if (g.KH != 3 || g.KW != 3 || g.SH != 1 || g.SW != 1 || g.up_h != g.up_w || (g.up_h != 1 && g.up_h != 2)) return 1;
+    if (g.Ho != g.H || g.Wo != g.W || g.pad_t != 1 || g.pad_l != 1) return 1;
+    const int H = g.H, W = g.W, CZ = g.Cout, CX = g.Cin;
+    const int zmode = idx != nullptr ? 2 : 1;
+    int shape;
+    if (CZ == 3 && CX == 8 && W == 32) shape = 0;
+    else if (CZ == 8 && CX == 16 && W == 16) shape = 1;
+    else if (CZ == 16 && CX == 32 && W == 8) shape = 2;
+    else if (CZ == 32 && CX == 16 && W == 8) shape = 3;
+    else if (CZ == 16 && CX == 8 && W == 16) shape = 4;
+    else return 1;
+    if (CZ == 3 && zmode == 2) return 1;
+    if ((H & 1) || y == nullptr) return 1;
+    const int tps = (H / 2) * (W / 8);
+    if (tps < 4 || (tps & (tps - 1))) return 1;
+    const int64_t sampleZ = (int64_t)(H + 2) * (W + 2) * CZ;
+    const int64_t units = (zmode == 2 ? (int64_t)(H / 2) * (W / 2) * CZ : (int64_t)H * W * CZ) / 4;
+    auto lds = [&](int ns) { return (size_t)(ns * sampleZ + 3 + 16) / 4 * 16; };
+    // workgroups: two per CU where a sample holds many pixel tiles (the 32- and 16-wide images with 8-channel dz or less),
+    // one per CU for the 8-wide images, where a second one only repeats the filter loads (measured at batch 1024)
+    int grid = (shape == 0 || shape == 1) ? 512 : 256;
+    if (const char* e = std::getenv("SPECTRUM_DGRAD_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+    if (grid > g.N) grid = g.N;
+    int ns = 1;
+    while (ns < 8 && lds(ns + 1) <= 64 * 1024 && (ns + 1) * units <= 256 * kDnUnits && (int64_t)(ns + 1) * grid * 2 <= g.N) ++ns;
+    if (lds(ns) > 64 * 1024 || ns * units > 256 * kDnUnits) return 1;
+    if ((int64_t)grid * ns > g.N) grid = (g.N + ns - 1) / ns;
+    DnArgs a{};
+    a.dy = dy; a.zy = y; a.zidx = idx; a.w = w; a.dx = dx;
+    a.N = g.N; a.H = H; a.up = g.up_h; a.zmode = zmode; a.ns = ns; a.tps_log = __builtin_ctz(tps);
+    a.zk = act_grad_coef(act, alpha);
+    const size_t bytes = lds(ns);
+    switch (shape) {
+        case 0: return dn_launch<3, 8, 32>(a, grid, bytes, st);
+        case 1: return dn_launch<8, 16, 16>(a, grid, bytes, st);
+        case 2: return dn_launch<16, 32, 8>(a, grid, bytes, st);
+        case 3: return dn_launch<32, 16, 8>(a, grid, bytes, st);
+        default: return dn_launch<16, 8, 16>(a, grid, bytes, st);
+    }
+}
+
+}  // namespace sv

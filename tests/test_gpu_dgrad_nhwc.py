@@ -1,0 +1,68 @@
+"""The channel-last matrix-core input-gradient kernel (the dx half of sv_conv2d_bwd on the layer shapes of the CAEPadded
+run_model.py defaults, autoencoder.py:437-526) against a float64 evaluation of
+dx[p, ci] = sum dz[p - (kh - 1, kw - 1), co] * w[kh, kw, ci, co] (summed over 2x2 windows where the conv read its input
+through nearest upsampling), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_wgrad_nhwc import act_grad
+
+pytestmark = pytest.mark.gpu
+
+# (stored h, stored w, Cin, Cout, upsampling of the input, pooled output, activation): every layer but the first
+LAYERS = [(16, 16, 8, 16, 1, True, "elu"), (8, 8, 16, 32, 1, True, "elu"), (4, 4, 32, 16, 2, False, "elu"),
+          (8, 8, 16, 8, 2, False, "elu"), (16, 16, 8, 3, 2, False, "tanh")]
+
+
+def reference(w, dy, y, idx, up, act):
+    g = dy.astype(np.float64) * act_grad(y.astype(np.float64), act)
+    if idx is not None:
+        n, ph, pw, c = g.shape
+        dz = np.zeros((n, 2 * ph, 2 * pw, c))
+        for s in range(4):
+            dz[:, (s >> 1)::2, (s & 1)::2, :] = np.where(idx == s, g, 0.0)
+    else:
+        dz = g
+    n, H, W, _ = dz.shape
+    zp = np.pad(dz, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    dx = np.zeros((n, H, W, w.shape[2]))
+    for kh in range(3):
+        for kw in range(3):
+            # x[p + (kh - 1, kw - 1)] feeds z[p]: dx[q] += dz[q - (kh - 1, kw - 1)] . w[kh, kw]
+            dx += zp[:, 2 - kh:2 - kh + H, 2 - kw:2 - kw + W, :] @ w[kh, kw].astype(np.float64).T
+    if up == 2:
+        dx = dx.reshape(n, H // 2, 2, W // 2, 2, -1).sum(axis=(2, 4))
+    return dx
+
+
+@pytest.mark.parametrize("n", [1, 3, 7, 130, 1024, 1027])
+@pytest.mark.parametrize("spec", LAYERS, ids=[f"{s[2]}to{s[3]}" for s in LAYERS])
+def test_matches_float64(spec, n, monkeypatch):
+    from spectrum_vae_amd import ops
+    monkeypatch.delenv("SPECTRUM_DGRAD_NHWC", raising=False)
+    h, w_, cin, cout, up, pooled, act = spec
+    H, W = h * up, w_ * up
+    rng = np.random.default_rng(n + cin * 7)
+    g = ops.conv_geom(n, H, W, cin, 3, 3, 1, 1, "same", cout, (up, up))
+    oh, ow = (H // 2, W // 2) if pooled else (H, W)
+    wt = rng.standard_normal((3, 3, cin, cout)).astype(np.float32)
+    y = rng.standard_normal((n, oh, ow, cout)).astype(np.float32)
+    if act == "tanh":
+        y = np.tanh(y)
+    dy = rng.standard_normal((n, oh, ow, cout)).astype(np.float32)
+    idx = rng.integers(0, 4, (n, oh, ow, cout)).astype(np.uint8) if pooled else None
+    dx = torch.full((n, h, w_, cin), 7.0, device="cuda")
+    args = (g, None, torch.from_numpy(wt).cuda(), torch.from_numpy(dy).cuda(), torch.from_numpy(y).cuda(),
+            torch.from_numpy(idx).cuda() if pooled else None, dx, None, None, act, 1.0, None)
+    ops.conv2d_bwd(*args)
+    want = reference(wt, dy, y, idx, up, act)
+    err = float(np.abs(dx.cpu().numpy() - want).max() / np.abs(want).max())
+    assert err < 2e-6, err
+    first = dx.clone()
+    dx.fill_(-3.0)
+    ops.conv2d_bwd(*args)
+    assert torch.equal(dx, first)  # overwrites, bit-reproducible
+    monkeypatch.setenv("SPECTRUM_DGRAD_NHWC", "0")  # the planar kernels on the same call
+    ops.conv2d_bwd(*args)
+    assert float((dx - first).abs().max()) <= 4e-6 * float(first.abs().max())
