@@ -289,9 +289,10 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     const int64_t sampleZ = (int64_t)(H + 2) * (W + 2) * CZ;
     const int64_t units = (zmode == 2 ? (int64_t)(H / 2) * (W / 2) * CZ : (int64_t)H * W * CZ) / 4;
     auto lds = [&](int ns) { return (size_t)(ns * sampleZ + 3 + 16) / 4 * 16; };
-    // workgroups: two per CU where a sample holds many pixel tiles (the 32- and 16-wide images with 8-channel dz or less),
-    // one per CU for the 8-wide images, where a second one only repeats the filter loads (measured at batch 1024)
-    int grid = (shape == 0 || shape == 1) ? 512 : 256;
+    // workgroups (measured at batch 1024): one sample each for the 32-wide 3-channel image (few registers, 14 KB of LDS:
+    // four workgroups share a CU and hide each other's load latencies), two per CU for the 16-wide image with 8-channel
+    // dz, one per CU elsewhere, where more workgroups only repeat the filter loads
+    int grid = shape == 0 ? 1024 : (shape == 1 ? 512 : 256);
     if (const char* e = std::getenv("SPECTRUM_DGRAD_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if (grid > g.N) grid = g.N;
     int ns = 1;
