@@ -401,6 +401,16 @@ int sv_gather_rows(const void* src, int src_is_f64, const int64_t* idx, float* d
  * (seed, offset + (n << 20) + 2d [+ 1]), so a mask is a pure function of the arguments. */
 int sv_random_block_mask(float* mask, int N, int H, int W, int C, double pct_mask, uint64_t seed, uint64_t offset,
                          sv_stream_t stream);
+/* The masked input of the context encoder folded into its first convolution (run_context_encoder.py:242-243:
+ * `X_masked = X * (1 - mask)`, `pred = context_encoder(X_masked)`): the forward conv and its kernel gradient read x as
+ * x * (1 - mask), mask laid out like x, while they gather it; the masked tensor never exists in memory.  Same results as
+ * sv_mask_input followed by sv_conv2d_fwd_ws / sv_conv2d_wgrad, bit for bit.  Geometries of the implicit-GEMM family
+ * only (sv_conv2d_masked_supported; strided convs with a reduction of >= 16 terms), f32. */
+int sv_conv2d_masked_supported(const sv_conv_geom* g);
+int sv_conv2d_fwd_masked(const sv_conv_geom* g, const void* x, const void* mask, const void* w, const void* bias, void* y,
+                         int act, float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
+int sv_conv2d_wgrad_masked(const sv_conv_geom* g, const void* x, const void* mask, const void* dz, void* dw, int accumulate,
+                           void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
 /* y = x * (1 - mask) (run_context_encoder.py:242) */
 int sv_mask_input(const float* x, const float* mask, float* y, int64_t n, sv_stream_t stream);
 /* the same with y in the storage type `dtype` (the masked input of a bf16 model) */

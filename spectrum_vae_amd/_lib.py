@@ -125,6 +125,9 @@ SIGNATURES = {
     "sv_adam_keras_prepare": (_i, [_p, _f, _f, _f, _i, _f, _i, _p]),
     "sv_adam_keras_apply": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),
     "sv_gather_rows": (_i, [_p, _i, _p, _p, _i64, _i64, _p]),
+    "sv_conv2d_masked_supported": (_i, [_g]),
+    "sv_conv2d_fwd_masked": (_i, [_g, _p, _p, _p, _p, _p, _i, _f, _p, _sz, _i, _p]),
+    "sv_conv2d_wgrad_masked": (_i, [_g, _p, _p, _p, _p, _i, _p, _sz, _i, _p]),
     "sv_mask_input": (_i, [_p, _p, _p, _i64, _p]),
     "sv_random_block_mask": (_i, [_p, _i, _i, _i, _i, C.c_double, _u64, _u64, _p]),
     "sv_mask_input_dt": (_i, [_p, _p, _p, _i64, _i, _p]),

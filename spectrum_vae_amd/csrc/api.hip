@@ -16,7 +16,10 @@ int launch_dgrad_direct(const sv_conv_geom& g, const float* dz, const float* w, 
                         int act, float alpha, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 size_t wgrad_direct_workspace(const sv_conv_geom& g);
 int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, float* dw, int accumulate, void* ws,
-                        size_t ws_bytes, hipStream_t st);
+                        size_t ws_bytes, hipStream_t st, const float* xmask = nullptr);
+bool conv_masked_supported(const sv_conv_geom& g);
+int launch_fwd_masked(const sv_conv_geom& g, const float* x, const float* mask, const float* w, const float* bias, float* y,
+                      int act, float alpha, hipStream_t st, void* ws, size_t ws_bytes);
 // bf16 storage: activations / filters / activation gradients bf16, bias and kernel gradients f32
 int launch_fwd_bf16(const sv_conv_geom& g, const void* x, const void* w, const float* bias, void* y, int act, float alpha,
                     hipStream_t st, void* ws, size_t ws_bytes);
@@ -113,6 +116,33 @@ int sv_conv2d_dgrad_ws(const sv_conv_geom* g, const void* dz, const void* w, voi
     }
     return launch_dgrad_direct(*g, (const float*)dz, (const float*)w, nullptr, (float*)dx, SV_ACT_NONE, 0.f,
                                to_stream(stream), workspace, workspace_bytes);
+}
+
+int sv_conv2d_masked_supported(const sv_conv_geom* g) {
+    if (validate_geom(g, "sv_conv2d_masked_supported")) return 0;
+    return g->up_h == 1 && g->up_w == 1 && !tiled_shape(*g) && conv_masked_supported(*g) ? 1 : 0;
+}
+
+int sv_conv2d_fwd_masked(const sv_conv_geom* g, const void* x, const void* mask, const void* w, const void* bias, void* y,
+                         int act, float alpha, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_fwd_masked");
+    int rc = validate_geom(g, "sv_conv2d_fwd_masked");
+    if (rc) return rc;
+    SV_REQUIRE(x && mask && w && y, "sv_conv2d_fwd_masked: null tensor");
+    SV_REQUIRE(sv_conv2d_masked_supported(g), "sv_conv2d_fwd_masked: geometry outside the implicit-GEMM family");
+    return launch_fwd_masked(*g, (const float*)x, (const float*)mask, (const float*)w, (const float*)bias, (float*)y, act,
+                             alpha, to_stream(stream), workspace, workspace_bytes);
+}
+
+int sv_conv2d_wgrad_masked(const sv_conv_geom* g, const void* x, const void* mask, const void* dz, void* dw, int accumulate,
+                           void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_wgrad_masked");
+    int rc = validate_geom(g, "sv_conv2d_wgrad_masked");
+    if (rc) return rc;
+    SV_REQUIRE(x && mask && dz && dw, "sv_conv2d_wgrad_masked: null tensor");
+    SV_REQUIRE(sv_conv2d_masked_supported(g), "sv_conv2d_wgrad_masked: geometry outside the implicit-GEMM family");
+    return launch_wgrad_direct(*g, (const float*)x, (const float*)dz, (float*)dw, accumulate, workspace, workspace_bytes,
+                               to_stream(stream), (const float*)mask);
 }
 
 size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g) {

@@ -17,11 +17,11 @@ int conv_gemm_wgrad_splits(const sv_conv_geom& g);
 size_t conv_gemm_wgrad_workspace(const sv_conv_geom& g);
 size_t conv_gemm_splitk_workspace(const sv_conv_geom& g, int mode);
 int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
-                         float alpha, void* ws, size_t ws_bytes, hipStream_t st);
+                         float alpha, void* ws, size_t ws_bytes, hipStream_t st, const float* xmask = nullptr);
 int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* w, const float* bias, float* dx, int act,
                            float alpha, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st,
-                           int accumulate);
+                           int accumulate, const float* xmask = nullptr);
 // conv_gemm_bf16.hip: the same three products with bf16 operands
 bool conv_gemm_bf16_ok(const sv_conv_geom& g, int mode);
 int conv_gemm_bf16_wgrad_splits(const sv_conv_geom& g);
@@ -334,6 +334,15 @@ static void wgrad_direct_any(const sv_conv_geom& g, const T* x, const T* dz, flo
         hipLaunchKernelGGL((conv2d_wgrad_direct<4, T>), grid, dim3(256), 0, st, g, x, dz, part, pps);
 }
 
+// The masked forms (x read as x * (1 - mask)) exist on the implicit-GEMM kernel only.
+bool conv_masked_supported(const sv_conv_geom& g) { return conv_gemm_worthwhile(g, 0) && conv_gemm_worthwhile(g, 2); }
+
+int launch_fwd_masked(const sv_conv_geom& g, const float* x, const float* mask, const float* w, const float* bias, float* y,
+                      int act, float alpha, hipStream_t st, void* ws, size_t ws_bytes) {
+    if (!conv_masked_supported(g)) return fail(SV_E_UNSUPPORTED, "sv_conv2d_fwd_masked: geometry outside the implicit-GEMM family");
+    return launch_conv_gemm_fwd(g, x, w, bias, y, act, alpha, ws, ws_bytes, st, mask);
+}
+
 int launch_fwd_direct(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
                       float alpha, hipStream_t st, void* ws, size_t ws_bytes) {
     if (conv_gemm_worthwhile(g, 0)) return launch_conv_gemm_fwd(g, x, w, bias, y, act, alpha, ws, ws_bytes, st);
@@ -378,15 +387,17 @@ size_t wgrad_direct_workspace(const sv_conv_geom& g) {
 }
 
 int launch_wgrad_direct(const sv_conv_geom& g, const float* x, const float* dz, float* dw, int accumulate,
-                        void* ws, size_t ws_bytes, hipStream_t st) {
+                        void* ws, size_t ws_bytes, hipStream_t st, const float* xmask) {
     const int64_t kc = (int64_t)g.KH * g.KW * g.Cin * g.Cout;
     if (ws == nullptr || ws_bytes < wgrad_direct_workspace(g))
         return fail(SV_E_WORKSPACE, "conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes,
                     wgrad_direct_workspace(g));
+    if (xmask != nullptr && !conv_masked_supported(g))
+        return fail(SV_E_UNSUPPORTED, "sv_conv2d_wgrad_masked: geometry outside the implicit-GEMM family");
     if (conv_gemm_worthwhile(g, 2)) {
         const int splits = conv_gemm_wgrad_splits(g);
-        if (splits == 1) return launch_conv_gemm_wgrad(g, x, dz, dw, 1, st, accumulate);  // tiles go straight into dw
-        int rc = launch_conv_gemm_wgrad(g, x, dz, (float*)ws, splits, st, 0);
+        if (splits == 1) return launch_conv_gemm_wgrad(g, x, dz, dw, 1, st, accumulate, xmask);  // tiles go straight into dw
+        int rc = launch_conv_gemm_wgrad(g, x, dz, (float*)ws, splits, st, 0, xmask);
         if (rc) return rc;
         if (defer_reduce((const float*)ws, dw, kc, splits, accumulate)) return SV_OK;
         hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(kc, 64)), dim3(1024), 0, st, (const float*)ws, dw, kc, splits,

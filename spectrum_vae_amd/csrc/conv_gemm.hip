@@ -37,6 +37,7 @@ struct ConvGemmArgs {
     float* slabs;       //              slabs[split][M][N] (indexed like c) and splitk_finish_k applies bias + activation
     int accumulate;     // WGRAD with a single split: c is dw itself and the tile is added to it when set
     unsigned a_bytes, b_bytes;  // sizes of the A / B tensors: the gathers are range-checked buffer loads
+    const float* amask;  // FWD / WGRAD (MK kernels): x is read as x * (1 - amask), amask laid out like x
 };
 
 typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
@@ -46,7 +47,10 @@ constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS row pitch (floats): 6
 // most 16 columns: the 3-channel image convs, single-logit heads): the waves sit 4 x 1, each on 16 x 16.
 // VA / VB: the A / B operand is gathered with 16-byte loads along its memory-contiguous index (channels); needs that
 // channel count to be a multiple of 4 and a 16-byte aligned tensor, else the operand falls back to 4-byte gathers.
-template <int MODE, int BNT, bool VA, bool VB>
+// MK (FWD / WGRAD): the input is masked on the way in, x * (1 - mask) (run_context_encoder.py:242): the mask element rides
+// the register ring beside the x element it belongs to and the product is formed when the pair is written to LDS, so
+// the masked tensor is never materialised.
+template <int MODE, int BNT, bool VA, bool VB, bool MK = false>
 __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     constexpr int WAVES_N = BNT == 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
     constexpr int TI = BM / WAVES_M / 16, TJ = BNT / WAVES_N / 16;  // accumulators per wave
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     // beyond the tensor and comes back as zero, so no load sits behind a branch.
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MK ? p.amask : p.a), 0, p.a_bytes, 0x00020000);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     const bool b_lane = BNT == 64 || t < 64;  // 16-byte B gathers of a 16-column tile need 64 threads only
 
     // global -> registers for one reduction step (issued ahead of its use, so the round trip overlaps the MFMAs)
-    auto gather = [&](int k0, float (&av)[4], float (&bv)[NBR]) {
+    auto gather = [&](int k0, float (&av)[4], float (&bv)[NBR], float (&mv)[4]) {
         // ---- the reduction index this thread decodes (FWD / DGRAD)
         const int kt = k0 + (VA ? (t & 3) * 4 : (t & 15));
         // ---- gather A
@@ -200,6 +205,10 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
                 const bool ok = kok && r_ok[i] && (unsigned)(r_h[i] + kh) < (unsigned)g.H && (unsigned)(r_w[i] + kw) < (unsigned)g.W;
                 if (VA) ld4(rs_a, r_base[i] + koff, ok, av);
                 else av[i] = ld1(rs_a, r_base[i] + koff, ok);
+                if (MK) {
+                    if (VA) ld4(rs_m, r_base[i] + koff, ok, mv);
+                    else mv[i] = ld1(rs_m, r_base[i] + koff, ok);
+                }
             }
         } else if (MODE == GEMM_DGRAD) {
             const bool kok = kt < kend;
@@ -227,6 +236,10 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
                 const int e = ((img * g.H + h0) * g.W + w0) * g.Cin + a_off;
                 if (VA) ld4(rs_a, e, ok, av);
                 else av[i] = ld1(rs_a, e, ok);
+                if (MK) {
+                    if (VA) ld4(rs_m, e, ok, mv);
+                    else mv[i] = ld1(rs_m, e, ok);
+                }
             }
         }
         // ---- gather B
@@ -266,15 +279,19 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
     // has PF - 1 multiply phases to arrive (one phase is 16 MFMAs per wave, shorter than a trip to L2 / HBM; the small
     // launches of the GAN drivers' batch sizes leave a SIMD one or two waves and nothing else to cover it).
     constexpr int PF = 3;
-    float av[PF][4], bv[PF][NBR];
+    float av[PF][4], bv[PF][NBR], mv[PF][4];
 #pragma unroll
-    for (int d = 0; d < PF - 1; ++d) gather(kbeg + d * BK, av[d], bv[d]);  // beyond kend: all pieces dead, zeros
+    for (int d = 0; d < PF - 1; ++d) gather(kbeg + d * BK, av[d], bv[d], mv[d]);  // beyond kend: all pieces dead, zeros
     // one reduction step out of ring slot D; GATHER: also issue the gather PF - 1 steps ahead (into the slot this step's
     // predecessor just freed).  Gathers are issued whether or not that step exists (beyond kend every piece is dead): a
     // fixed number of loads in flight lets the compiler wait for the oldest slot only instead of draining the ring.
     auto step = [&](auto slot, int k0, bool do_gather) {
         constexpr int d = decltype(slot)::value;
         __syncthreads();  // the previous step's MFMA reads are done
+        if (MK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[d][i] *= 1.f - mv[d][i];
+        }
         if (MODE == GEMM_WGRAD) {
             if (VA) {
                 *reinterpret_cast<float4*>(&As[t >> 4][(t & 15) * 4]) = make_float4(av[d][0], av[d][1], av[d][2], av[d][3]);
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256) void conv_gemm_mfma(ConvGemmArgs p) {
             for (int i = 0; i < NB; ++i) Bs[(t / BNT) + BROWS * i][t & (BNT - 1)] = bv[d][i];
         }
         __syncthreads();
-        if (do_gather) gather(k0 + (PF - 1) * BK, av[(d + PF - 1) % PF], bv[(d + PF - 1) % PF]);
+        if (do_gather) gather(k0 + (PF - 1) * BK, av[(d + PF - 1) % PF], bv[(d + PF - 1) % PF], mv[(d + PF - 1) % PF]);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float a[TI], b[TJ];
@@ -412,8 +429,17 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 
 template <int MODE>
 static void launch_variant(const ConvGemmArgs& p, dim3 grid, int bnt, bool va, bool vb, hipStream_t st) {
-#define SV_GEMM_CASE(B, A_, B_) \
-    if (bnt == B && va == A_ && vb == B_) { hipLaunchKernelGGL((conv_gemm_mfma<MODE, B, A_, B_>), grid, dim3(256), 0, st, p); return; }
+#define SV_GEMM_CASE(B, A_, B_)                                                                                          \
+    if (bnt == B && va == A_ && vb == B_) {                                                                              \
+        if constexpr (MODE != GEMM_DGRAD) {                                                                              \
+            if (p.amask != nullptr) {                                                                                    \
+                hipLaunchKernelGGL((conv_gemm_mfma<MODE, B, A_, B_, true>), grid, dim3(256), 0, st, p);                  \
+                return;                                                                                                  \
+            }                                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((conv_gemm_mfma<MODE, B, A_, B_>), grid, dim3(256), 0, st, p);                                \
+        return;                                                                                                          \
+    }
     SV_GEMM_CASE(64, true, true) SV_GEMM_CASE(64, true, false) SV_GEMM_CASE(64, false, true) SV_GEMM_CASE(64, false, false)
     SV_GEMM_CASE(16, true, true) SV_GEMM_CASE(16, true, false) SV_GEMM_CASE(16, false, true) SV_GEMM_CASE(16, false, false)
 #undef SV_GEMM_CASE
@@ -506,10 +532,10 @@ static void fill_common(ConvGemmArgs& p, const sv_conv_geom& g, int mode) {
 
 // ws / ws_bytes: optional scratch of conv_gemm_splitk_workspace(g, mode) bytes; without it the reduction is not cut
 int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
-                         float alpha, void* ws, size_t ws_bytes, hipStream_t st) {
+                         float alpha, void* ws, size_t ws_bytes, hipStream_t st, const float* xmask) {
     ConvGemmArgs p{};
     fill_common(p, g, GEMM_FWD);
-    p.a = x; p.b = w; p.bias = bias; p.c = y; p.act = act; p.alpha = alpha;
+    p.a = x; p.b = w; p.bias = bias; p.c = y; p.act = act; p.alpha = alpha; p.amask = xmask;
     p.M = g.N * g.Ho * g.Wo; p.N = g.Cout; p.K = g.KH * g.KW * g.Cin;
     p.splits = 1;
     const size_t need = conv_gemm_splitk_workspace(g, GEMM_FWD);
@@ -519,7 +545,7 @@ int launch_conv_gemm_fwd(const sv_conv_geom& g, const float* x, const float* w, 
     }
     const int bnt = tile_cols(p.N);
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, bnt), (unsigned)p.splits);
-    launch_variant<GEMM_FWD>(p, grid, bnt, (g.Cin & 3) == 0 && aligned16(x), (g.Cout & 3) == 0 && aligned16(w), st);
+    launch_variant<GEMM_FWD>(p, grid, bnt, (g.Cin & 3) == 0 && aligned16(x) && aligned16(xmask), (g.Cout & 3) == 0 && aligned16(w), st);
     int rc = check_launch("conv_gemm_mfma<fwd>");
     if (rc || p.splits == 1) return rc;
     return launch_splitk_finish(p, st);
@@ -551,16 +577,16 @@ int launch_conv_gemm_dgrad(const sv_conv_geom& g, const float* dz, const float* 
 
 // splits > 1: slabs only, the caller sums them (wgrad_reduce); splits == 1: `slabs` is dw itself (accumulate applies)
 int launch_conv_gemm_wgrad(const sv_conv_geom& g, const float* x, const float* dz, float* slabs, int splits, hipStream_t st,
-                           int accumulate) {
+                           int accumulate, const float* xmask) {
     ConvGemmArgs p{};
     fill_common(p, g, GEMM_WGRAD);
-    p.a = x; p.b = dz; p.bias = nullptr; p.c = slabs; p.act = SV_ACT_NONE; p.alpha = 0.f;
+    p.a = x; p.b = dz; p.bias = nullptr; p.c = slabs; p.act = SV_ACT_NONE; p.alpha = 0.f; p.amask = xmask;
     p.accumulate = splits == 1 && accumulate;
     p.M = g.KH * g.KW * g.Cin; p.N = g.Cout; p.K = g.N * g.Ho * g.Wo;
     p.k_per_split = (int)(ceil_div(ceil_div(p.K, splits), BK) * BK);
     const int bnt = tile_cols(p.N);
     dim3 grid((unsigned)ceil_div(p.M, BM), (unsigned)ceil_div(p.N, bnt), (unsigned)splits);
-    launch_variant<GEMM_WGRAD>(p, grid, bnt, (g.Cin & 3) == 0 && aligned16(x), (g.Cout & 3) == 0 && aligned16(dz), st);
+    launch_variant<GEMM_WGRAD>(p, grid, bnt, (g.Cin & 3) == 0 && aligned16(x) && aligned16(xmask), (g.Cout & 3) == 0 && aligned16(dz), st);
     return check_launch("conv_gemm_mfma<wgrad>");
 }
 

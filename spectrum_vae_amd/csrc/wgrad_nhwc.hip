@@ -105,6 +105,29 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
         }
         return v;
     };
+    // LDS positions of this thread's pieces: they depend on the thread and the piece only, not on the pass, so they are
+    // formed once (the store phase of a pass is then the writes and the dz arithmetic, no index decoding)
+    constexpr int SEL = CS % 4 == 0 ? 1 : 4;  // 3 channels: the 4 floats of a piece land on 4 positions
+    int s_at[kWnUnits][SEL], p_at[kWnUnits];
+#pragma unroll
+    for (int i = 0; i < kWnUnits; ++i) {
+        const int e = 4 * ((int)threadIdx.x + i * 256);
+#pragma unroll
+        for (int t = 0; t < SEL; ++t) {
+            const int p = (e + t) / CS, c = (e + t) - p * CS;
+            const int ss = fd(p, f_shw), pp = p - ss * (Ho * Wo);
+            const int row = fd(pp, f_sw), col = pp - row * Wo;
+            s_at[i][t] = ss * sampleS + ((row + 1) * SW + col + 1) * CS + c;
+        }
+        if (SWAP || pz != 2) {
+            p_at[i] = e;  // the image is the tensor
+        } else {
+            const int p = e / CP, c = e - p * CP;
+            const int ss = fd(p, f_phw), pp = p - ss * (p_h * p_w);
+            const int row = fd(pp, f_pw), col = pp - row * p_w;
+            p_at[i] = ss * sampleP + ((2 * row) * Wo + 2 * col) * CP + c;
+        }
+    }
     auto store_pass = [&](int ns) {
         const int su = (ns * s_sample) >> 2, pu = (ns * p_sample) >> 2;
 #pragma unroll
@@ -112,21 +135,11 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
             const int u = threadIdx.x + i * 256;
             if (u < su) {
                 const float4 v = SWAP ? grad4(R.sv[i], R.sy[i], s_act) : R.sv[i];
-                const int e = 4 * u;
                 if (CS % 4 == 0) {  // one pixel, 4 of its channels
-                    const int p = e / CS, c = e - p * CS;
-                    const int ss = fd(p, f_shw), pp = p - ss * (Ho * Wo);
-                    const int row = fd(pp, f_sw), col = pp - row * Wo;
-                    *reinterpret_cast<float4*>(s_lds + ss * sampleS + ((row + 1) * SW + col + 1) * CS + c) = v;
+                    *reinterpret_cast<float4*>(s_lds + s_at[i][0]) = v;
                 } else {
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int p = (e + t) / CS, c = (e + t) - p * CS;
-                        const int ss = fd(p, f_shw), pp = p - ss * (Ho * Wo);
-                        const int row = fd(pp, f_sw), col = pp - row * Wo;
-                        s_lds[ss * sampleS + ((row + 1) * SW + col + 1) * CS + c] = vv[t];
-                    }
+                    s_lds[s_at[i][0]] = v.x; s_lds[s_at[i][1 % SEL]] = v.y;
+                    s_lds[s_at[i][2 % SEL]] = v.z; s_lds[s_at[i][3 % SEL]] = v.w;
                 }
             }
         }
@@ -136,15 +149,11 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
             if (u < pu) {
                 if (SWAP || pz != 2) {
                     const float4 v = SWAP ? R.pv[i] : grad4(R.pv[i], R.py[i], pz == 1);
-                    *reinterpret_cast<float4*>(p_lds + 4 * u) = v;  // the image is the tensor
+                    *reinterpret_cast<float4*>(p_lds + p_at[i]) = v;
                 } else {
                     const float4 v = grad4(R.pv[i], R.py[i], true);
                     const uint32_t k = R.pk[i];
-                    const int e = 4 * u;
-                    const int p = e / CP, c = e - p * CP;
-                    const int ss = fd(p, f_phw), pp = p - ss * (p_h * p_w);
-                    const int row = fd(pp, f_pw), col = pp - row * p_w;
-                    float* q = p_lds + ss * sampleP + ((2 * row) * Wo + 2 * col) * CP + c;
+                    float* q = p_lds + p_at[i];
                     const uint32_t k0 = k & 0xff, k1 = (k >> 8) & 0xff, k2 = (k >> 16) & 0xff, k3 = k >> 24;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {

@@ -353,16 +353,25 @@ class Model(Layer):
             prev = y
         return prev
 
-    def forward_raw(self, x: torch.Tensor, training: bool, side=None, mse=None, bn_groups: int = 1) -> torch.Tensor:
+    def forward_raw(self, x: torch.Tensor, training: bool, side=None, mse=None, bn_groups: int = 1,
+                    input_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Forward on a prepared device tensor; the result aliases the model's buffer pool.  ``side``: stream
         the backward pass of this call may use for its weight-gradient kernels (the caller joins it).  ``mse``: see
-        ``_net_forward``; honoured only when the whole forward is the one-launch kernel (check ``ctx.loss_fold``)."""
+        ``_net_forward``; honoured only when the whole forward is the one-launch kernel (check ``ctx.loss_fold``).
+        ``input_mask`` (float32, shape of x): the model sees x * (1 - input_mask) (run_context_encoder.py:242-243); when
+        the first layer is a convolution of the implicit-GEMM family the product is formed inside its gathers (forward
+        and kernel gradient) and the masked tensor never exists, otherwise it costs one elementwise pass."""
         if training:
             ctx = CallCtx(self._pool, len(self._calls), True, self._act_dtype)
             ctx.side = side
             self._calls.append(ctx)
         else:
             ctx = CallCtx(self._pool, "infer", False, self._act_dtype)
+        fold_mask = input_mask is not None and self._act_dtype == torch.float32
+        if input_mask is not None and not fold_mask:  # bf16 policy: one elementwise pass in float32, ahead of the cast
+            xm = self._pool.get(("input_masked", ctx.slot), tuple(x.shape), torch.float32)
+            ops.mask_input(x, input_mask, xm)
+            x = xm
         if self._act_dtype != torch.float32:
             if self._lp_dirty:
                 self._refresh_lp()
@@ -370,6 +379,12 @@ class Model(Layer):
         ctx.loss_fold = None
         ctx.bn_groups = int(bn_groups)  # the batch is this many independent BatchNorm groups (see CallCtx)
         self._last_ctx = ctx
+        if fold_mask:  # the first layer that runs takes the request (a Conv2D folds it into its gathers)
+            ctx.input_mask = input_mask
+            y = self.forward(ctx, x)
+            if ctx.input_mask is not None:
+                raise RuntimeError("forward_raw: no layer consumed input_mask (the model does not start with a layer stack)")
+            return y
         if self.use_net_fused and not ctx.lp:
             y = self._net_forward(ctx, x, mse)
             if y is not None:

@@ -218,6 +218,8 @@ class CallCtx:
         self.side_rr = 0
         # A list: fused conv layers leave their kernel-gradient partial sums in per-layer workspaces and append a job
         # here; the owner finishes all of them with one launch after the backward pass.  None: reduce per layer.
+        # Set by Model.forward_raw(input_mask=...): the first conv layer reads the model input as x * (1 - mask)
+        self.input_mask: Optional[torch.Tensor] = None
         self.wgrad_jobs: Optional[list] = None
         self.wgrad_finish: list = []
         # (partials, n, scale) when the forward launch also evaluated the loss and left per-workgroup sums to fold
@@ -448,6 +450,12 @@ class _ConvBase(Layer):
         b = self.bias.data if self.bias is not None else None
         if ctx.lp and (self.pool is not None or self.up != (1, 1)):
             raise NotImplementedError(f"{self.name}: the fused 3x3 / 5x5 stride-1 family is float32 only")
+        mask = ctx.input_mask  # the model input is to be read as x * (1 - mask): the first layer consumes the request
+        ctx.input_mask = None
+        if mask is not None and (self.transposed or ctx.lp or not self.masked_ok(g)):
+            xm = ctx.buf(self, "x_masked", tuple(x.shape), torch.float32)  # geometry outside the folded form: one pass
+            ops.mask_input(x, mask, xm)
+            x, mask = xm, None
         if self.pool is not None:
             ho, wo, cout = self.output_shape_
             y = ctx.buf(self, "y", (n, ho // 2, wo // 2, cout))
@@ -460,11 +468,20 @@ class _ConvBase(Layer):
         if self.transposed:
             ops.conv2d_transpose_fwd(g, x, self._w(ctx), b, y, self.act, self.alpha,
                                      self._scratch(ctx, g, ops.OP_TRANSPOSE_FWD))
+        elif mask is not None:
+            ops.conv2d_fwd_masked(g, x, mask, self.kernel.data, b, y, self.act, self.alpha, self._scratch(ctx, g, ops.OP_FWD))
         else:
             ops.conv2d_fwd(g, x, self._w(ctx), b, y, self.act, self.alpha, self._scratch(ctx, g, ops.OP_FWD))
         if ctx.training:
-            ctx.saved[id(self)] = {"x": x, "y": y}
+            ctx.saved[id(self)] = {"x": x, "y": y, "mask": mask}
         return y
+
+    def masked_ok(self, g) -> bool:
+        """The conv can read its input through a mask while gathering it (implicit-GEMM geometries, float32)."""
+        ok = self.__dict__.get("_masked_ok")
+        if ok is None:
+            ok = self._masked_ok = self.pool is None and self.up == (1, 1) and ops.conv2d_masked_supported(g)
+        return ok
 
     def backward(self, ctx, dy, need_dx=True):
         s = ctx.saved[id(self)]
@@ -528,6 +545,8 @@ class _ConvBase(Layer):
             ws = ctx.pool.workspace(ops.conv2d_wgrad_workspace(g))
             if self.transposed:
                 ops.conv2d_transpose_wgrad(g, x, dz, self.kernel.grad, True, ws)
+            elif s.get("mask") is not None:
+                ops.conv2d_wgrad_masked(g, x, s["mask"], dz, self.kernel.grad, True, ws)
             else:
                 ops.conv2d_wgrad(g, x, dz, self.kernel.grad, True, ws)
         if not need_dx:
@@ -537,6 +556,8 @@ class _ConvBase(Layer):
             ops.conv2d_transpose_dgrad(g, dz, self._w(ctx), dx, self._scratch(ctx, g, ops.OP_TRANSPOSE_DGRAD))
         else:
             ops.conv2d_dgrad(g, dz, self._w(ctx), dx, self._scratch(ctx, g, ops.OP_DGRAD))
+        if s.get("mask") is not None:  # d(x * (1 - mask)) / dx
+            ops.mask_input(dx, s["mask"], dx)
         return dx
 
 
@@ -941,6 +962,14 @@ class Sequential(Layer):
 
     def forward(self, ctx, x):
         for l in self.layers:
+            if ctx.input_mask is not None and type(l) is not Conv2D and not isinstance(l, (Sequential, InputLayer)):
+                # a pending input mask (Model.forward_raw) and a first layer that cannot read through it: one pass
+                mask, ctx.input_mask = ctx.input_mask, None
+                xm = ctx.buf(self, "x_masked", tuple(x.shape), torch.float32)
+                ops.mask_input(x, mask, xm)
+                if ctx.training:
+                    ctx.saved[("input_mask", id(self))] = mask
+                x = xm
             x = l.forward(ctx, x)
         return x
 
@@ -953,6 +982,9 @@ class Sequential(Layer):
             dy = self.layers[i].backward(ctx, dy, need_dx=want)
             if dy is None:
                 return None
+        mask = ctx.saved.get(("input_mask", id(self)))
+        if mask is not None:  # d(x * (1 - mask)) / dx
+            ops.mask_input(dy, mask, dy)
         return dy
 
     # ---- keras-style introspection

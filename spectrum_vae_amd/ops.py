@@ -105,6 +105,25 @@ def conv2d_fwd(g: ConvGeom, x, w, bias, y, act: str, alpha: float, ws=None):
                                *_ws_args(ws), _dt(x), _stream()), "sv_conv2d_fwd_ws")
 
 
+def conv2d_masked_supported(g: ConvGeom) -> bool:
+    """Whether ``conv2d_fwd_masked`` / ``conv2d_wgrad_masked`` cover this geometry."""
+    return bool(lib.sv_conv2d_masked_supported(C.byref(g)))
+
+
+def conv2d_fwd_masked(g: ConvGeom, x, mask, w, bias, y, act: str, alpha: float, ws=None):
+    """``conv2d_fwd`` of x * (1 - mask) without the masked tensor (float32)."""
+    if mask.shape != x.shape:
+        raise ValueError(f"conv2d_fwd_masked: mask {tuple(mask.shape)} vs x {tuple(x.shape)}")
+    check(lib.sv_conv2d_fwd_masked(C.byref(g), _ptr(x), _ptr(mask), _ptr(w), _ptr(bias), _ptr(y), ACT[act], alpha,
+                                   *_ws_args(ws), F32, _stream()), "sv_conv2d_fwd_masked")
+
+
+def conv2d_wgrad_masked(g: ConvGeom, x, mask, dz, dw, accumulate: bool, ws: torch.Tensor):
+    """``conv2d_wgrad`` with x read as x * (1 - mask) (float32)."""
+    check(lib.sv_conv2d_wgrad_masked(C.byref(g), _ptr(x), _ptr(mask), _ptr(dz), _ptr(dw), int(accumulate),
+                                     _ptr(ws, torch.uint8), ws.numel(), F32, _stream()), "sv_conv2d_wgrad_masked")
+
+
 def conv2d_dgrad(g: ConvGeom, dz, w, dx, ws=None):
     check(lib.sv_conv2d_dgrad_ws(C.byref(g), _aptr(dz), _aptr(w, dz, "w"), _aptr(dx, dz, "dx"), *_ws_args(ws), _dt(dz),
                                  _stream()), "sv_conv2d_dgrad_ws")

@@ -204,8 +204,11 @@ def _step_body(ce, disc, ce_opt, disc_opt, st: _StepState, l2_weight: float, ove
     main = torch.cuda.current_stream()
     if st.X is not st.both and st.X.data_ptr() != st.both.data_ptr():  # bf16 policy: the real half in the models' type
         ops.cast(st.X, st.both[:bs])
-    ops.mask_input(st.X, st.mask, st.Xm)  # X * (1 - mask)
-    pred = ce.forward_raw(st.Xm, True)
+    if ce._act_dtype == torch.float32:
+        pred = ce.forward_raw(st.X, True, input_mask=st.mask)  # X * (1 - mask), formed inside the first conv's gathers
+    else:
+        ops.mask_input(st.X, st.mask, st.Xm)
+        pred = ce.forward_raw(st.Xm, True)
     # l2 = MSE(X, pred, sample_weight = mask[..., 0] * 10): channel 0 of the NHWC mask is read with stride C
     mse.value_and_grad(st.X, pred, st.l2, st.dpred, 1.0, sample_weight=st.mask, weight_scale=10.0,
                        weight_stride=st.mask.shape[-1])
