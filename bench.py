@@ -69,6 +69,7 @@ class OpTimer:
 
     def __init__(self):
         self.records = []
+        self.calls = []  # (name, info, unwrapped function, arguments) of every call, for re-issuing one of them
 
     def __enter__(self):
         from spectrum_vae_amd import _lib
@@ -114,6 +115,7 @@ class OpTimer:
                     h, w = (ho // 2, wo // 2) if L.pool else (ho, wo)
                 info = {"N": n, "layers": nl, "flops": fl}
             self.records.append((name, info, s, e))
+            self.calls.append((name, info, fn, args))
             return rc
         return call
 
@@ -295,8 +297,25 @@ def main():
             gr["flops_per_step"] += fl * row["calls_per_step"]
         if groups:
             kname, gr = max(groups.items(), key=lambda kv: kv[1]["us_per_step"])
-            avg_us = gr["us_per_step"] / gr["launches_per_step"]
+            avg_us_in_step = gr["us_per_step"] / gr["launches_per_step"]
             fl = gr["flops_per_step"] / gr["launches_per_step"]
+            # The dominant kernel's launch duration: its calls of the last eager step are issued again, 20 times back to
+            # back between two HIP events on the launch stream, so the queue stays full and the host's launch path (5-7 us
+            # of an eager call's event-to-event time) is not in the figure; this is the number to hold against AverageNs
+            # of the same kernel in profiles/*_kernel_stats.csv.
+            again = [(fn, a) for (n_, info, fn, a) in ot.calls
+                     if (kernel_of_call(n_, info) or (None,))[0] == kname]
+            reps_k = 20
+            for fn, a in again:
+                fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps_k):
+                for fn, a in again:
+                    fn(*a)
+            e1.record()
+            torch.cuda.synchronize()
+            avg_us = e0.elapsed_time(e1) * 1e3 / (reps_k * max(len(again), 1)) if again else avg_us_in_step
             ach = fl / (avg_us * 1e-6) / 1e12
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -305,10 +324,13 @@ def main():
                     traffic = json.load(f).get("hbm_bytes_per_launch", {}).get(kname)
             roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
-                        "avg_launch_us": round(avg_us, 2), "launches_per_step": gr["launches_per_step"],
-                        "flops_per_launch": fl, "time_share_of_step": round(gr["us_per_step"] / (elapsed / args.steps * 1e6), 3),
-                        "note": "f32 vector FMA peak == f32 MFMA peak on MI355X; averages over the launches of this "
-                                "kernel in one step, HIP events on the launch stream, eager (ungraphed) step"}
+                        "avg_launch_us": round(avg_us, 2), "avg_call_us_in_eager_step": round(avg_us_in_step, 2),
+                        "launches_per_step": gr["launches_per_step"],
+                        "flops_per_launch": fl, "time_share_of_step": round(avg_us * gr["launches_per_step"] / (elapsed / args.steps * 1e6), 3),
+                        "note": "f32 vector FMA peak == f32 MFMA peak on MI355X; avg_launch_us: this kernel's calls of "
+                                "one step issued 20 times back to back between two HIP events on the launch stream; "
+                                "avg_call_us_in_eager_step: event-to-event time of the same calls inside an eager step "
+                                "(includes the host launch path)"}
         else:
             top = table[0]
             roofline = {"bound": "hbm", "kernel": top["call"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
