@@ -43,6 +43,8 @@ struct NetLayer {
     int in_plane, in_wp, in_halo;      // planar layout of the input
     int out_plane, out_wp, out_halo;   // planar layout of the output (= the next layer's input layout)
     int co_t, n_cot, ks;
+    int pair;        // vector path, 1: a thread carries its pixel tile through two samples at once (a.S is even);
+                     // the variants compiled for it are listed in net_layer_fwd_any
     int mfma;        // 0: vector path; 1..3: the matrix-core variant compiled for this layer shape (net_layer_fwd_mfma)
     float* y;        // global output [N][Hout][Wout][Cout] (pooled extent when pool)
     uint8_t* idx;    // global argmax slots (pool only, may be null)
@@ -153,7 +155,66 @@ __device__ __forceinline__ void net_w_store(const NetFwdArgs& a, const NetLayer&
 }
 
 // ---- one layer, LDS -> LDS ---------------------------------------------------------------------------------------------
-template <int K, int UP, int CO_T, int POOL>
+// The register-tile FMA loop of tile_common.h for NS samples at once: a thread owns the same 2x2 output pixels x CO_T
+// channels in NS samples, so one filter read (a broadcast LDS read, the larger part of this loop's LDS traffic) feeds
+// NS times the arithmetic.
+template <int K, int UP, int CO_T, int NS>
+__device__ __forceinline__ void net_tile_fma(float (&acc)[NS][2][2][CO_T], const float* img, int sample_stride,
+                                             const float* wtile, int plane, int wp, int r0, int c0, int c_begin, int c_end,
+                                             int c_step) {
+    constexpr int PADL = (K - 1) / 2;
+    constexpr int NPR = patch_row<UP, PADL>(K) + 1;  // patch rows == patch cols
+    for (int c = c_begin; c < c_end; c += c_step) {
+        float patch[NS][NPR][NPR + 1];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            const float* pl = img + e * sample_stride + c * plane + r0 * wp + c0;
+#pragma unroll
+            for (int pr = 0; pr < NPR; ++pr) {
+                if (UP == 1) {  // NPR = K + 1 is even and c0 is even: 8-byte aligned pairs
+#pragma unroll
+                    for (int pc = 0; pc < NPR; pc += 2) {
+                        const float2 v2 = *reinterpret_cast<const float2*>(pl + pr * wp + pc);
+                        patch[e][pr][pc] = v2.x;
+                        patch[e][pr][pc + 1] = v2.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int pc = 0; pc < NPR; ++pc) patch[e][pr][pc] = pl[pr * wp + pc];
+                }
+            }
+        }
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                float wv[CO_T];
+                const float* wq = wtile + (c * K * K + kh * K + kw) * CO_T;
+#pragma unroll
+                for (int q = 0; q < CO_T; q += 4) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wq + q);
+                    wv[q] = w4.x; wv[q + 1] = w4.y; wv[q + 2] = w4.z; wv[q + 3] = w4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < NS; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float v = patch[e][patch_row<UP, PADL>(i + kh)][patch_row<UP, PADL>(j + kw)];
+#pragma unroll
+                            for (int q = 0; q < CO_T; ++q) acc[e][i][j][q] = fmaf(v, wv[q], acc[e][i][j][q]);
+                        }
+            }
+            // with two samples' sums and patches in registers the filter reads of one kernel row at a time may be in
+            // flight, not those of the whole channel
+            if (NS > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// NS = 2 needs an even a.S: item = (channel tile, sample pair, pixel tile, channel share).
+template <int K, int UP, int CO_T, int POOL, int NS>
 __device__ __forceinline__ void net_layer_fwd(const NetFwdArgs& a, const NetLayer& L, float* smem, int ns, int nt) {
     constexpr int PADL = (K - 1) / 2;
     const int Ho = L.Hs * UP, Wo = L.Ws * UP;
@@ -161,7 +222,7 @@ __device__ __forceinline__ void net_layer_fwd(const NetFwdArgs& a, const NetLaye
     const int T = tiles_x * tiles_y;
     const int cop = L.n_cot * CO_T;
     const int ks = L.ks;
-    const int per_cot = a.S * T * ks;
+    const int per_cot = (a.S / NS) * T * ks;
     const int total = L.n_cot * per_cot;
     const float* in = smem + L.in_off;
     float* out = smem + L.out_off;
@@ -174,69 +235,102 @@ __device__ __forceinline__ void net_layer_fwd(const NetFwdArgs& a, const NetLaye
     for (int item0 = 0; item0 < total; item0 += nt) {
         const int item = item0 + threadIdx.x;
         const bool live = item < total;
-        int cot = 0, s = 0, ty = 0, tx = 0, kl = 0;
+        int cot = 0, sp = 0, ty = 0, tx = 0, kl = 0;
         if (live) {
             cot = fd(item, f_percot);
             const int r = item - cot * per_cot;
             const int r1 = fd(r, f_ks);
             kl = r - r1 * ks;
-            s = fd(r1, f_T);
-            const int t = r1 - s * T;
+            sp = fd(r1, f_T);
+            const int t = r1 - sp * T;
             ty = fd(t, f_tx);
             tx = t - ty * tiles_x;
         }
-        const bool work = live && s < ns;
-        float acc[2][2][CO_T];
+        const int s0 = sp * NS;
+        const bool work = live && s0 < ns;
+        float acc[NS][2][2][CO_T];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int c = 0; c < CO_T; ++c) acc[i][j][c] = 0.f;
-        if (work) {
-            const int r0 = (UP == 1 ? 2 * ty : ty) + L.in_halo + floordiv_c(-PADL, UP);
-            const int c0 = (UP == 1 ? 2 * tx : tx) + L.in_halo + floordiv_c(-PADL, UP);
-            conv_tile_fma<K, UP, CO_T>(acc, in + (size_t)s * L.Cin * L.in_plane, w_lds + cot * L.Cin * K * K * CO_T, L.in_plane,
-                                       L.in_wp, r0, c0, kl, L.Cin, ks);
-        }
-        for (int o = 1; o < ks; o <<= 1) {
+        for (int e = 0; e < NS; ++e)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int q = 0; q < CO_T; ++q) acc[i][j][q] += __shfl_xor(acc[i][j][q], o, 64);
+                    for (int c = 0; c < CO_T; ++c) acc[e][i][j][c] = 0.f;
+        if (work) {
+            const int r0 = (UP == 1 ? 2 * ty : ty) + L.in_halo + floordiv_c(-PADL, UP);
+            const int c0 = (UP == 1 ? 2 * tx : tx) + L.in_halo + floordiv_c(-PADL, UP);
+            // a sample past ns (the last, short pass) reads its zeroed image; its results are dropped below
+            net_tile_fma<K, UP, CO_T, NS>(acc, in + (size_t)s0 * L.Cin * L.in_plane, L.Cin * L.in_plane,
+                                          w_lds + cot * L.Cin * K * K * CO_T, L.in_plane, L.in_wp, r0, c0, kl, L.Cin, ks);
+        }
+        for (int o = 1; o < ks; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < NS; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < CO_T; ++q) acc[e][i][j][q] += __shfl_xor(acc[e][i][j][q], o, 64);
         }
         if (work && kl == 0) {
             const int cg = cot * CO_T;
-            if (POOL == 0) {
 #pragma unroll
-                for (int q = 0; q < CO_T; ++q)
-                    if (cg + q < L.Cout) {
-                        const float b = b_lds[cg + q];
-                        float* o = out + (size_t)(s * L.Cout + cg + q) * L.out_plane + (2 * ty + oh) * L.out_wp + 2 * tx + oh;
-                        o[0] = act_apply(acc[0][0][q] + b, L.act, L.alpha);
-                        o[1] = act_apply(acc[0][1][q] + b, L.act, L.alpha);
-                        o[L.out_wp] = act_apply(acc[1][0][q] + b, L.act, L.alpha);
-                        o[L.out_wp + 1] = act_apply(acc[1][1][q] + b, L.act, L.alpha);
-                    }
-            } else {
-                // max of the pre-activations, then one activation per window (all activations here are non-decreasing);
-                // relu's flattened ties record slot 0, the slot the unfused order would pick
+            for (int e = 0; e < NS; ++e) {
+                const int s = s0 + e;
+                if (s >= ns) continue;
+                if (POOL == 0) {
 #pragma unroll
-                for (int q = 0; q < CO_T; ++q)
-                    if (cg + q < L.Cout) {
-                        float best = acc[0][0][q];
-                        uint32_t bi = 0;
-                        if (acc[0][1][q] > best) { best = acc[0][1][q]; bi = 1; }
-                        if (acc[1][0][q] > best) { best = acc[1][0][q]; bi = 2; }
-                        if (acc[1][1][q] > best) { best = acc[1][1][q]; bi = 3; }
-                        const float v = act_apply(best + b_lds[cg + q], L.act, L.alpha);
-                        if (L.act == SV_ACT_RELU && v <= 0.f) bi = 0;
-                        out[(size_t)(s * L.Cout + cg + q) * L.out_plane + (ty + oh) * L.out_wp + tx + oh] = v;
-                        idx_lds[((size_t)s * T + ty * tiles_x + tx) * L.Cout + cg + q] = (uint8_t)bi;
-                    }
+                    for (int q = 0; q < CO_T; ++q)
+                        if (cg + q < L.Cout) {
+                            const float b = b_lds[cg + q];
+                            float* o = out + (size_t)(s * L.Cout + cg + q) * L.out_plane + (2 * ty + oh) * L.out_wp + 2 * tx + oh;
+                            o[0] = act_apply(acc[e][0][0][q] + b, L.act, L.alpha);
+                            o[1] = act_apply(acc[e][0][1][q] + b, L.act, L.alpha);
+                            o[L.out_wp] = act_apply(acc[e][1][0][q] + b, L.act, L.alpha);
+                            o[L.out_wp + 1] = act_apply(acc[e][1][1][q] + b, L.act, L.alpha);
+                        }
+                } else {
+                    // max of the pre-activations, then one activation per window (all activations here are
+                    // non-decreasing); relu's flattened ties record slot 0, the slot the unfused order would pick
+#pragma unroll
+                    for (int q = 0; q < CO_T; ++q)
+                        if (cg + q < L.Cout) {
+                            float best = acc[e][0][0][q];
+                            uint32_t bi = 0;
+                            if (acc[e][0][1][q] > best) { best = acc[e][0][1][q]; bi = 1; }
+                            if (acc[e][1][0][q] > best) { best = acc[e][1][0][q]; bi = 2; }
+                            if (acc[e][1][1][q] > best) { best = acc[e][1][1][q]; bi = 3; }
+                            const float v = act_apply(best + b_lds[cg + q], L.act, L.alpha);
+                            if (L.act == SV_ACT_RELU && v <= 0.f) bi = 0;
+                            out[(size_t)(s * L.Cout + cg + q) * L.out_plane + (ty + oh) * L.out_wp + tx + oh] = v;
+                            idx_lds[((size_t)s * T + ty * tiles_x + tx) * L.Cout + cg + q] = (uint8_t)bi;
+                        }
+                }
             }
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void net_layer_fwd_any(const NetFwdArgs& a, const NetLayer& L, float* smem, int ns, int nt) {
+    if (L.pair == 1) net_layer_fwd<K, 1, 8, 1, 2>(a, L, smem, ns, nt);
+    else if (L.up == 1) {
+        if (L.co_t == 8) {
+            if (L.pool) net_layer_fwd<K, 1, 8, 1, 1>(a, L, smem, ns, nt);
+            else net_layer_fwd<K, 1, 8, 0, 1>(a, L, smem, ns, nt);
+        } else {
+            if (L.pool) net_layer_fwd<K, 1, 4, 1, 1>(a, L, smem, ns, nt);
+            else net_layer_fwd<K, 1, 4, 0, 1>(a, L, smem, ns, nt);
+        }
+    } else {
+        if (L.co_t == 8) {
+            if (L.pool) net_layer_fwd<K, 2, 8, 1, 1>(a, L, smem, ns, nt);
+            else net_layer_fwd<K, 2, 8, 0, 1>(a, L, smem, ns, nt);
+        } else {
+            if (L.pool) net_layer_fwd<K, 2, 4, 1, 1>(a, L, smem, ns, nt);
+            else net_layer_fwd<K, 2, 4, 0, 1>(a, L, smem, ns, nt);
         }
     }
 }
@@ -372,6 +466,143 @@ __device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const Ne
     }
 }
 
+// ---- a 3x3 conv behind a 2x nearest upsampling on the matrix cores, LDS -> LDS.  The four output pixels (2r + a, 2c + b)
+// above a stored pixel (r, c) read the SAME 3 x 3 stored neighbourhood, each through its own 2 x 2 subset of it with
+// sums of the original taps as weights (rows: a = 0 reads stored rows r - 1 with tap 0 and r with taps 1 + 2; a = 1 reads
+// r with taps 0 + 1 and r + 1 with tap 2; columns alike).  So the layer is one GEMM over STORED pixels:
+//   D[stored pixel][(phase, co)] = sum_{stored tap, ci} x[pixel + tap][ci] * Wp[(tap, ci)][(phase, co)],
+// a quarter of the A-operand reads and, for 8 output channels, full 16-wide tiles (4 phases x 8 channels = 32 columns)
+// where the direct form leaves half of each tile empty.  Wp is built once per layer and workgroup from the nine taps
+// of each (ci, co) filter pair; its LDS layout [tap][ci / 4][column / 16][ci % 4][column % 16] makes a wave's B read
+// 64 consecutive floats at lane + a compile-time offset.
+template <int CIN, int COUT>
+struct NetPhase {
+    static constexpr int NT = (4 * COUT + 15) / 16, CG = CIN / 4, W_FLOATS = 9 * CG * NT * 64;
+};
+__host__ __device__ constexpr int net_phase_tap(int a, int k) { return floordiv_c(a + k - 1, 2) + 1; }  // stored tap 0..2
+
+// thread t < Cin * Cout keeps the nine taps of filter pair (ci, co) = (t / Cout, t % Cout): w[tap][ci][co]
+__device__ __forceinline__ void net_wp_load(const NetFwdArgs& a, const NetLayer& L, float4 (&wpre)[kNetWPre], float& bpre) {
+    const int pairs = L.Cin * L.Cout;
+    const float* w = a.params + L.w_off + min((int)threadIdx.x, pairs - 1);
+    wpre[0] = make_float4(w[0], w[pairs], w[2 * pairs], w[3 * pairs]);
+    wpre[1] = make_float4(w[4 * pairs], w[5 * pairs], w[6 * pairs], w[7 * pairs]);
+    wpre[2] = make_float4(w[8 * pairs], 0.f, 0.f, 0.f);
+    bpre = (L.b_off >= 0 && (int)threadIdx.x < L.Cout) ? a.params[L.b_off + threadIdx.x] : 0.f;
+}
+
+template <int CIN, int COUT>
+__device__ __forceinline__ void net_wp_store(const float4 (&wpre)[kNetWPre], float bpre, float* w_lds) {
+    typedef NetPhase<CIN, COUT> G;
+    if ((int)threadIdx.x < CIN * COUT) {
+        const int ci = threadIdx.x / COUT, co = threadIdx.x % COUT;
+        const float r[9] = {wpre[0].x, wpre[0].y, wpre[0].z, wpre[0].w, wpre[1].x, wpre[1].y, wpre[1].z, wpre[1].w, wpre[2].x};
+        float wp[4][9];
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wp[ph][t] = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) wp[ph][net_phase_tap(ph >> 1, kh) * 3 + net_phase_tap(ph & 1, kw)] += r[kh * 3 + kw];
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int col = ph * COUT + co;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                w_lds[(((t * G::CG + (ci >> 2)) * G::NT + (col >> 4)) * 4 + (ci & 3)) * 16 + (col & 15)] = wp[ph][t];
+        }
+    }
+    if (4 * COUT < 16 * G::NT) {  // columns past the last phase: zero, so their (dropped) sums stay finite
+        constexpr int spare = 16 * G::NT - 4 * COUT;
+        for (int u = threadIdx.x; u < 9 * G::CG * 4 * spare; u += blockDim.x) {
+            const int row = u / spare, col = 4 * COUT + u % spare;  // row = (tap * CG + cg) * 4 + ci % 4
+            w_lds[(((row >> 2) * G::NT + (col >> 4)) * 4 + (row & 3)) * 16 + (col & 15)] = 0.f;
+        }
+    }
+    if ((int)threadIdx.x < COUT) w_lds[G::W_FLOATS + threadIdx.x] = bpre;
+}
+
+template <int CIN, int COUT>
+__device__ __forceinline__ void net_layer_fwd_mfma_up2(const NetFwdArgs& a, const NetLayer& L, float* smem, int ns, int nt) {
+    typedef NetPhase<CIN, COUT> G;
+    constexpr int KK = 9, NT = G::NT, CG = G::CG;
+    const bool wide = L.Ws == 16;  // else 8 stored columns
+    const int units_ps = (L.Hs * L.Ws) >> 5;
+    const int n_units = ns * units_ps;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const float* in = smem + L.in_off;
+    float* out = smem + L.out_off;
+    const float* w_lane = smem + a.w_off + lane;
+    const float* b_lds = smem + a.w_off + G::W_FLOATS;
+    const int oh = L.out_halo, ih = L.in_halo;
+    const FDiv f_ups = fd_make(units_ps);
+    for (int u = wave; u < n_units; u += nw) {
+        const int s = fd(u, f_ups), uu = u - s * units_ps;
+        int abase[2];  // LDS offset of stored pixel (row li of tile t) inside a plane, tap (0, 0)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int pr = wide ? 2 * uu + t : 4 * uu + 2 * t + (li >> 3);
+            const int pc = wide ? li : (li & 7);
+            abase[t] = (pr + ih) * L.in_wp + pc + ih;
+        }
+        nf_v4f acc[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = nf_v4f{0.f, 0.f, 0.f, 0.f};
+        const float* ins = in + ((size_t)s * CIN + lk) * L.in_plane;
+        float av[2][CG][2], bv[2][CG][NT];
+        auto load_tap = [&](int tap, float (&a_)[CG][2], float (&b_)[CG][NT]) {
+            const int d = (tap / 3 - 1) * L.in_wp + (tap % 3 - 1);
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a_[cg][t] = ins[cg * 4 * L.in_plane + abase[t] + d];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b_[cg][n] = w_lane[((tap * CG + cg) * NT + n) * 64];
+            }
+        };
+        load_tap(0, av[0], bv[0]);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            if (tap + 1 < KK) load_tap(tap + 1, av[(tap + 1) & 1], bv[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap & 1][cg][t], bv[tap & 1][cg][n], acc[t][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue: the lane holds column 16 n + li = (phase, co) of stored pixels 4 lk .. 4 lk + 3 of each tile
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = 16 * n + li;
+            if (col < 4 * COUT) {
+                const int ph = col / COUT, co = col - ph * COUT;
+                const float b = b_lds[co];
+                float* oc = out + (size_t)(s * L.Cout + co) * L.out_plane + ((ph >> 1) + oh) * L.out_wp + (ph & 1) + oh;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int p = 4 * lk + j;
+                        const int row = wide ? 2 * uu + t : 4 * uu + 2 * t + (p >> 3);
+                        const int c = wide ? p : (p & 7);
+                        oc[2 * row * L.out_wp + 2 * c] = act_apply(acc[t][n][j] + b, L.act, L.alpha);
+                    }
+            }
+        }
+    }
+}
+
 // output arena (planar) -> global NHWC, argmax bytes -> global.  LOSS: the values are also compared with the targets
 // (squared error summed into lacc, its gradient written) on their way out.
 template <bool LOSS>
@@ -383,33 +614,79 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
     const float* out = smem + L.out_off;
     const int oh = L.out_halo;
     const FDiv fP = fd_make(P), fW = fd_make(Wout);
+    constexpr int U = 2;  // units per batch: their LDS reads (and target loads) are all issued before the first use
+    auto emit = [&](size_t gi, const float4& v, const float4& t) {
+        *reinterpret_cast<float4*>(L.y + gi) = v;
+        if (LOSS) {
+            const float4 d = make_float4(v.x - t.x, v.y - t.y, v.z - t.z, v.w - t.w);
+            lacc += d.x * d.x;
+            lacc += d.y * d.y;
+            lacc += d.z * d.z;
+            lacc += d.w * d.w;
+            *reinterpret_cast<float4*>(a.loss_dpred + gi) =
+                make_float4(a.loss_gscale * d.x, a.loss_gscale * d.y, a.loss_gscale * d.z, a.loss_gscale * d.w);
+        }
+    };
     if ((L.Cout & 3) == 0) {
         const int c4n = L.Cout >> 2;
         const int units = ns * P * c4n;
         const FDiv f4 = fd_make(c4n);
-        for (int u = threadIdx.x; u < units; u += nt) {
-            const int r = fd(u, f4), c4 = u - r * c4n;
-            const int s = fd(r, fP), p = r - s * P;
-            const int row = fd(p, fW), col = p - row * Wout;
-            const float* q = out + (size_t)(s * L.Cout + 4 * c4) * L.out_plane + (row + oh) * L.out_wp + col + oh;
-            const float4 v = make_float4(q[0], q[L.out_plane], q[2 * L.out_plane], q[3 * L.out_plane]);
-            const size_t gi = ((size_t)n0 * P + r) * L.Cout + 4 * c4;
-            *reinterpret_cast<float4*>(L.y + gi) = v;
-            if (LOSS) {
-                const float4 t = *reinterpret_cast<const float4*>(a.loss_t + gi);
-                const float4 d = make_float4(v.x - t.x, v.y - t.y, v.z - t.z, v.w - t.w);
-                lacc += d.x * d.x;
-                lacc += d.y * d.y;
-                lacc += d.z * d.z;
-                lacc += d.w * d.w;
-                *reinterpret_cast<float4*>(a.loss_dpred + gi) =
-                    make_float4(a.loss_gscale * d.x, a.loss_gscale * d.y, a.loss_gscale * d.z, a.loss_gscale * d.w);
+        for (int u0 = threadIdx.x; u0 < units; u0 += U * nt) {
+            float4 v[U], t[U];
+            size_t gi[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = min(u0 + i * nt, units - 1);
+                const int r = fd(u, f4), c4 = u - r * c4n;
+                const int s = fd(r, fP), p = r - s * P;
+                const int row = fd(p, fW), col = p - row * Wout;
+                const float* q = out + (size_t)(s * L.Cout + 4 * c4) * L.out_plane + (row + oh) * L.out_wp + col + oh;
+                gi[i] = ((size_t)n0 * P + r) * L.Cout + 4 * c4;
+                if (LOSS) t[i] = *reinterpret_cast<const float4*>(a.loss_t + gi[i]);
+                v[i] = make_float4(q[0], q[L.out_plane], q[2 * L.out_plane], q[3 * L.out_plane]);
             }
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                if (u0 + i * nt < units) emit(gi[i], v[i], t[i]);
         }
         if (L.pool && L.idx != nullptr) {
             const uint32_t* ib = reinterpret_cast<const uint32_t*>(smem + a.idx_off);
+#pragma unroll 4
             for (int u = threadIdx.x; u < units; u += nt)
                 *reinterpret_cast<uint32_t*>(L.idx + ((size_t)n0 * P) * L.Cout + 4 * (size_t)u) = ib[u];
+        }
+    } else if (((P * L.Cout) & 3) == 0) {
+        // 16-byte pieces of the contiguous NHWC range of these samples; a piece's four floats may belong to two pixels
+        const int units = (ns * P * L.Cout) >> 2;
+        const FDiv fC = fd_make(L.Cout);
+        for (int u0 = threadIdx.x; u0 < units; u0 += U * nt) {
+            float4 v[U], t[U];
+            size_t gi[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int u = min(u0 + i * nt, units - 1);
+                gi[i] = (size_t)n0 * P * L.Cout + 4 * (size_t)u;
+                if (LOSS) t[i] = *reinterpret_cast<const float4*>(a.loss_t + gi[i]);
+                float e4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * u + k;
+                    const int r = fd(e, fC), c = e - r * L.Cout;
+                    const int s = fd(r, fP), p = r - s * P;
+                    const int row = fd(p, fW), col = p - row * Wout;
+                    e4[k] = out[(size_t)(s * L.Cout + c) * L.out_plane + (row + oh) * L.out_wp + col + oh];
+                }
+                v[i] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                if (u0 + i * nt < units) emit(gi[i], v[i], t[i]);
+        }
+        if (L.pool && L.idx != nullptr) {
+            const uint32_t* ib = reinterpret_cast<const uint32_t*>(smem + a.idx_off);
+#pragma unroll 4
+            for (int u = threadIdx.x; u < units; u += nt)
+                *reinterpret_cast<uint32_t*>(L.idx + (size_t)n0 * P * L.Cout + 4 * (size_t)u) = ib[u];
         }
     } else {
         const int units = ns * P * L.Cout;
@@ -434,8 +711,17 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
     }
 }
 
+__device__ __forceinline__ void net_zero(float* arena, int floats, int nt) {
+    float4* z = reinterpret_cast<float4*>(arena);
+    for (int i = threadIdx.x; i < (floats >> 2); i += nt) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <int K>
-__global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
+__global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs args_by_value) {
+    // the layer table is indexed at run time: read it where the launch put it (the kernel-argument segment, through the
+    // scalar cache) instead of letting the compiler copy the by-value struct to per-lane scratch memory
+    (void)args_by_value;
+    const NetFwdArgs& a = *(const NetFwdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt = blockDim.x;
     float* w_lds = smem + a.w_off;
@@ -449,54 +735,54 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs a) {
             const NetLayer& L = a.L[0];
             net_w_load<K>(a, L, wpre, bpre, nt);
             __syncthreads();  // the previous pass is done with every arena
-            float4* z = reinterpret_cast<float4*>(smem + L.in_off);
-            const int nz = (a.S * L.Cin * L.in_plane) >> 2;
-            for (int i = threadIdx.x; i < nz; i += nt) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            net_zero(smem + L.in_off, a.S * L.Cin * L.in_plane, nt);
+            net_zero(smem + L.out_off, a.S * L.Cout * L.out_plane, nt);
             __syncthreads();
             PlanarSrc src;
             src.x = a.x; src.zy = nullptr; src.zidx = nullptr; src.mode = 0; src.zk = ActGradCoef{};
             src.Hs = L.Hs; src.Ws = L.Ws; src.C = L.Cin;
             const PlanarDst dst{L.Cin, L.in_plane, L.in_wp, L.in_halo};
-            stage_pass(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
+            // 8 pieces per thread in flight: the 32 x 32 x 3 input of two samples arrives in one global round trip
+            stage_pass_m<0, 8>(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
+            net_w_store<K>(a, L, wpre, bpre, w_lds, nt);
+            __syncthreads();
         }
         NET_MARK(1);
         for (int l = 0; l < a.n_layers; ++l) {
             const NetLayer& L = a.L[l];
-            // [A]
-            float4* z = reinterpret_cast<float4*>(smem + L.out_off);
-            const int nz = (a.S * L.Cout * L.out_plane) >> 2;
-            for (int i = threadIdx.x; i < nz; i += nt) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            net_w_store<K>(a, L, wpre, bpre, w_lds, nt);
-            __syncthreads();
+            // the layer's filters are in the filter arena and its output arena is zero (set up by the previous step)
             NET_MARK(2 + 3 * l);
             // [B]
-            if (l + 1 < a.n_layers) net_w_load<K>(a, a.L[l + 1], wpre, bpre, nt);
+            if (l + 1 < a.n_layers) {
+                if (a.L[l + 1].mfma >= 4) net_wp_load(a, a.L[l + 1], wpre, bpre);
+                else net_w_load<K>(a, a.L[l + 1], wpre, bpre, nt);
+            }
             // [C]
             if (L.mfma == 1) net_layer_fwd_mfma<8, 1, 1, 1>(a, L, smem, ns, nt);
             else if (L.mfma == 2) net_layer_fwd_mfma<16, 2, 1, 1>(a, L, smem, ns, nt);
             else if (L.mfma == 3) net_layer_fwd_mfma<32, 1, 2, 0>(a, L, smem, ns, nt);
-            else if (L.up == 1) {
-                if (L.co_t == 8) {
-                    if (L.pool) net_layer_fwd<K, 1, 8, 1>(a, L, smem, ns, nt);
-                    else net_layer_fwd<K, 1, 8, 0>(a, L, smem, ns, nt);
-                } else {
-                    if (L.pool) net_layer_fwd<K, 1, 4, 1>(a, L, smem, ns, nt);
-                    else net_layer_fwd<K, 1, 4, 0>(a, L, smem, ns, nt);
-                }
-            } else {
-                if (L.co_t == 8) {
-                    if (L.pool) net_layer_fwd<K, 2, 8, 1>(a, L, smem, ns, nt);
-                    else net_layer_fwd<K, 2, 8, 0>(a, L, smem, ns, nt);
-                } else {
-                    if (L.pool) net_layer_fwd<K, 2, 4, 1>(a, L, smem, ns, nt);
-                    else net_layer_fwd<K, 2, 4, 0>(a, L, smem, ns, nt);
-                }
-            }
+            else if (L.mfma == 4) net_layer_fwd_mfma_up2<16, 8>(a, L, smem, ns, nt);
+            else if (L.mfma == 5) net_layer_fwd_mfma_up2<8, 3>(a, L, smem, ns, nt);
+            else net_layer_fwd_any<K>(a, L, smem, ns, nt);
             __syncthreads();
             NET_MARK(3 + 3 * l);
+            // [A] of the next layer first: its filters were loaded a whole layer ago, so this wait does not also wait for
+            // the acknowledgements of the global stores below; the filter arena and this layer's input arena are free
+            if (l + 1 < a.n_layers) {
+                if (a.L[l + 1].mfma == 4) net_wp_store<16, 8>(wpre, bpre, w_lds);
+                else if (a.L[l + 1].mfma == 5) net_wp_store<8, 3>(wpre, bpre, w_lds);
+                else net_w_store<K>(a, a.L[l + 1], wpre, bpre, w_lds, nt);
+            }
+            if (l == 1) NET_MARK(20);
             // [E]
             if (a.loss_t != nullptr && l + 1 == a.n_layers) net_copy_out<true>(a, L, smem, n0, ns, nt, lacc);
             else net_copy_out<false>(a, L, smem, n0, ns, nt, lacc);
+            if (l == 1) NET_MARK(21);
+            if (l + 1 < a.n_layers) {
+                net_zero(smem + a.L[l + 1].out_off, a.S * a.L[l + 1].Cout * a.L[l + 1].out_plane, nt);
+                if (l == 1) NET_MARK(22);
+                __syncthreads();
+            }
             NET_MARK(4 + 3 * l);
         }
     }
@@ -556,8 +842,13 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
         L.n_cot = (s.Cout + L.co_t - 1) / L.co_t;
         const int Ho = h * s.up, Wo = w * s.up;
         const int T = (Ho / 2) * (Wo / 2);
+        static const bool no_pair = std::getenv("SPECTRUM_NETFWD_PAIR") != nullptr && std::getenv("SPECTRUM_NETFWD_PAIR")[0] == '0';
+        L.pair = 0;
+        if (S % 2 == 0 && !no_pair) {
+            if (s.up == 1 && L.co_t == 8 && s.pool) L.pair = 1;
+        }
         int ks = 1;
-        while (ks < 8 && s.Cin / (2 * ks) >= 2 && (int64_t)L.n_cot * S * T * ks < nt) ks <<= 1;
+        while (ks < 8 && s.Cin / (2 * ks) >= 2 && (int64_t)L.n_cot * (L.pair ? S / 2 : S) * T * ks < nt) ks <<= 1;
         L.ks = ks;
         // matrix-core variants exist for the shapes whose 16-wide tiles are full: (Cin, Cout, up, pool)
         L.mfma = 0;
@@ -567,7 +858,17 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
             else if (s.Cin == 16 && s.Cout == 32 && s.up == 1 && s.pool) L.mfma = 2;
             else if (s.Cin == 32 && s.Cout == 16 && s.up == 2 && !s.pool) L.mfma = 3;
         }
-        const size_t wf = (size_t)9 * s.Cin * L.n_cot * L.co_t + L.n_cot * L.co_t;
+        // an upsampled input as one GEMM over the stored pixels (net_layer_fwd_mfma_up2); never the first layer, whose
+        // filters take the generic path into LDS
+        static const bool no_phase = std::getenv("SPECTRUM_NETFWD_PHASE") != nullptr && std::getenv("SPECTRUM_NETFWD_PHASE")[0] == '0';
+        if (L.mfma == 0 && l > 0 && s.up == 2 && !s.pool && (w == 8 || w == 16) && (h * w) % 32 == 0 && (nt & 63) == 0 &&
+            s.Cin * s.Cout <= nt && !no_phase && std::getenv("SPECTRUM_NETFWD_VALU") == nullptr) {
+            if (s.Cin == 16 && s.Cout == 8) L.mfma = 4;
+            else if (s.Cin == 8 && s.Cout == 3) L.mfma = 5;
+        }
+        size_t wf = (size_t)9 * s.Cin * L.n_cot * L.co_t + L.n_cot * L.co_t;
+        if (L.mfma == 4) wf = NetPhase<16, 8>::W_FLOATS + 8;
+        else if (L.mfma == 5) wf = NetPhase<8, 3>::W_FLOATS + 4;
         if (wf > w_floats) w_floats = wf;
         if (s.pool) {
             const size_t ib = (size_t)S * T * s.Cout;

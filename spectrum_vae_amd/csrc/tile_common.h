@@ -85,15 +85,15 @@ __device__ __forceinline__ void stage_put(const PlanarSrc& s, const PlanarDst& d
     }
 }
 
-// One pass: every thread walks its units with a stride of nt.  The loop bodies are branch-free and unrolled by 4 so
-// that the global loads of four units are issued before the first LDS write (a global round trip costs far more
+// One pass: every thread walks its units with a stride of nt.  The loop bodies are branch-free and unrolled by U so
+// that the global loads of U units are issued before the first LDS write (a global round trip costs far more
 // than the instructions that consume it).
-template <int MODE>
+template <int MODE, int U = 4>
 __device__ __forceinline__ void stage_pass_m(const PlanarSrc& s, const PlanarDst& d, const StageJob& j, float* lds, int nt) {
     const int HW = s.Hs * s.Ws;
     const FDiv fHW = fd_make(HW), fW = fd_make(s.Ws);
     constexpr bool need_y = MODE == 1 || MODE == 2;
-    constexpr int U = 4;  // units per batch: all their loads are issued (index clamped, so unconditional) before any use
+    // U units per batch: all their loads are issued (index clamped, so unconditional) before any use
     if (j.kind == 0) {
         const FDiv fC4 = fd_make(j.C4);
         for (int u0 = threadIdx.x; u0 < j.units; u0 += U * nt) {

@@ -61,4 +61,8 @@ if bwd and t[:, 24].any():
     for s_, nm in ((24, "e3 wgrad prologue done"), (25, "mfma loop done"), (26, "slab stored")):
         v = (t[:, s_] - t0) / 100.0
         print(f"{nm:22s} med {np.median(v):7.2f}")
+if not bwd and t[:, 20].any():
+    for s_, nm in ((20, "L1: next filters stored"), (21, "L1: copy-out issued"), (22, "L1: next arena zeroed")):
+        v = (t[:, s_] - t0) / 100.0
+        print(f"{nm:26s} med {np.median(v):7.2f}   after 'L1 computed': {np.median(v - (t[:, 6] - t0) / 100.0):6.2f}")
 print("workgroups:", t.shape[0])
