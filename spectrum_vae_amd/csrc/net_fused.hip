@@ -40,6 +40,8 @@ struct NetLayer {
     float alpha;
     int w_off, b_off;                  // float offsets into the flat parameter buffer (b_off < 0: no bias)
     int in_off, out_off;               // LDS float offsets of the input / output arena
+    int idx_off;                       // LDS float offset of this layer's argmax bytes (two arenas, by layer parity: the
+                                       // copy-out of layer l runs beside the arithmetic of layer l + 1)
     int in_plane, in_wp, in_halo;      // planar layout of the input
     int out_plane, out_wp, out_halo;   // planar layout of the output (= the next layer's input layout)
     int co_t, n_cot, ks;
@@ -55,7 +57,6 @@ struct NetFwdArgs {
     const float* params;
     int N, S, n_layers;
     int w_off;    // LDS float offset of the filter arena ([tap][Cin][cop] + cop bias values)
-    int idx_off;  // LDS float offset of the argmax byte arena
     // squared-error loss evaluated while the network output leaves (all null / zero when the forward runs alone):
     // loss_t = targets shaped like the output, loss_dpred receives loss_gscale * (y - t), loss_partials[blockIdx.x] the
     // workgroup's sum of (y - t)^2
@@ -228,7 +229,7 @@ __device__ __forceinline__ void net_layer_fwd(const NetFwdArgs& a, const NetLaye
     float* out = smem + L.out_off;
     const float* w_lds = smem + a.w_off;
     const float* b_lds = w_lds + K * K * L.Cin * cop;
-    uint8_t* idx_lds = reinterpret_cast<uint8_t*>(smem + a.idx_off);
+    uint8_t* idx_lds = reinterpret_cast<uint8_t*>(smem + L.idx_off);
     const int oh = L.out_halo;
     const FDiv f_percot = fd_make(per_cot), f_ks = fd_make(ks), f_T = fd_make(T), f_tx = fd_make(tiles_x);
 
@@ -357,7 +358,7 @@ __device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const Ne
     const float* w_lds = smem + a.w_off;
     const int cop = L.n_cot * CO8;
     const float* b_lds = w_lds + KK * CIN * cop;
-    uint8_t* idx_lds = reinterpret_cast<uint8_t*>(smem + a.idx_off);
+    uint8_t* idx_lds = reinterpret_cast<uint8_t*>(smem + L.idx_off);
     const int oh = L.out_halo, ih = L.in_halo;
     int boff[NT];
 #pragma unroll
@@ -650,7 +651,7 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
                 if (u0 + i * nt < units) emit(gi[i], v[i], t[i]);
         }
         if (L.pool && L.idx != nullptr) {
-            const uint32_t* ib = reinterpret_cast<const uint32_t*>(smem + a.idx_off);
+            const uint32_t* ib = reinterpret_cast<const uint32_t*>(smem + L.idx_off);
 #pragma unroll 4
             for (int u = threadIdx.x; u < units; u += nt)
                 *reinterpret_cast<uint32_t*>(L.idx + ((size_t)n0 * P) * L.Cout + 4 * (size_t)u) = ib[u];
@@ -683,7 +684,7 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
                 if (u0 + i * nt < units) emit(gi[i], v[i], t[i]);
         }
         if (L.pool && L.idx != nullptr) {
-            const uint32_t* ib = reinterpret_cast<const uint32_t*>(smem + a.idx_off);
+            const uint32_t* ib = reinterpret_cast<const uint32_t*>(smem + L.idx_off);
 #pragma unroll 4
             for (int u = threadIdx.x; u < units; u += nt)
                 *reinterpret_cast<uint32_t*>(L.idx + (size_t)n0 * P * L.Cout + 4 * (size_t)u) = ib[u];
@@ -705,7 +706,7 @@ __device__ __forceinline__ void net_copy_out(const NetFwdArgs& a, const NetLayer
             }
         }
         if (L.pool && L.idx != nullptr) {
-            const uint8_t* ib = reinterpret_cast<const uint8_t*>(smem + a.idx_off);
+            const uint8_t* ib = reinterpret_cast<const uint8_t*>(smem + L.idx_off);
             for (int u = threadIdx.x; u < units; u += nt) L.idx[(size_t)n0 * P * L.Cout + u] = ib[u];
         }
     }
@@ -734,17 +735,21 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs args_by_value) {
         {
             const NetLayer& L = a.L[0];
             net_w_load<K>(a, L, wpre, bpre, nt);
+            NET_MARK(23);
             __syncthreads();  // the previous pass is done with every arena
             net_zero(smem + L.in_off, a.S * L.Cin * L.in_plane, nt);
             net_zero(smem + L.out_off, a.S * L.Cout * L.out_plane, nt);
             __syncthreads();
+            NET_MARK(24);
             PlanarSrc src;
             src.x = a.x; src.zy = nullptr; src.zidx = nullptr; src.mode = 0; src.zk = ActGradCoef{};
             src.Hs = L.Hs; src.Ws = L.Ws; src.C = L.Cin;
             const PlanarDst dst{L.Cin, L.in_plane, L.in_wp, L.in_halo};
             // 8 pieces per thread in flight: the 32 x 32 x 3 input of two samples arrives in one global round trip
             stage_pass_m<0, 8>(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
+            NET_MARK(25);
             net_w_store<K>(a, L, wpre, bpre, w_lds, nt);
+            NET_MARK(26);
             __syncthreads();
         }
         NET_MARK(1);
@@ -766,23 +771,21 @@ __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs args_by_value) {
             else net_layer_fwd_any<K>(a, L, smem, ns, nt);
             __syncthreads();
             NET_MARK(3 + 3 * l);
-            // [A] of the next layer first: its filters were loaded a whole layer ago, so this wait does not also wait for
-            // the acknowledgements of the global stores below; the filter arena and this layer's input arena are free
+            // [A] of the next layer: its filters (loaded a whole layer ago) into the filter arena, its output arena (this
+            // layer's input arena) zeroed; both are free now
             if (l + 1 < a.n_layers) {
                 if (a.L[l + 1].mfma == 4) net_wp_store<16, 8>(wpre, bpre, w_lds);
                 else if (a.L[l + 1].mfma == 5) net_wp_store<8, 3>(wpre, bpre, w_lds);
                 else net_w_store<K>(a, a.L[l + 1], wpre, bpre, w_lds, nt);
+                net_zero(smem + a.L[l + 1].out_off, a.S * a.L[l + 1].Cout * a.L[l + 1].out_plane, nt);
+                __syncthreads();
             }
             if (l == 1) NET_MARK(20);
-            // [E]
+            // [E] no barrier after it: the copy only reads what the next layer's arithmetic also only reads (the argmax
+            // bytes of consecutive layers live in different arenas), so a wave goes from its last store straight on
             if (a.loss_t != nullptr && l + 1 == a.n_layers) net_copy_out<true>(a, L, smem, n0, ns, nt, lacc);
             else net_copy_out<false>(a, L, smem, n0, ns, nt, lacc);
             if (l == 1) NET_MARK(21);
-            if (l + 1 < a.n_layers) {
-                net_zero(smem + a.L[l + 1].out_off, a.S * a.L[l + 1].Cout * a.L[l + 1].out_plane, nt);
-                if (l == 1) NET_MARK(22);
-                __syncthreads();
-            }
             NET_MARK(4 + 3 * l);
         }
     }
@@ -813,7 +816,7 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
                     size_t* lds_floats) {
     // activation i is the input of layer i (i = n_layers: the network output); it lives in arena i % 2
     size_t arena[2] = {0, 0};
-    size_t w_floats = 0, idx_bytes = 0;
+    size_t w_floats = 0, idx_bytes[2] = {0, 0};
     int h = H, w = W;
     for (int l = 0; l <= n_layers; ++l) {
         int C, plane, wp, halo;
@@ -872,20 +875,21 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
         if (wf > w_floats) w_floats = wf;
         if (s.pool) {
             const size_t ib = (size_t)S * T * s.Cout;
-            if (ib > idx_bytes) idx_bytes = ib;
+            if (ib > idx_bytes[l & 1]) idx_bytes[l & 1] = ib;
         }
         h = s.pool ? Ho / 2 : Ho;
         w = s.pool ? Wo / 2 : Wo;
     }
     auto r4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
     const size_t o0 = 0, o1 = r4(arena[0]), ow = o1 + r4(arena[1]), oi = ow + r4(w_floats);
+    const size_t oi1 = oi + r4((idx_bytes[0] + 3) / 4);
     for (int l = 0; l < n_layers; ++l) {
         a.L[l].in_off = (int)((l & 1) ? o1 : o0);
         a.L[l].out_off = (int)((l & 1) ? o0 : o1);
+        a.L[l].idx_off = (int)((l & 1) ? oi1 : oi);
     }
     a.w_off = (int)ow;
-    a.idx_off = (int)oi;
-    *lds_floats = oi + r4((idx_bytes + 3) / 4);
+    *lds_floats = oi1 + r4((idx_bytes[1] + 3) / 4);
     return 0;
 }
 

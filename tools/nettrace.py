@@ -62,7 +62,10 @@ if bwd and t[:, 24].any():
         v = (t[:, s_] - t0) / 100.0
         print(f"{nm:22s} med {np.median(v):7.2f}")
 if not bwd and t[:, 20].any():
-    for s_, nm in ((20, "L1: next filters stored"), (21, "L1: copy-out issued"), (22, "L1: next arena zeroed")):
+    for s_, nm in ((20, "L1: next layer set up"), (21, "L1: copy-out issued")):
         v = (t[:, s_] - t0) / 100.0
         print(f"{nm:26s} med {np.median(v):7.2f}   after 'L1 computed': {np.median(v - (t[:, 6] - t0) / 100.0):6.2f}")
+    for s_, nm in ((23, "filter loads issued"), (24, "arenas zeroed"), (25, "input in LDS"), (26, "filters in LDS")):
+        v = (t[:, s_] - t[:, 0]) / 100.0
+        print(f"{nm:26s} med {np.median(v):7.2f} after the workgroup's start")
 print("workgroups:", t.shape[0])
