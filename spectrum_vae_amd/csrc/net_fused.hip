@@ -11,6 +11,7 @@
 //   [E] copies the output arena to global memory as NHWC with full-width stores (the backward pass reads it).
 // One launch replaces one launch per layer, and no layer waits for a global-memory round trip of its input.
 #include <cstdlib>
+#include <type_traits>
 
 #include "tile_common.h"
 
@@ -717,6 +718,106 @@ __device__ __forceinline__ void net_zero(float* arena, int floats, int nt) {
     for (int i = threadIdx.x; i < (floats >> 2); i += nt) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void net_static_for(F& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        net_static_for<I + 1, N>(f);
+    }
+}
+
+// The pass loop of net_fwd_s1 (below) for a layer table known at compile time: the layer loop is unrolled, layer(l)
+// returns a table row whose extents and LDS layout are constants, and every index division, layer dispatch and filter
+// layout folds to the one case the row names.  256 threads, exactly ceil(N / S) workgroups.
+template <int K, int NL, typename LayerOf>
+__device__ __forceinline__ void net_fwd_run(const NetFwdArgs& a, LayerOf layer, float* smem) {
+    static_assert(NL > 0, "compile-time layer tables only");
+    constexpr int nt = 256;
+    float* w_lds = smem + a.w_off;
+    float4 wpre[kNetWPre];
+    float bpre;
+    float lacc = 0.f;
+    NET_MARK(0);
+    // one pass per workgroup (the launch has ceil(N / S) of them): with a pass LOOP around constant layer extents the
+    // compiler hoists every layer's per-lane index arithmetic in front of it and spills what it hoisted
+    {
+        const int n0 = blockIdx.x * a.S;
+        const int ns = min(a.S, a.N - n0);
+        {
+            const NetLayer& L = layer(0);
+            net_w_load<K>(a, L, wpre, bpre, nt);
+            NET_MARK(23);
+            __syncthreads();  // the previous pass is done with every arena
+            net_zero(smem + L.in_off, a.S * L.Cin * L.in_plane, nt);
+            net_zero(smem + L.out_off, a.S * L.Cout * L.out_plane, nt);
+            __syncthreads();
+            NET_MARK(24);
+            PlanarSrc src;
+            src.x = a.x; src.zy = nullptr; src.zidx = nullptr; src.mode = 0; src.zk = ActGradCoef{};
+            src.Hs = L.Hs; src.Ws = L.Ws; src.C = L.Cin;
+            const PlanarDst dst{L.Cin, L.in_plane, L.in_wp, L.in_halo};
+            // 8 pieces per thread in flight: the 32 x 32 x 3 input of two samples arrives in one global round trip
+            stage_pass_m<0, 8>(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
+            NET_MARK(25);
+            net_w_store<K>(a, L, wpre, bpre, w_lds, nt);
+            NET_MARK(26);
+            __syncthreads();
+        }
+        NET_MARK(1);
+        auto step = [&](auto lc) __attribute__((always_inline)) {
+            constexpr int l = decltype(lc)::value;
+            const NetLayer L = layer(l);
+            const bool more = l + 1 < a.n_layers;
+            // the layer's filters are in the filter arena and its output arena is zero (set up by the previous step)
+            NET_MARK(2 + 3 * l);
+            // [B]
+            if (more) {
+                const NetLayer Ln = layer(l + 1);
+                if (Ln.mfma >= 4) net_wp_load(a, Ln, wpre, bpre);
+                else net_w_load<K>(a, Ln, wpre, bpre, nt);
+            }
+            // [C]
+            if (L.mfma == 1) net_layer_fwd_mfma<8, 1, 1, 1>(a, L, smem, ns, nt);
+            else if (L.mfma == 2) net_layer_fwd_mfma<16, 2, 1, 1>(a, L, smem, ns, nt);
+            else if (L.mfma == 3) net_layer_fwd_mfma<32, 1, 2, 0>(a, L, smem, ns, nt);
+            else if (L.mfma == 4) net_layer_fwd_mfma_up2<16, 8>(a, L, smem, ns, nt);
+            else if (L.mfma == 5) net_layer_fwd_mfma_up2<8, 3>(a, L, smem, ns, nt);
+            else net_layer_fwd_any<K>(a, L, smem, ns, nt);
+            __syncthreads();
+            NET_MARK(3 + 3 * l);
+            // [A] of the next layer: its filters (loaded a whole layer ago) into the filter arena, its output arena (this
+            // layer's input arena) zeroed; both are free now
+            if (more) {
+                const NetLayer Ln = layer(l + 1);
+                if (Ln.mfma == 4) net_wp_store<16, 8>(wpre, bpre, w_lds);
+                else if (Ln.mfma == 5) net_wp_store<8, 3>(wpre, bpre, w_lds);
+                else net_w_store<K>(a, Ln, wpre, bpre, w_lds, nt);
+                net_zero(smem + Ln.out_off, a.S * Ln.Cout * Ln.out_plane, nt);
+                __syncthreads();
+            }
+            if (l == 1) NET_MARK(20);
+            // [E] no barrier after it: the copy only reads what the next layer's arithmetic also only reads (the argmax
+            // bytes of consecutive layers live in different arenas), so a wave goes from its last store straight on
+            if (a.loss_t != nullptr && !more) net_copy_out<true>(a, L, smem, n0, ns, nt, lacc);
+            else net_copy_out<false>(a, L, smem, n0, ns, nt, lacc);
+            if (l == 1) NET_MARK(21);
+            NET_MARK(4 + 3 * l);
+        };
+        net_static_for<0, NL>(step);
+    }
+    if (a.loss_t != nullptr) {  // fixed-order sum over the workgroup: lanes of a wave, then the waves in index order
+        __shared__ float lred[16];
+        for (int o = 32; o > 0; o >>= 1) lacc += __shfl_down(lacc, o);
+        if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = lacc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < (nt >> 6); ++w) t += lred[w];
+            a.loss_partials[blockIdx.x] = t;
+        }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(512) void net_fwd_s1(NetFwdArgs args_by_value) {
     // the layer table is indexed at run time: read it where the launch put it (the kernel-argument segment, through the
@@ -812,14 +913,20 @@ struct NetPlan {
 
 constexpr size_t kNetLdsPerBlock = 78 * 1024;  // two workgroups share a CU's 160 KiB
 
-static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int N, int H, int W, int S, int nt,
-                    size_t* lds_floats) {
+// Extents, LDS layout and kernel variants of every layer for S samples per workgroup of nt threads: everything in the
+// table that does not depend on pointers or parameter offsets.  constexpr: the same function lays out the table the
+// compile-time kernel (net_fwd_cae) is built for.
+struct NetLayoutFlags {
+    bool no_pair, no_phase, valu;
+};
+constexpr size_t net_layout(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int H, int W, int S, int nt,
+                            NetLayoutFlags f) {
     // activation i is the input of layer i (i = n_layers: the network output); it lives in arena i % 2
     size_t arena[2] = {0, 0};
     size_t w_floats = 0, idx_bytes[2] = {0, 0};
     int h = H, w = W;
     for (int l = 0; l <= n_layers; ++l) {
-        int C, plane, wp, halo;
+        int C = 0, plane = 0, wp = 0, halo = 0;
         if (l < n_layers) {
             C = layers[l].Cin; halo = 1;
             wp = (w + 2 * halo + 3) & ~3;
@@ -838,16 +945,14 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
         if (l == n_layers) break;
         const sv_net_layer& s = layers[l];
         NetLayer& L = a.L[l];
-        L.Cin = s.Cin; L.Cout = s.Cout; L.Hs = h; L.Ws = w; L.up = s.up; L.pool = s.pool; L.act = s.act; L.alpha = s.alpha;
-        L.w_off = (int)s.w_off; L.b_off = (int)s.b_off; L.in_plane = plane; L.in_wp = wp; L.in_halo = halo;
-        L.y = (float*)s.y; L.idx = s.idx;
+        L.Cin = s.Cin; L.Cout = s.Cout; L.Hs = h; L.Ws = w; L.up = s.up; L.pool = s.pool;
+        L.in_plane = plane; L.in_wp = wp; L.in_halo = halo;
         L.co_t = s.Cout > 4 ? 8 : 4;
         L.n_cot = (s.Cout + L.co_t - 1) / L.co_t;
         const int Ho = h * s.up, Wo = w * s.up;
         const int T = (Ho / 2) * (Wo / 2);
-        static const bool no_pair = std::getenv("SPECTRUM_NETFWD_PAIR") != nullptr && std::getenv("SPECTRUM_NETFWD_PAIR")[0] == '0';
         L.pair = 0;
-        if (S % 2 == 0 && !no_pair) {
+        if (S % 2 == 0 && !f.no_pair) {
             if (s.up == 1 && L.co_t == 8 && s.pool) L.pair = 1;
         }
         int ks = 1;
@@ -855,17 +960,15 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
         L.ks = ks;
         // matrix-core variants exist for the shapes whose 16-wide tiles are full: (Cin, Cout, up, pool)
         L.mfma = 0;
-        if ((Wo == 8 || Wo == 16) && (Ho * Wo) % 32 == 0 && (nt & 63) == 0 && l + 1 < n_layers &&
-            std::getenv("SPECTRUM_NETFWD_VALU") == nullptr) {
+        if ((Wo == 8 || Wo == 16) && (Ho * Wo) % 32 == 0 && (nt & 63) == 0 && l + 1 < n_layers && !f.valu) {
             if (s.Cin == 8 && s.Cout == 16 && s.up == 1 && s.pool) L.mfma = 1;
             else if (s.Cin == 16 && s.Cout == 32 && s.up == 1 && s.pool) L.mfma = 2;
             else if (s.Cin == 32 && s.Cout == 16 && s.up == 2 && !s.pool) L.mfma = 3;
         }
         // an upsampled input as one GEMM over the stored pixels (net_layer_fwd_mfma_up2); never the first layer, whose
         // filters take the generic path into LDS
-        static const bool no_phase = std::getenv("SPECTRUM_NETFWD_PHASE") != nullptr && std::getenv("SPECTRUM_NETFWD_PHASE")[0] == '0';
         if (L.mfma == 0 && l > 0 && s.up == 2 && !s.pool && (w == 8 || w == 16) && (h * w) % 32 == 0 && (nt & 63) == 0 &&
-            s.Cin * s.Cout <= nt && !no_phase && std::getenv("SPECTRUM_NETFWD_VALU") == nullptr) {
+            s.Cin * s.Cout <= nt && !f.no_phase && !f.valu) {
             if (s.Cin == 16 && s.Cout == 8) L.mfma = 4;
             else if (s.Cin == 8 && s.Cout == 3) L.mfma = 5;
         }
@@ -880,17 +983,101 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
         h = s.pool ? Ho / 2 : Ho;
         w = s.pool ? Wo / 2 : Wo;
     }
-    auto r4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
-    const size_t o0 = 0, o1 = r4(arena[0]), ow = o1 + r4(arena[1]), oi = ow + r4(w_floats);
-    const size_t oi1 = oi + r4((idx_bytes[0] + 3) / 4);
+    const size_t o0 = 0, o1 = (arena[0] + 3) & ~(size_t)3, ow = o1 + ((arena[1] + 3) & ~(size_t)3);
+    const size_t oi = ow + ((w_floats + 3) & ~(size_t)3);
+    const size_t oi1 = oi + (((idx_bytes[0] + 3) / 4 + 3) & ~(size_t)3);
     for (int l = 0; l < n_layers; ++l) {
         a.L[l].in_off = (int)((l & 1) ? o1 : o0);
         a.L[l].out_off = (int)((l & 1) ? o0 : o1);
         a.L[l].idx_off = (int)((l & 1) ? oi1 : oi);
     }
     a.w_off = (int)ow;
-    *lds_floats = oi1 + r4((idx_bytes[1] + 3) / 4);
+    a.S = S;
+    a.n_layers = n_layers;
+    return oi1 + (((idx_bytes[1] + 3) / 4 + 3) & ~(size_t)3);
+}
+
+static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int N, int H, int W, int S, int nt,
+                    size_t* lds_floats) {
+    // the switches are read at every plan, so a process can compare the variants
+    auto off = [](const char* name) { const char* e = std::getenv(name); return e != nullptr && e[0] == '0'; };
+    const NetLayoutFlags flags{off("SPECTRUM_NETFWD_PAIR"), off("SPECTRUM_NETFWD_PHASE"), std::getenv("SPECTRUM_NETFWD_VALU") != nullptr};
+    *lds_floats = net_layout(a, layers, n_layers, H, W, S, nt, flags);
+    for (int l = 0; l < n_layers; ++l) {
+        const sv_net_layer& s = layers[l];
+        NetLayer& L = a.L[l];
+        L.act = s.act; L.alpha = s.alpha; L.w_off = (int)s.w_off; L.b_off = (int)s.b_off;
+        L.y = (float*)s.y; L.idx = s.idx;
+    }
     return 0;
+}
+
+// ---- the forward launch built for ONE layer table: the conv stack of CAEPadded at the run_model.py defaults
+// (autoencoder.py:437-526 with global_vars / run_model.py:80-104: 3 -> 8 -> 16 -> 32 pooled, 32 -> 16 -> 8 -> 3
+// upsampled, 32 x 32 inputs), two samples per workgroup of 256 threads.  Only pointers, parameter offsets, activations
+// and the batch size are launch arguments; a launch takes this kernel when the table net_fill computes for it equals
+// the compile-time one field by field, and the run-time-table kernel otherwise.
+constexpr int kCaeLayers = 6;
+constexpr sv_net_layer kCaeChain[kCaeLayers] = {
+    {3, 8, 3, 1, 1, 0, 0.f, 0, 0, 0, nullptr, nullptr},   {8, 16, 3, 1, 1, 0, 0.f, 0, 0, 0, nullptr, nullptr},
+    {16, 32, 3, 1, 1, 0, 0.f, 0, 0, 0, nullptr, nullptr}, {32, 16, 3, 2, 0, 0, 0.f, 0, 0, 0, nullptr, nullptr},
+    {16, 8, 3, 2, 0, 0, 0.f, 0, 0, 0, nullptr, nullptr},  {8, 3, 3, 2, 0, 0, 0.f, 0, 0, 0, nullptr, nullptr}};
+struct NetCaeTable {
+    NetFwdArgs a;
+    size_t lds_floats;
+};
+constexpr NetCaeTable net_cae_table() {
+    NetCaeTable t{};
+    t.lds_floats = net_layout(t.a, kCaeChain, kCaeLayers, 32, 32, 2, 256, NetLayoutFlags{false, false, false});
+    return t;
+}
+constexpr NetCaeTable kCae = net_cae_table();
+static_assert(kCae.lds_floats * sizeof(float) <= 78 * 1024, "two workgroups per CU");
+
+struct NetCaeLayerArgs {
+    int act;
+    float alpha;
+    int w_off, b_off;
+    float* y;
+    uint8_t* idx;
+};
+struct NetCaeArgs {
+    const float* x;
+    const float* params;
+    int N;
+    const float* loss_t;
+    float* loss_dpred;
+    float* loss_partials;
+    float loss_gscale;
+    NetCaeLayerArgs rt[kCaeLayers];
+};
+
+__global__ __launch_bounds__(256, 2) void net_fwd_cae(NetCaeArgs r) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    NetFwdArgs a{};
+    a.x = r.x; a.params = r.params; a.N = r.N; a.S = kCae.a.S; a.n_layers = kCaeLayers; a.w_off = kCae.a.w_off;
+    a.loss_t = r.loss_t; a.loss_dpred = r.loss_dpred; a.loss_partials = r.loss_partials; a.loss_gscale = r.loss_gscale;
+    net_fwd_run<3, kCaeLayers>(a, [&](int l) __attribute__((always_inline)) {
+        NetLayer L = kCae.a.L[l];
+        L.act = r.rt[l].act; L.alpha = r.rt[l].alpha; L.w_off = r.rt[l].w_off; L.b_off = r.rt[l].b_off;
+        L.y = r.rt[l].y; L.idx = r.rt[l].idx;
+        return L;
+    }, smem);
+}
+
+// true when the plan's table is the compile-time one (pointers, offsets and activations aside)
+static bool net_plan_is_cae(const NetFwdArgs& p, int nt) {
+    if (std::getenv("SPECTRUM_NETFWD_GENERIC") != nullptr || nt != 256 || p.n_layers != kCaeLayers || p.S != kCae.a.S || p.w_off != kCae.a.w_off) return false;
+    for (int l = 0; l < kCaeLayers; ++l) {
+        const NetLayer &x = p.L[l], &y = kCae.a.L[l];
+        if (x.Cin != y.Cin || x.Cout != y.Cout || x.Hs != y.Hs || x.Ws != y.Ws || x.up != y.up || x.pool != y.pool ||
+            x.in_off != y.in_off || x.out_off != y.out_off || x.idx_off != y.idx_off || x.in_plane != y.in_plane ||
+            x.in_wp != y.in_wp || x.in_halo != y.in_halo || x.out_plane != y.out_plane || x.out_wp != y.out_wp ||
+            x.out_halo != y.out_halo || x.co_t != y.co_t || x.n_cot != y.n_cot || x.ks != y.ks || x.pair != y.pair ||
+            x.mfma != y.mfma)
+            return false;
+    }
+    return true;
 }
 
 int net_validate(const sv_net_layer* layers, int n_layers, int N, int H, int W, const char* who) {
@@ -953,6 +1140,9 @@ static int net_enable_lds(size_t bytes) {
     if (bytes <= enabled) return SV_OK;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&net_fwd_s1<3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNetLdsPerBlock);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&net_fwd_cae), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kNetLdsPerBlock);
     if (e != hipSuccess) return fail(SV_E_LAUNCH, "net_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
     enabled = kNetLdsPerBlock;
     return SV_OK;
@@ -1595,6 +1785,22 @@ static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_la
         p.args.loss_partials = partials;
         p.args.loss_gscale = (float)(2.0 * (double)loss_scale / count);
         *n_partials = p.grid;
+    }
+    // one workgroup per pass there: with the loss, the per-workgroup sums must fit the caller's partials buffer
+    // (sv_loss_workspace_bytes: 1024 floats)
+    if (net_plan_is_cae(p.args, p.nt) && (y_true == nullptr || (N + p.S - 1) / p.S <= 1024)) {
+        NetCaeArgs r{};
+        r.x = p.args.x; r.params = p.args.params; r.N = N;
+        r.loss_t = p.args.loss_t; r.loss_dpred = p.args.loss_dpred; r.loss_partials = p.args.loss_partials;
+        r.loss_gscale = p.args.loss_gscale;
+        for (int l = 0; l < kCaeLayers; ++l) {
+            const NetLayer& L = p.args.L[l];
+            r.rt[l] = NetCaeLayerArgs{L.act, L.alpha, L.w_off, L.b_off, L.y, L.idx};
+        }
+        const int passes = (N + p.S - 1) / p.S;
+        if (y_true != nullptr) *n_partials = passes;
+        hipLaunchKernelGGL(net_fwd_cae, dim3((unsigned)passes), dim3(256), p.lds_bytes, to_stream(stream), r);
+        return check_launch("net_fwd_cae");
     }
     hipLaunchKernelGGL((net_fwd_s1<3>), dim3((unsigned)p.grid), dim3((unsigned)p.nt), p.lds_bytes, to_stream(stream), p.args);
     return check_launch("net_fwd_s1");

@@ -553,6 +553,40 @@ def test_whole_network_forward_matches_per_layer_path_and_oracle(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 5, 64, 1100, 2100])
+def test_forward_kernel_built_for_the_default_layer_table_equals_the_run_time_table_kernel(n, monkeypatch):
+    """The run_model.py default conv stack has a forward kernel compiled for its layer table (extents and LDS layout as
+    constants); SPECTRUM_NETFWD_GENERIC selects the kernel that reads the table at run time.  Same arithmetic in the same
+    order: every layer output, the argmax bytes, the loss gradient and the loss partial sums agree bit for bit.  2100
+    samples are more passes than the loss workspace has slots, so that launch takes the run-time-table kernel by itself."""
+    from spectrum_vae_amd import autoencoder, ops
+    from spectrum_vae_amd.losses import to_device_f32
+    x = to_device_f32(data(n, seed=51 + n))
+    got = {}
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("SPECTRUM_NETFWD_GENERIC", "1")
+        else:
+            monkeypatch.delenv("SPECTRUM_NETFWD_GENERIC", raising=False)
+        model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
+        model.build((None, 32, 32, 3))
+        model._materialize()
+        torch.manual_seed(3)
+        model._params.copy_(torch.randn_like(model._params) * 0.2)
+        part = torch.zeros(ops.loss_workspace_floats(), device="cuda")
+        dpred = torch.empty(n, 32, 32, 3, device="cuda")
+        pred = model.forward_raw(x, True, None, (x, dpred, part))
+        ctx = model._calls[-1]
+        outs = [ctx.saved[id(l)]["y"].clone() for l in model._conv_chain()]
+        idxs = [ctx.saved[id(l)]["idx"].clone() for l in model._conv_chain() if "idx" in ctx.saved[id(l)]]
+        got[generic] = (pred.clone(), dpred, float(part.sum()), outs, idxs)
+    a, b = got[False], got[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert abs(a[2] - b[2]) <= 1e-6 * abs(b[2])  # the same squared errors, summed over differently many workgroups
+    assert all(torch.equal(u, v) for u, v in zip(a[3], b[3])) and all(torch.equal(u, v) for u, v in zip(a[4], b[4]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 5, 64, 1100])
 def test_forward_launch_with_loss_matches_the_separate_loss(n):
     """MSE evaluated while the one-launch forward writes its output: gradient and value against the loss kernel, the value
