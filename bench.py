@@ -104,7 +104,9 @@ class OpTimer:
                 for i in range(nj):
                     q = arr[i].g
                     fl += 2 * q.N * q.Ho * q.Wo * q.Cout * q.KH * q.KW * q.Cin
-                info = {"jobs": nj, "flops": fl, "single_launch": not args[2]}
+                shapes = sorted((arr[i].g.Cin, arr[i].g.Cout, arr[i].g.W) for i in range(nj))
+                nhwc = all(sh in ((3, 8, 32), (8, 16, 16), (16, 32, 8), (32, 16, 8), (16, 8, 16), (8, 3, 32)) for sh in shapes)
+                info = {"jobs": nj, "flops": fl, "single_launch": not args[2], "nhwc": nhwc}
             elif name in ("sv_convnet_fwd", "sv_convnet_fwd_mse"):
                 arr, nl, n, h, w = args[0], args[1], args[2], args[3], args[4]
                 fl = 0
@@ -139,8 +141,15 @@ def kernel_of_call(name: str, g):
         # the layer table of the run_model.py defaults has a kernel built for it; other tables take the run-time-table one
         known = g.get("default_chain") and "SPECTRUM_NETFWD_GENERIC" not in os.environ
         return ("net_fwd_cae" if known else "net_fwd_s1<3>"), float(g["flops"])
-    if name == "sv_conv2d_wgrad_batch":  # with its own reduction the call is two launches: not a single kernel's time
-        return ("wgrad_s1_multi<3>", float(g["flops"])) if g["single_launch"] else None
+    if name == "sv_conv2d_wgrad_batch":
+        if g["single_launch"]:
+            return "wgrad_s1_multi<3>", float(g["flops"])
+        # with its own reduction the call is two launches, wgrad_nhwc_multi and the few-microsecond wn_reduce_multi: the
+        # call's time ranks it among the kernels, and the back-to-back measurement below switches the second launch off
+        # (SPECTRUM_WGRAD_DBG=8) so that the figure is the first kernel's alone
+        if g.get("nhwc") and os.environ.get("SPECTRUM_WGRAD_NHWC", "1")[0] != "0":
+            return "wgrad_nhwc_multi", float(g["flops"])
+        return None
     if "KH" not in g:
         return None
     fl = 2.0 * g["N"] * g["Ho"] * g["Wo"] * g["Cout"] * g["KH"] * g["KW"] * g["Cin"]
@@ -313,6 +322,9 @@ def main():
             again = [(fn, a) for (n_, info, fn, a) in ot.calls
                      if (kernel_of_call(n_, info) or (None,))[0] == kname]
             reps_k = 20
+            only_first_launch = kname == "wgrad_nhwc_multi"
+            if only_first_launch:
+                os.environ["SPECTRUM_WGRAD_DBG"] = "8"
             for fn, a in again:
                 fn(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -322,6 +334,8 @@ def main():
                     fn(*a)
             e1.record()
             torch.cuda.synchronize()
+            if only_first_launch:
+                del os.environ["SPECTRUM_WGRAD_DBG"]
             avg_us = e0.elapsed_time(e1) * 1e3 / (reps_k * max(len(again), 1)) if again else avg_us_in_step
             ach = fl / (avg_us * 1e-6) / 1e12
             traffic = None
@@ -337,7 +351,11 @@ def main():
                         "note": "f32 vector FMA peak == f32 MFMA peak on MI355X; avg_launch_us: this kernel's calls of "
                                 "one step issued 20 times back to back between two HIP events on the launch stream; "
                                 "avg_call_us_in_eager_step: event-to-event time of the same calls inside an eager step "
-                                "(includes the host launch path)"}
+                                "(includes the host launch path)"
+                                + ("; the call's second launch (wn_reduce_multi, the sum of the slabs) is switched off in the "
+                                   "back-to-back measurement and included in the eager call's time" if only_first_launch else "")}
+            roofline["kernels_ranked_by_eager_call_us"] = {k: round(v["us_per_step"], 1) for k, v in
+                                                           sorted(groups.items(), key=lambda kv: -kv[1]["us_per_step"])[:4]}
             # calls that are more than one launch cannot be put against a single kernel's row; when such a call is longer
             # than the dominant kernel, say so beside it
             multi = [r_ for r_ in table if kernel_of_call(r_["call"], r_["geom"]) is None and r_["geom"] and "flops" in r_["geom"]]

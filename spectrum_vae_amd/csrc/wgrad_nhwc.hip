@@ -514,6 +514,10 @@ int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStrea
     hipLaunchKernelGGL(wgrad_nhwc_multi, dim3((unsigned)blocks), dim3(256), lds, st, m);
     int rc = check_launch("wgrad_nhwc_multi");
     if (rc) return rc;
+    // measurements only (bit 8 of SPECTRUM_WGRAD_DBG): time the launch above without the sum of its slabs; dw / db stay
+    // as they were
+    if (const char* e = std::getenv("SPECTRUM_WGRAD_DBG"))
+        if (atoi(e) & 8) return SV_OK;
     hipLaunchKernelGGL(wn_reduce_multi, dim3((unsigned)rblocks), dim3(1024), 0, st, rm);
     return check_launch("wn_reduce_multi");
 }
