@@ -40,13 +40,20 @@ __device__ __forceinline__ float dn_dpp_ror8(float v) {  // value of lane ^ 8 (r
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
 }
 
-template <int CZ, int CX, int WO>
+// PH (a conv behind a 2x nearest upsampling, a.up == 2): the result tile holds 16 STORED pixels instead of 16 pixels of
+// the upsampled image.  The four upsampled pixels above a stored pixel (r, c) read dz rows 2r - 1 .. 2r + 2 and columns
+// 2c - 1 .. 2c + 2 between them, each dz pixel of that 4 x 4 window with the SUM of the filter taps that connect it to
+// one of the four (window row t reads kernel rows {2 - t, 3 - t} within 0..2, columns alike), so
+//   dx[r, c][ci] = sum over the 4 x 4 window and co of dz[2r - 1 + ta, 2c - 1 + tb][co] * wsum[ta][tb][ci][co]:
+// 16 window taps per stored pixel instead of 4 x 9 per stored pixel, and no 2 x 2 sums afterwards.
+template <int CZ, int CX, int WO, bool PH>
 __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     constexpr int MT = (CX + 15) / 16;
     constexpr int VEC = CZ == 3 ? 1 : (CZ == 8 ? 2 : 4);          // dz channels per lane and read
     constexpr int NH = CZ == 3 ? 1 : CZ / (4 * VEC);              // reads per tap
-    constexpr int NSTEP = CZ == 3 ? 7 : 9 * NH;                   // reads per pixel tile
-    constexpr int SW = WO + 2, TX = WO / 8;
+    constexpr int TW = PH ? 4 : 3, TAPS = TW * TW;                // window of dz pixels a result pixel reads
+    constexpr int NSTEP = CZ == 3 ? (3 * TAPS + 3) / 4 : TAPS * NH;  // reads per pixel tile
+    constexpr int SW = WO + 2, TX = PH ? WO / 16 : WO / 8;
     constexpr bool PING = NSTEP * VEC <= 36;                      // operand registers of two tiles fit
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -118,18 +125,30 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     // element j is output channel h * 4 VEC + VEC * lk + j of tap (a, b) = mirrored (kh, kw)
     float wreg[NSTEP][VEC][MT];
     int zoff[CZ == 3 ? NSTEP : 1];  // 3 channels: reduction index kk = 4 s + lk walks (a, b, co) flattened
+    // the filter value that connects window position (ta, tb) of dz with input channel ci: one mirrored tap, or (PH) the
+    // sum of the taps named above
+    auto wtap = [&](int ta, int tb, int ci, int co) {
+        if (!PH) return a.w[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co];
+        float t = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                if ((kh == 2 - ta || kh == 3 - ta) && (kw == 2 - tb || kw == 3 - tb)) t += a.w[((kh * 3 + kw) * CX + ci) * CZ + co];
+        return t;
+    };
     if (CZ == 3) {
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int kk = 4 * s + lk;
-            const bool ok = kk < 27;
+            const bool ok = kk < 3 * TAPS;
             const int k2 = ok ? kk : 0;
-            const int ta = k2 / 9, rem = k2 - ta * 9, tb = rem / 3, co = rem - tb * 3;
+            const int ta = k2 / (3 * TW), rem = k2 - ta * (3 * TW), tb = rem / 3, co = rem - tb * 3;
             zoff[s] = ta * SW * CZ + rem;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int ci = mt * 16 + li;
-                wreg[s][0][mt] = (ok && ci < CX) ? a.w[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co] : 0.f;
+                wreg[s][0][mt] = (ok && ci < CX) ? wtap(ta, tb, ci, co) : 0.f;
             }
         }
     } else {
@@ -137,18 +156,19 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int tap = s / NH, h = s - tap * NH;
-            const int ta = tap / 3, tb = tap - ta * 3;
+            const int ta = tap / TW, tb = tap - ta * TW;
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int ci = mt * 16 + li;
                     const int co = h * 4 * VEC + VEC * lk + j;
-                    wreg[s][j][mt] = ci < CX ? a.w[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co] : 0.f;
+                    wreg[s][j][mt] = ci < CX ? wtap(ta, tb, ci, co) : 0.f;
                 }
         }
     }
-    const int lz = (pr * SW + pc) * CZ + (CZ == 3 ? 0 : VEC * lk);  // the lane's pixel (and channel group) inside a tile
+    // the lane's pixel (and channel group) inside a tile; PH: the window of stored pixel (pr, pc) starts at (2 pr, 2 pc)
+    const int lz = (PH ? 2 : 1) * (pr * SW + pc) * CZ + (CZ == 3 ? 0 : VEC * lk);
 
     int n0 = blockIdx.x * a.ns;
     if (n0 < a.N) load_pass(n0);
@@ -176,14 +196,14 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
         auto load_tile = [&](float (&zv)[NSTEP][VEC], int i) {
             int ss, oh, ow0;
             tile_pos(i, ss, oh, ow0);
-            const float* zq = smem + ss * sampleZ + (oh * SW + ow0) * CZ + lz;
+            const float* zq = smem + ss * sampleZ + (PH ? 2 : 1) * (oh * SW + ow0) * CZ + lz;  // PH: (oh, ow0) are stored pixels
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
                 if (CZ == 3) {
                     zv[s][0] = zq[zoff[s]];
                 } else {
                     const int tap = s / NH, h = s - tap * NH;
-                    const float* q = zq + ((tap / 3) * SW + tap % 3) * CZ + h * 4 * VEC;
+                    const float* q = zq + ((tap / TW) * SW + tap % TW) * CZ + h * 4 * VEC;
                     if (VEC == 2) {
                         const float2 v = *reinterpret_cast<const float2*>(q);
                         zv[s][0] = v.x; zv[s][VEC - 1] = v.y;
@@ -209,7 +229,13 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
             tile_pos(i, ss, oh, ow0);
             if (!live) return;  // the second tile of the last pair when a wave's tile count is odd
             // lane (li, lk) holds input channels mt * 16 + 4 lk .. + 3 of pixel (oh + pr, ow0 + pc)
-            if (a.up == 2) {
+            if (PH) {
+                float* o = a.dx + (((size_t)(n0 + ss) * (H >> 1) + oh + pr) * (WO >> 1) + ow0 + pc) * CX;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (mt * 16 + 4 * lk < CX)
+                        *reinterpret_cast<float4*>(o + mt * 16 + 4 * lk) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+            } else if (a.up == 2) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -260,8 +286,14 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------- host side
 template <int CZ, int CX, int WO>
-static int dn_launch(const DnArgs& a, int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO>), dim3((unsigned)grid), dim3(256), lds, st, a);
+static int dn_launch(const DnArgs& a, int grid, size_t lds, hipStream_t st, bool ph) {
+    if constexpr (WO >= 16) {  // a tile is 2 x 8 stored pixels: the stored image must be 8 wide
+        if (ph) {
+            hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
+            return check_launch("dgrad_nhwc");
+        }
+    }
+    hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return check_launch("dgrad_nhwc");
 }
 
@@ -284,7 +316,12 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     else return 1;
     if (CZ == 3 && zmode == 2) return 1;
     if ((H & 1) || y == nullptr) return 1;
-    const int tps = (H / 2) * (W / 8);
+    // an upsampled conv as a 4 x 4 window over the stored pixels (PH in the kernel) where the stored image holds tiles
+    bool ph = g.up_h == 2 && (shape == 0 || shape == 1) && (H % 4) == 0 && (W % 16) == 0;
+    if (const char* e = std::getenv("SPECTRUM_DGRAD_PHASE"))
+        if (e[0] == '0') ph = false;
+    int tps = ph ? (H / 4) * (W / 16) : (H / 2) * (W / 8);
+    if (ph && (tps < 4 || (tps & (tps - 1)))) { ph = false; tps = (H / 2) * (W / 8); }
     if (tps < 4 || (tps & (tps - 1))) return 1;
     const int64_t sampleZ = (int64_t)(H + 2) * (W + 2) * CZ;
     const int64_t units = (zmode == 2 ? (int64_t)(H / 2) * (W / 2) * CZ : (int64_t)H * W * CZ) / 4;
@@ -293,6 +330,7 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     // four workgroups share a CU and hide each other's load latencies), two per CU for the 16-wide image with 8-channel
     // dz, one per CU elsewhere, where more workgroups only repeat the filter loads
     int grid = shape == 0 ? 1024 : (shape == 1 ? 512 : 256);
+    if (ph) grid = shape == 0 ? 512 : 256;  // a quarter of the tiles per sample: fewer, longer-lived workgroups
     if (const char* e = std::getenv("SPECTRUM_DGRAD_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if (grid > g.N) grid = g.N;
     int ns = 1;
@@ -305,11 +343,11 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     a.zk = act_grad_coef(act, alpha);
     const size_t bytes = lds(ns);
     switch (shape) {
-        case 0: return dn_launch<3, 8, 32>(a, grid, bytes, st);
-        case 1: return dn_launch<8, 16, 16>(a, grid, bytes, st);
-        case 2: return dn_launch<16, 32, 8>(a, grid, bytes, st);
-        case 3: return dn_launch<32, 16, 8>(a, grid, bytes, st);
-        default: return dn_launch<16, 8, 16>(a, grid, bytes, st);
+        case 0: return dn_launch<3, 8, 32>(a, grid, bytes, st, ph);
+        case 1: return dn_launch<8, 16, 16>(a, grid, bytes, st, ph);
+        case 2: return dn_launch<16, 32, 8>(a, grid, bytes, st, false);
+        case 3: return dn_launch<32, 16, 8>(a, grid, bytes, st, false);
+        default: return dn_launch<16, 8, 16>(a, grid, bytes, st, false);
     }
 }
 

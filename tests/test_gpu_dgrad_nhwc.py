@@ -66,3 +66,27 @@ def test_matches_float64(spec, n, monkeypatch):
     monkeypatch.setenv("SPECTRUM_DGRAD_NHWC", "0")  # the planar kernels on the same call
     ops.conv2d_bwd(*args)
     assert float((dx - first).abs().max()) <= 4e-6 * float(first.abs().max())
+
+
+@pytest.mark.parametrize("n", [1, 5, 130, 1027])
+@pytest.mark.parametrize("spec", [LAYERS[3], LAYERS[4]], ids=["16to8", "8to3"])
+def test_stored_pixel_form_of_upsampled_layers_agrees_with_the_direct_form(spec, n, monkeypatch):
+    """A conv behind a 2x upsampling: the kernel sums a 4 x 4 window of dz per STORED pixel with tap sums as weights
+    (default) or computes the upsampled image's gradient and adds 2 x 2 windows (SPECTRUM_DGRAD_PHASE=0).  The same
+    mathematics in a different association: agreement to rounding, and the switch does select two bodies."""
+    from spectrum_vae_amd import ops
+    monkeypatch.delenv("SPECTRUM_DGRAD_NHWC", raising=False)
+    h, w_, cin, cout, up, pooled, act = spec
+    rng = np.random.default_rng(n + cout)
+    g = ops.conv_geom(n, h * up, w_ * up, cin, 3, 3, 1, 1, "same", cout, (up, up))
+    wt = torch.from_numpy(rng.standard_normal((3, 3, cin, cout)).astype(np.float32)).cuda()
+    y = torch.from_numpy(np.tanh(rng.standard_normal((n, h * up, w_ * up, cout))).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((n, h * up, w_ * up, cout)).astype(np.float32)).cuda()
+    got = {}
+    for phase in ("1", "0"):
+        monkeypatch.setenv("SPECTRUM_DGRAD_PHASE", phase)
+        dx = torch.full((n, h, w_, cin), 7.0, device="cuda")
+        ops.conv2d_bwd(g, None, wt, dy, y, None, dx, None, None, act, 1.0, None)
+        got[phase] = dx
+    assert float((got["1"] - got["0"]).abs().max()) <= 4e-6 * float(got["0"].abs().max())
+    assert not torch.equal(got["1"], got["0"])
