@@ -159,10 +159,15 @@ def kernel_of_call(name: str, g):
     if name == "sv_conv2d_bwd" and g.get("half") == "dgrad":
         if k == 3 and (g["Cout"], g["Cin"], g["W"]) in ((3, 8, 32), (8, 16, 16), (16, 32, 8), (32, 16, 8), (16, 8, 16)) \
                 and os.environ.get("SPECTRUM_DGRAD_NHWC", "1")[0] != "0":
-            # last template argument: the stored-pixel form of a conv behind an upsampling (where the kernel has it)
-            ph = g["up_h"] == 2 and (g["Cout"], g["Cin"], g["W"]) in ((3, 8, 32), (8, 16, 16)) \
-                and os.environ.get("SPECTRUM_DGRAD_PHASE", "1")[0] != "0"
-            return f"dgrad_nhwc<{g['Cout']}, {g['Cin']}, {g['W']}, {'true' if ph else 'false'}>", fl
+            # last template argument: 1 = the stored-pixel form of a conv behind an upsampling, 2 = pixel pairs as result
+            # columns for an 8-channel result (where the kernel has them), 0 = the direct form
+            shape = (g["Cout"], g["Cin"], g["W"])
+            mode = 0
+            if g["up_h"] == 2 and shape in ((3, 8, 32), (8, 16, 16)) and os.environ.get("SPECTRUM_DGRAD_PHASE", "1")[0] != "0":
+                mode = 1
+            elif g["up_h"] == 1 and shape == (16, 8, 16) and os.environ.get("SPECTRUM_DGRAD_PAIR", "1")[0] != "0":
+                mode = 2
+            return f"dgrad_nhwc<{shape[0]}, {shape[1]}, {shape[2]}, {mode}>", fl
         epi = 2 if g["up_h"] == 2 else 0
         return f"conv_s1_lds<{k}, 1, {8 if g['Cin'] > 4 else 4}, {epi}>", fl
     if name == "sv_conv2d_pool_fwd":

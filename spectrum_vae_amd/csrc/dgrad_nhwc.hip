@@ -46,14 +46,20 @@ __device__ __forceinline__ float dn_dpp_ror8(float v) {  // value of lane ^ 8 (r
 // one of the four (window row t reads kernel rows {2 - t, 3 - t} within 0..2, columns alike), so
 //   dx[r, c][ci] = sum over the 4 x 4 window and co of dz[2r - 1 + ta, 2c - 1 + tb][co] * wsum[ta][tb][ci][co]:
 // 16 window taps per stored pixel instead of 4 x 9 per stored pixel, and no 2 x 2 sums afterwards.
-template <int CZ, int CX, int WO, bool PH>
+// MODE 2 (8 input channels, where the filters fill only half of a 16-row A operand): rows 8..15 hold the same filters
+// shifted by one column, so a result column is a PAIR of horizontally adjacent pixels (even column in rows 0..7, odd
+// column in rows 8..15) reading a 3 x 4 window of dz between them: 12 window taps per pixel pair instead of 2 x 9.
+template <int CZ, int CX, int WO, int MODE>
 __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
+    constexpr bool PH = MODE == 1, WD = MODE == 2;
+    static_assert(!WD || CX == 8, "the pair form fills the rows an 8-channel filter leaves empty");
     constexpr int MT = (CX + 15) / 16;
     constexpr int VEC = CZ == 3 ? 1 : (CZ == 8 ? 2 : 4);          // dz channels per lane and read
     constexpr int NH = CZ == 3 ? 1 : CZ / (4 * VEC);              // reads per tap
-    constexpr int TW = PH ? 4 : 3, TAPS = TW * TW;                // window of dz pixels a result pixel reads
+    constexpr int TW = (PH || WD) ? 4 : 3, TAPS = (PH ? 4 : 3) * TW;  // window of dz pixels a result column reads
     constexpr int NSTEP = CZ == 3 ? (3 * TAPS + 3) / 4 : TAPS * NH;  // reads per pixel tile
-    constexpr int SW = WO + 2, TX = PH ? WO / 16 : WO / 8;
+    constexpr int SW = WO + 2, TX = (PH || WD) ? WO / 16 : WO / 8;
+    static_assert(!WD || CZ != 3, "pair form: channel counts that are multiples of 4");
     constexpr bool PING = NSTEP * VEC <= 36;                      // operand registers of two tiles fit
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -127,7 +133,12 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     int zoff[CZ == 3 ? NSTEP : 1];  // 3 channels: reduction index kk = 4 s + lk walks (a, b, co) flattened
     // the filter value that connects window position (ta, tb) of dz with input channel ci: one mirrored tap, or (PH) the
     // sum of the taps named above
-    auto wtap = [&](int ta, int tb, int ci, int co) {
+    auto wtap = [&](int ta, int tb, int row, int co) {
+        if (WD) {  // row = (pixel of the pair, channel): the odd pixel's window starts one column to the right
+            const int e = row >> 3, ci = row & 7, t = tb - e;
+            return (t >= 0 && t <= 2) ? a.w[(((2 - ta) * 3 + (2 - t)) * CX + ci) * CZ + co] : 0.f;
+        }
+        const int ci = row;
         if (!PH) return a.w[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co];
         float t = 0.f;
 #pragma unroll
@@ -163,12 +174,12 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
                 for (int mt = 0; mt < MT; ++mt) {
                     const int ci = mt * 16 + li;
                     const int co = h * 4 * VEC + VEC * lk + j;
-                    wreg[s][j][mt] = ci < CX ? wtap(ta, tb, ci, co) : 0.f;
+                    wreg[s][j][mt] = ci < (WD ? 16 : CX) ? wtap(ta, tb, ci, co) : 0.f;
                 }
         }
     }
     // the lane's pixel (and channel group) inside a tile; PH: the window of stored pixel (pr, pc) starts at (2 pr, 2 pc)
-    const int lz = (PH ? 2 : 1) * (pr * SW + pc) * CZ + (CZ == 3 ? 0 : VEC * lk);
+    const int lz = (PH ? 2 * (pr * SW + pc) : (WD ? pr * SW + 2 * pc : pr * SW + pc)) * CZ + (CZ == 3 ? 0 : VEC * lk);
 
     int n0 = blockIdx.x * a.ns;
     if (n0 < a.N) load_pass(n0);
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
             ss = t >> tps_log;
             const int q = t & tps_mask;
             oh = (q / TX) * 2;
-            ow0 = (q % TX) * 8;
+            ow0 = (q % TX) * (WD ? 16 : 8);
         };
         auto load_tile = [&](float (&zv)[NSTEP][VEC], int i) {
             int ss, oh, ow0;
@@ -229,7 +240,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
             tile_pos(i, ss, oh, ow0);
             if (!live) return;  // the second tile of the last pair when a wave's tile count is odd
             // lane (li, lk) holds input channels mt * 16 + 4 lk .. + 3 of pixel (oh + pr, ow0 + pc)
-            if (PH) {
+            if (WD) {  // rows 4 lk .. 4 lk + 3 = channels 4 (lk & 1) .. + 3 of the pair's pixel lk >> 1
+                float* o = a.dx + (((size_t)(n0 + ss) * H + oh + pr) * WO + ow0 + 2 * pc + (lk >> 1)) * CX + 4 * (lk & 1);
+                *reinterpret_cast<float4*>(o) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+            } else if (PH) {
                 float* o = a.dx + (((size_t)(n0 + ss) * (H >> 1) + oh + pr) * (WO >> 1) + ow0 + pc) * CX;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -286,14 +300,20 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------- host side
 template <int CZ, int CX, int WO>
-static int dn_launch(const DnArgs& a, int grid, size_t lds, hipStream_t st, bool ph) {
-    if constexpr (WO >= 16) {  // a tile is 2 x 8 stored pixels: the stored image must be 8 wide
-        if (ph) {
-            hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
+static int dn_launch(const DnArgs& a, int grid, size_t lds, hipStream_t st, int mode) {
+    if constexpr (WO >= 16) {  // a tile is 2 x 8 stored pixels (mode 1) / 2 x 8 pixel pairs (mode 2): 16 columns at least
+        if (mode == 1) {
+            hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO, 1>), dim3((unsigned)grid), dim3(256), lds, st, a);
             return check_launch("dgrad_nhwc");
         }
+        if constexpr (CX == 8 && CZ != 3) {
+            if (mode == 2) {
+                hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO, 2>), dim3((unsigned)grid), dim3(256), lds, st, a);
+                return check_launch("dgrad_nhwc");
+            }
+        }
     }
-    hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((dgrad_nhwc<CZ, CX, WO, 0>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return check_launch("dgrad_nhwc");
 }
 
@@ -322,6 +342,15 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
         if (e[0] == '0') ph = false;
     int tps = ph ? (H / 4) * (W / 16) : (H / 2) * (W / 8);
     if (ph && (tps < 4 || (tps & (tps - 1)))) { ph = false; tps = (H / 2) * (W / 8); }
+    // 8 input channels without upsampling: pixel pairs as result columns (MODE 2 in the kernel)
+    bool wd = !ph && g.up_h == 1 && shape == 4 && (W % 16) == 0;
+    if (const char* e = std::getenv("SPECTRUM_DGRAD_PAIR"))
+        if (e[0] == '0') wd = false;
+    if (wd) {
+        const int t2 = (H / 2) * (W / 16);
+        if (t2 >= 4 && !(t2 & (t2 - 1))) tps = t2;
+        else wd = false;
+    }
     if (tps < 4 || (tps & (tps - 1))) return 1;
     const int64_t sampleZ = (int64_t)(H + 2) * (W + 2) * CZ;
     const int64_t units = (zmode == 2 ? (int64_t)(H / 2) * (W / 2) * CZ : (int64_t)H * W * CZ) / 4;
@@ -343,11 +372,11 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     a.zk = act_grad_coef(act, alpha);
     const size_t bytes = lds(ns);
     switch (shape) {
-        case 0: return dn_launch<3, 8, 32>(a, grid, bytes, st, ph);
-        case 1: return dn_launch<8, 16, 16>(a, grid, bytes, st, ph);
-        case 2: return dn_launch<16, 32, 8>(a, grid, bytes, st, false);
-        case 3: return dn_launch<32, 16, 8>(a, grid, bytes, st, false);
-        default: return dn_launch<16, 8, 16>(a, grid, bytes, st, false);
+        case 0: return dn_launch<3, 8, 32>(a, grid, bytes, st, ph ? 1 : 0);
+        case 1: return dn_launch<8, 16, 16>(a, grid, bytes, st, ph ? 1 : 0);
+        case 2: return dn_launch<16, 32, 8>(a, grid, bytes, st, 0);
+        case 3: return dn_launch<32, 16, 8>(a, grid, bytes, st, 0);
+        default: return dn_launch<16, 8, 16>(a, grid, bytes, st, wd ? 2 : 0);
     }
 }
 

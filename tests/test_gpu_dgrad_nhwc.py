@@ -90,3 +90,26 @@ def test_stored_pixel_form_of_upsampled_layers_agrees_with_the_direct_form(spec,
         got[phase] = dx
     assert float((got["1"] - got["0"]).abs().max()) <= 4e-6 * float(got["0"].abs().max())
     assert not torch.equal(got["1"], got["0"])
+
+
+@pytest.mark.parametrize("n", [1, 5, 130, 1027])
+def test_pixel_pair_form_of_the_8_channel_layer_equals_the_direct_form(n, monkeypatch):
+    """16 -> 8 channels back through a pooled 16 x 16 layer: rows 8..15 of the filter operand hold the filters shifted by
+    one column, a result column is a pair of adjacent pixels (default), or every pixel is its own column
+    (SPECTRUM_DGRAD_PAIR=0).  The extra products have zero weights: the sums are the same, bit for bit."""
+    from spectrum_vae_amd import ops
+    monkeypatch.delenv("SPECTRUM_DGRAD_NHWC", raising=False)
+    h, w_, cin, cout, up, pooled, act = LAYERS[0]
+    rng = np.random.default_rng(n + 17)
+    g = ops.conv_geom(n, h, w_, cin, 3, 3, 1, 1, "same", cout, (1, 1))
+    wt = torch.from_numpy(rng.standard_normal((3, 3, cin, cout)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.standard_normal((n, h // 2, w_ // 2, cout)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((n, h // 2, w_ // 2, cout)).astype(np.float32)).cuda()
+    idx = torch.from_numpy(rng.integers(0, 4, (n, h // 2, w_ // 2, cout)).astype(np.uint8)).cuda()
+    got = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("SPECTRUM_DGRAD_PAIR", pair)
+        dx = torch.full((n, h, w_, cin), 7.0, device="cuda")
+        ops.conv2d_bwd(g, None, wt, dy, y, idx, dx, None, None, act, 1.0, None)
+        got[pair] = dx
+    assert torch.equal(got["1"], got["0"])
