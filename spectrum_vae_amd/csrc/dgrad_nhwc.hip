@@ -140,12 +140,18 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
         }
         const int ci = row;
         if (!PH) return a.w[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co];
+        // kernel rows {2 - ta, 3 - ta} and columns {2 - tb, 3 - tb} inside 0..2: four loads at clamped indices, the ones
+        // outside weighted 0 (a loop over the nine taps with a condition each costs nine predicated loads per value)
         float t = 0.f;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-                if ((kh == 2 - ta || kh == 3 - ta) && (kw == 2 - tb || kw == 3 - tb)) t += a.w[((kh * 3 + kw) * CX + ci) * CZ + co];
+            for (int j = 0; j < 2; ++j) {
+                const int kh = 2 - ta + i, kw = 2 - tb + j;
+                const bool in = kh >= 0 && kh <= 2 && kw >= 0 && kw <= 2;
+                const float v = a.w[((min(max(kh, 0), 2) * 3 + min(max(kw, 0), 2)) * CX + ci) * CZ + co];
+                t += in ? v : 0.f;
+            }
         return t;
     };
     if (CZ == 3) {
