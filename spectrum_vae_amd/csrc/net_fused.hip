@@ -945,7 +945,7 @@ constexpr size_t net_layout(NetFwdArgs& a, const sv_net_layer* layers, int n_lay
         if (l == n_layers) break;
         const sv_net_layer& s = layers[l];
         NetLayer& L = a.L[l];
-        L.Cin = s.Cin; L.Cout = s.Cout; L.Hs = h; L.Ws = w; L.up = s.up; L.pool = s.pool;
+        L.Cin = s.Cin; L.Cout = s.Cout; L.Hs = h; L.Ws = w; L.up = s.up; L.pool = s.pool; L.act = s.act; L.alpha = s.alpha;
         L.in_plane = plane; L.in_wp = wp; L.in_halo = halo;
         L.co_t = s.Cout > 4 ? 8 : 4;
         L.n_cot = (s.Cout + L.co_t - 1) / L.co_t;
@@ -1006,7 +1006,7 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
     for (int l = 0; l < n_layers; ++l) {
         const sv_net_layer& s = layers[l];
         NetLayer& L = a.L[l];
-        L.act = s.act; L.alpha = s.alpha; L.w_off = (int)s.w_off; L.b_off = (int)s.b_off;
+        L.w_off = (int)s.w_off; L.b_off = (int)s.b_off;
         L.y = (float*)s.y; L.idx = s.idx;
     }
     return 0;
@@ -1014,14 +1014,14 @@ static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int
 
 // ---- the forward launch built for ONE layer table: the conv stack of CAEPadded at the run_model.py defaults
 // (autoencoder.py:437-526 with global_vars / run_model.py:80-104: 3 -> 8 -> 16 -> 32 pooled, 32 -> 16 -> 8 -> 3
-// upsampled, 32 x 32 inputs), two samples per workgroup of 256 threads.  Only pointers, parameter offsets, activations
+// upsampled, 32 x 32 inputs, ELU / tanh), two samples per workgroup of 256 threads.  Only pointers, parameter offsets
 // and the batch size are launch arguments; a launch takes this kernel when the table net_fill computes for it equals
 // the compile-time one field by field, and the run-time-table kernel otherwise.
 constexpr int kCaeLayers = 6;
-constexpr sv_net_layer kCaeChain[kCaeLayers] = {
-    {3, 8, 3, 1, 1, 0, 0.f, 0, 0, 0, nullptr, nullptr},   {8, 16, 3, 1, 1, 0, 0.f, 0, 0, 0, nullptr, nullptr},
-    {16, 32, 3, 1, 1, 0, 0.f, 0, 0, 0, nullptr, nullptr}, {32, 16, 3, 2, 0, 0, 0.f, 0, 0, 0, nullptr, nullptr},
-    {16, 8, 3, 2, 0, 0, 0.f, 0, 0, 0, nullptr, nullptr},  {8, 3, 3, 2, 0, 0, 0.f, 0, 0, 0, nullptr, nullptr}};
+constexpr sv_net_layer kCaeChain[kCaeLayers] = {  // ELU (alpha 1) inside, tanh on the output: the activations are constants too
+    {3, 8, 3, 1, 1, SV_ACT_ELU, 1.f, 0, 0, 0, nullptr, nullptr},   {8, 16, 3, 1, 1, SV_ACT_ELU, 1.f, 0, 0, 0, nullptr, nullptr},
+    {16, 32, 3, 1, 1, SV_ACT_ELU, 1.f, 0, 0, 0, nullptr, nullptr}, {32, 16, 3, 2, 0, SV_ACT_ELU, 1.f, 0, 0, 0, nullptr, nullptr},
+    {16, 8, 3, 2, 0, SV_ACT_ELU, 1.f, 0, 0, 0, nullptr, nullptr},  {8, 3, 3, 2, 0, SV_ACT_TANH, 1.f, 0, 0, 0, nullptr, nullptr}};
 struct NetCaeTable {
     NetFwdArgs a;
     size_t lds_floats;
@@ -1035,8 +1035,6 @@ constexpr NetCaeTable kCae = net_cae_table();
 static_assert(kCae.lds_floats * sizeof(float) <= 78 * 1024, "two workgroups per CU");
 
 struct NetCaeLayerArgs {
-    int act;
-    float alpha;
     int w_off, b_off;
     float* y;
     uint8_t* idx;
@@ -1059,13 +1057,13 @@ __global__ __launch_bounds__(256, 2) void net_fwd_cae(NetCaeArgs r) {
     a.loss_t = r.loss_t; a.loss_dpred = r.loss_dpred; a.loss_partials = r.loss_partials; a.loss_gscale = r.loss_gscale;
     net_fwd_run<3, kCaeLayers>(a, [&](int l) __attribute__((always_inline)) {
         NetLayer L = kCae.a.L[l];
-        L.act = r.rt[l].act; L.alpha = r.rt[l].alpha; L.w_off = r.rt[l].w_off; L.b_off = r.rt[l].b_off;
+        L.w_off = r.rt[l].w_off; L.b_off = r.rt[l].b_off;
         L.y = r.rt[l].y; L.idx = r.rt[l].idx;
         return L;
     }, smem);
 }
 
-// true when the plan's table is the compile-time one (pointers, offsets and activations aside)
+// true when the plan's table is the compile-time one (pointers and parameter offsets aside)
 static bool net_plan_is_cae(const NetFwdArgs& p, int nt) {
     if (std::getenv("SPECTRUM_NETFWD_GENERIC") != nullptr || nt != 256 || p.n_layers != kCaeLayers || p.S != kCae.a.S || p.w_off != kCae.a.w_off) return false;
     for (int l = 0; l < kCaeLayers; ++l) {
@@ -1074,7 +1072,7 @@ static bool net_plan_is_cae(const NetFwdArgs& p, int nt) {
             x.in_off != y.in_off || x.out_off != y.out_off || x.idx_off != y.idx_off || x.in_plane != y.in_plane ||
             x.in_wp != y.in_wp || x.in_halo != y.in_halo || x.out_plane != y.out_plane || x.out_wp != y.out_wp ||
             x.out_halo != y.out_halo || x.co_t != y.co_t || x.n_cot != y.n_cot || x.ks != y.ks || x.pair != y.pair ||
-            x.mfma != y.mfma)
+            x.mfma != y.mfma || x.act != y.act)  // ELU and tanh take no parameter
             return false;
     }
     return true;
@@ -1795,7 +1793,7 @@ static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_la
         r.loss_gscale = p.args.loss_gscale;
         for (int l = 0; l < kCaeLayers; ++l) {
             const NetLayer& L = p.args.L[l];
-            r.rt[l] = NetCaeLayerArgs{L.act, L.alpha, L.w_off, L.b_off, L.y, L.idx};
+            r.rt[l] = NetCaeLayerArgs{L.w_off, L.b_off, L.y, L.idx};
         }
         const int passes = (N + p.S - 1) / p.S;
         if (y_true != nullptr) *n_partials = passes;
