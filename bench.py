@@ -98,7 +98,7 @@ class OpTimer:
                 info = {f: getattr(g, f) for f, _ in g._fields_}
                 if name == "sv_conv2d_bwd":  # which half ran: dx = args[6], dw = args[7]
                     info["half"] = "dgrad" if not args[7] else ("wgrad" if not args[6] else "both")
-            elif name == "sv_conv2d_wgrad_batch":
+            elif name in ("sv_conv2d_wgrad_batch", "sv_conv2d_wgrad_batch_slabs"):
                 arr, nj = args[0], args[1]
                 fl = 0
                 for i in range(nj):
@@ -106,7 +106,8 @@ class OpTimer:
                     fl += 2 * q.N * q.Ho * q.Wo * q.Cout * q.KH * q.KW * q.Cin
                 shapes = sorted((arr[i].g.Cin, arr[i].g.Cout, arr[i].g.W) for i in range(nj))
                 nhwc = all(sh in ((3, 8, 32), (8, 16, 16), (16, 32, 8), (32, 16, 8), (16, 8, 16), (8, 3, 32)) for sh in shapes)
-                info = {"jobs": nj, "flops": fl, "single_launch": not args[2], "nhwc": nhwc}
+                slabs = name.endswith("_slabs")  # one launch: the slabs stay for the optimizer launch to sum
+                info = {"jobs": nj, "flops": fl, "single_launch": slabs or not args[2], "nhwc": nhwc, "slabs": slabs}
             elif name in ("sv_convnet_fwd", "sv_convnet_fwd_mse"):
                 arr, nl, n, h, w = args[0], args[1], args[2], args[3], args[4]
                 fl = 0
@@ -133,23 +134,25 @@ class OpTimer:
 DEFAULT_CHAIN = [(3, 8, 1, 1), (8, 16, 1, 1), (16, 32, 1, 1), (32, 16, 2, 0), (16, 8, 2, 0), (8, 3, 2, 0)]
 
 
+def _opt(name: str) -> int:
+    from spectrum_vae_amd import ops
+    return ops.get_option(name)
+
+
 def kernel_of_call(name: str, g):
     """(rocprof kernel name, algorithmic FLOPs) of a C-ABI call that is exactly ONE kernel launch, else None."""
     if g is None:
         return None
     if name in ("sv_convnet_fwd", "sv_convnet_fwd_mse"):
         # the layer table of the run_model.py defaults has a kernel built for it; other tables take the run-time-table one
-        known = g.get("default_chain") and "SPECTRUM_NETFWD_GENERIC" not in os.environ
+        known = g.get("default_chain") and _opt("netfwd_generic") != 1
         return ("net_fwd_cae" if known else "net_fwd_s1<3>"), float(g["flops"])
+    if name == "sv_conv2d_wgrad_batch_slabs":
+        return "wgrad_nhwc_multi", float(g["flops"])  # exactly that launch; the optimizer launch sums its slabs
     if name == "sv_conv2d_wgrad_batch":
         if g["single_launch"]:
             return "wgrad_s1_multi<3>", float(g["flops"])
-        # with its own reduction the call is two launches, wgrad_nhwc_multi and the few-microsecond wn_reduce_multi: the
-        # call's time ranks it among the kernels, and the back-to-back measurement below switches the second launch off
-        # (SPECTRUM_WGRAD_DBG=8) so that the figure is the first kernel's alone
-        if g.get("nhwc") and os.environ.get("SPECTRUM_WGRAD_NHWC", "1")[0] != "0":
-            return "wgrad_nhwc_multi", float(g["flops"])
-        return None
+        return None  # two launches (partial sums, then their sum): no single kernel to hold the call's time against
     if "KH" not in g:
         return None
     fl = 2.0 * g["N"] * g["Ho"] * g["Wo"] * g["Cout"] * g["KH"] * g["KW"] * g["Cin"]
@@ -158,14 +161,14 @@ def kernel_of_call(name: str, g):
         return f"wgrad_s1_lds<{k}, {8 if (k == 3 and g['Cout'] > 4) else 4}>", fl
     if name == "sv_conv2d_bwd" and g.get("half") == "dgrad":
         if k == 3 and (g["Cout"], g["Cin"], g["W"]) in ((3, 8, 32), (8, 16, 16), (16, 32, 8), (32, 16, 8), (16, 8, 16)) \
-                and os.environ.get("SPECTRUM_DGRAD_NHWC", "1")[0] != "0":
+                and _opt("dgrad_nhwc") != 0:
             # last template argument: 1 = the stored-pixel form of a conv behind an upsampling, 2 = pixel pairs as result
             # columns for an 8-channel result (where the kernel has them), 0 = the direct form
             shape = (g["Cout"], g["Cin"], g["W"])
             mode = 0
-            if g["up_h"] == 2 and shape in ((3, 8, 32), (8, 16, 16)) and os.environ.get("SPECTRUM_DGRAD_PHASE", "1")[0] != "0":
+            if g["up_h"] == 2 and shape in ((3, 8, 32), (8, 16, 16)) and _opt("dgrad_phase") != 0:
                 mode = 1
-            elif g["up_h"] == 1 and shape == (16, 8, 16) and os.environ.get("SPECTRUM_DGRAD_PAIR", "1")[0] != "0":
+            elif g["up_h"] == 1 and shape == (16, 8, 16) and _opt("dgrad_pair") != 0:
                 mode = 2
             return f"dgrad_nhwc<{shape[0]}, {shape[1]}, {shape[2]}, {mode}>", fl
         epi = 2 if g["up_h"] == 2 else 0
@@ -330,9 +333,6 @@ def main():
             again = [(fn, a) for (n_, info, fn, a) in ot.calls
                      if (kernel_of_call(n_, info) or (None,))[0] == kname]
             reps_k = 20
-            only_first_launch = kname == "wgrad_nhwc_multi"
-            if only_first_launch:
-                os.environ["SPECTRUM_WGRAD_DBG"] = "8"
             for fn, a in again:
                 fn(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -342,8 +342,6 @@ def main():
                     fn(*a)
             e1.record()
             torch.cuda.synchronize()
-            if only_first_launch:
-                del os.environ["SPECTRUM_WGRAD_DBG"]
             avg_us = e0.elapsed_time(e1) * 1e3 / (reps_k * max(len(again), 1)) if again else avg_us_in_step
             ach = fl / (avg_us * 1e-6) / 1e12
             traffic = None
@@ -359,9 +357,7 @@ def main():
                         "note": "f32 vector FMA peak == f32 MFMA peak on MI355X; avg_launch_us: this kernel's calls of "
                                 "one step issued 20 times back to back between two HIP events on the launch stream; "
                                 "avg_call_us_in_eager_step: event-to-event time of the same calls inside an eager step "
-                                "(includes the host launch path)"
-                                + ("; the call's second launch (wn_reduce_multi, the sum of the slabs) is switched off in the "
-                                   "back-to-back measurement and included in the eager call's time" if only_first_launch else "")}
+                                "(includes the host launch path)"}
             roofline["kernels_ranked_by_eager_call_us"] = {k: round(v["us_per_step"], 1) for k, v in
                                                            sorted(groups.items(), key=lambda kv: -kv[1]["us_per_step"])[:4]}
             # calls that are more than one launch cannot be put against a single kernel's row; when such a call is longer
@@ -372,7 +368,7 @@ def main():
                 roofline["longer_multi_launch_call"] = {
                     "call": m["call"], "avg_call_us_in_eager_step": round(m["avg_us"], 2),
                     "frac_of_peak_over_the_call": round(m["geom"]["flops"] / (m["avg_us"] * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
-                    "note": "sv_conv2d_wgrad_batch = wgrad_nhwc_multi + wn_reduce_multi (see profiles/*_kernel_stats.csv)"}
+                    "note": "a call of two or more launches (see profiles/*_kernel_stats.csv)"}
         else:
             top = table[0]
             roofline = {"bound": "hbm", "kernel": top["call"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

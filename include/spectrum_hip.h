@@ -54,6 +54,16 @@ typedef struct sv_conv_geom {
 const char* sv_last_error(void);
 int sv_version(void);
 
+/* ---- Plan-time options.  No counterpart in the reference (TensorFlow picks its kernels by itself).  Where the library
+ *      holds several bodies or launch shapes for the same arithmetic, an option selects one; none changes what an entry
+ *      point computes.  They exist for the tests (one body held against another) and for measurements; -1, the initial
+ *      value of every option, leaves the choice to the planner.  Process-wide; the library never reads the environment on
+ *      a launch path.  Names: dgrad_nhwc, dgrad_phase, dgrad_pair, wgrad_nhwc, netfwd_pair, netfwd_phase, small_convt,
+ *      s1_mfma (0 = the other body); dgrad_valu, wgrad_valu, netfwd_valu, netfwd_generic (1 = the other body);
+ *      dgrad_grid, netfwd_s, netfwd_grid (> 0: workgroups / samples per workgroup).  Unknown names: SV_E_INVALID. */
+int sv_set_option(const char* name, int value);
+int sv_get_option(const char* name, int* value);
+
 /* ---- Conv2D (autoencoder.py:443,510,521; unet.py:40; context_encoder.py:57,72,172,185,230,242,334,346) */
 /* y = act(conv(x, w) + bias); bias may be NULL. */
 int sv_conv2d_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,
@@ -72,7 +82,11 @@ int sv_conv2d_wgrad(const sv_conv_geom* g, const void* x, const void* dz, void* 
  *      ends; sv_static_scratch_bytes() returns its size); the call uses the CURRENT device's copy.  Geometries whose
  *      sv_conv2d_wgrad_workspace_bytes exceeds that size are refused with SV_E_WORKSPACE.  Results are bit-identical to
  *      sv_conv2d_wgrad.  All calls on one GPU share the array: calls that overlap in time on one GPU (different
- *      streams, different threads) race - serialise them. */
+ *      streams, different threads) race - serialise them.  The first use on a GPU looks the array's address up, which
+ *      must not happen under stream capture: sv_static_scratch_bytes() also performs that lookup for the current
+ *      device, so call it once per GPU before recording (a first use inside a capture is refused with SV_E_INVALID).
+ *      Inside a sv_deferred_reduce_begin / _flush bracket the sum of this call's partial sums is NOT deferred (the
+ *      shared array would be overwritten before the flush): it launches at once. */
 size_t sv_static_scratch_bytes(void);
 int sv_conv2d_wgrad_static(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate, int dtype,
                            sv_stream_t stream);
@@ -175,6 +189,23 @@ typedef struct sv_wgrad_batch_job {
                              sizes the workspace. */
 } sv_wgrad_batch_job;
 int sv_conv2d_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, int dtype, sv_stream_t stream);
+
+/* ---- The same launch for a training step whose optimizer reads its gradients as sums of partial sums
+ *      (`optimizer.apply_gradients` right behind the tape, run_model.py:281-289): the per-workgroup slabs stay in the
+ *      jobs' workspaces and slabs_out[j] describes job j's (n_split rows of slab_floats floats; a row holds the kernel
+ *      gradient in HWIO order, n_dw floats, then the bias gradient, n_db floats).  dw / db are not touched;
+ *      sv_adam_keras_step_slabs consumes the descriptions on the same stream.  Only the few-channel 3x3 family has this
+ *      form: sv_conv2d_wgrad_batch_slabs_supported tells (1) whether ALL jobs are in it; otherwise the call fails with
+ *      SV_E_UNSUPPORTED and nothing is launched.  At most 8 jobs. */
+typedef struct sv_grad_slabs {
+    const void* slabs;
+    void* dw;             /* where the sums belong: the job's dw ... */
+    void* db;             /* ... and db (NULL: the layer has no bias; the bias columns of the slabs are ignored) */
+    int32_t slab_floats, n_split, n_dw, n_db;
+} sv_grad_slabs;
+int sv_conv2d_wgrad_batch_slabs_supported(const sv_wgrad_batch_job* jobs, int n_jobs);
+int sv_conv2d_wgrad_batch_slabs(const sv_wgrad_batch_job* jobs, int n_jobs, sv_grad_slabs* slabs_out, int dtype,
+                                sv_stream_t stream);
 
 /* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
 /* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */
@@ -365,6 +396,16 @@ int sv_adam_keras_step(float* theta, float* grad, float* m, float* v, int64_t n,
                        float grad_scale, int zero_grad, void* theta_bf16, const float* fold_partials, int fold_n,
                        float fold_scale, float* fold_out, float* fold_running, float fold_running_weight,
                        sv_stream_t stream);
+/* sv_adam_keras_step whose gradient of element i is grad[i] + the fixed-order sum of the slab rows that
+ * sv_conv2d_wgrad_batch_slabs left for it (dw / db of each description must lie inside grad[0..n); elements no description
+ * covers take grad[i] alone): the "sum the partial sums" launch and the optimizer launch of a training step in one.  The
+ * sums are formed in the order sv_conv2d_wgrad_batch(reduce = 1) forms them, so both routes give the same bits.  At most
+ * 16 descriptions that do not overlap. */
+int sv_adam_keras_step_slabs(float* theta, float* grad, float* m, float* v, int64_t n, int64_t* step_state, float lr0,
+                             float beta1, float beta2, float eps, int decay_steps, float decay_rate, int staircase,
+                             float grad_scale, int zero_grad, void* theta_bf16, const float* fold_partials, int fold_n,
+                             float fold_scale, float* fold_out, float* fold_running, float fold_running_weight,
+                             const sv_grad_slabs* slabs, int n_slabs, sv_stream_t stream);
 /* out[0] = [out[0] +] scale * sum(partials[0..n)) in a fixed order (one workgroup); running as above. */
 int sv_fold_scalar(const float* partials, int n, float scale, float* out, int accumulate, float* running,
                    float running_weight, sv_stream_t stream);

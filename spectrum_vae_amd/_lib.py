@@ -42,6 +42,13 @@ class WgradJob(C.Structure):
                 ("accumulate", C.c_int32), ("blocks", C.c_int32)]
 
 
+class GradSlabs(C.Structure):
+    """Mirror of ``sv_grad_slabs``."""
+
+    _fields_ = [("slabs", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("slab_floats", C.c_int32),
+                ("n_split", C.c_int32), ("n_dw", C.c_int32), ("n_db", C.c_int32)]
+
+
 class WgradBatchJob(C.Structure):
     """Mirror of ``sv_wgrad_batch_job``."""
 
@@ -57,6 +64,8 @@ _g = C.POINTER(ConvGeom)
 SIGNATURES = {
     "sv_last_error": (C.c_char_p, []),
     "sv_version": (_i, []),
+    "sv_set_option": (_i, [C.c_char_p, _i]),
+    "sv_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
     "sv_conv2d_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
     "sv_conv2d_wgrad_workspace_bytes": (_sz, [_g]),
@@ -74,6 +83,8 @@ SIGNATURES = {
     "sv_conv2d_bwd_partial": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p, _sz, _i, _p]),
     "sv_conv2d_wgrad_finish": (_i, [C.POINTER(WgradJob), _i, _i, _p]),
     "sv_conv2d_wgrad_batch": (_i, [C.POINTER(WgradBatchJob), _i, _i, _i, _p]),
+    "sv_conv2d_wgrad_batch_slabs_supported": (_i, [C.POINTER(WgradBatchJob), _i]),
+    "sv_conv2d_wgrad_batch_slabs": (_i, [C.POINTER(WgradBatchJob), _i, C.POINTER(GradSlabs), _i, _p]),
     "sv_conv2d_transpose_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_transpose_dgrad": (_i, [_g, _p, _p, _p, _i, _p]),
     "sv_conv2d_transpose_wgrad": (_i, [_g, _p, _p, _p, _i, _p, _sz, _i, _p]),
@@ -118,6 +129,8 @@ SIGNATURES = {
     "sv_loss_bce": (_i, [_p, _f, _i, _p, _i, _p, _f, _i64, _p, _i, _p]),
     "sv_adam_keras_step": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _f, _i, _f, _i, _p, _p, _i, _f, _p, _p, _f,
                                 _p]),
+    "sv_adam_keras_step_slabs": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _f, _i, _f, _i, _p, _p, _i, _f, _p, _p,
+                                      _f, C.POINTER(GradSlabs), _i, _p]),
     "sv_deferred_reduce_begin": (_i, []),
     "sv_deferred_reduce_flush": (_i, [_i, _p]),
     "sv_fold_scalar": (_i, [_p, _i, _f, _p, _i, _p, _f, _p]),

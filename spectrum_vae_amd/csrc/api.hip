@@ -1,11 +1,30 @@
 // C-ABI entry points for the convolution family and library-wide helpers.
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace sv {
 
 thread_local char g_last_error[512] = "";
+
+// ---- plan-time options: a process-wide table of ints, -1 = the planner's own choice
+static std::atomic<int> g_opt[OPT_COUNT];
+static const char* const kOptNames[OPT_COUNT] = {
+    "dgrad_nhwc", "dgrad_phase", "dgrad_pair", "dgrad_grid", "dgrad_valu", "wgrad_nhwc", "wgrad_valu", "netfwd_generic",
+    "netfwd_pair", "netfwd_phase", "netfwd_valu", "netfwd_s", "netfwd_grid", "small_convt", "s1_mfma"};
+static const bool g_opt_init = [] {
+    for (int i = 0; i < OPT_COUNT; ++i) g_opt[i].store(-1, std::memory_order_relaxed);
+    return true;
+}();
+int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
+static int opt_index(const char* name) {
+    if (name != nullptr)
+        for (int i = 0; i < OPT_COUNT; ++i)
+            if (strcmp(name, kOptNames[i]) == 0) return i;
+    return -1;
+}
 
 // conv_direct.hip
 int validate_geom(const sv_conv_geom* g, const char* who);
@@ -42,6 +61,8 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
                        float zalpha = 0.f, int defer = 0, int with_bias = 0);
 int launch_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, hipStream_t st);
 int launch_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, hipStream_t st);
+bool wgrad_nhwc_batch_ok(const sv_wgrad_batch_job* jobs, int n_jobs);  // wgrad_nhwc.hip
+int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st, sv_grad_slabs* slabs_out);
 int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
                       int act, float alpha, hipStream_t st);
 
@@ -60,6 +81,20 @@ extern "C" {
 const char* sv_last_error(void) { return g_last_error; }
 
 int sv_version(void) { return 1; }
+
+int sv_set_option(const char* name, int value) {
+    const int i = opt_index(name);
+    SV_REQUIRE(i >= 0, "sv_set_option: unknown option '%s'", name ? name : "(null)");
+    g_opt[i].store(value, std::memory_order_relaxed);
+    return SV_OK;
+}
+
+int sv_get_option(const char* name, int* value) {
+    const int i = opt_index(name);
+    SV_REQUIRE(i >= 0 && value != nullptr, "sv_get_option: unknown option '%s' or null result", name ? name : "(null)");
+    *value = opt(i);
+    return SV_OK;
+}
 
 int sv_conv2d_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y, int act,
                   float alpha, int dtype, sv_stream_t stream) {
@@ -276,6 +311,29 @@ int sv_conv2d_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce
         if (rc) return rc;
     }
     return SV_OK;
+}
+
+static bool wgrad_batch_jobs_valid(const sv_wgrad_batch_job* jobs, int n_jobs) {
+    if (jobs == nullptr || n_jobs < 1 || n_jobs > 8) return false;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (validate_geom(&jobs[j].g, "sv_conv2d_wgrad_batch_slabs")) return false;
+        if (!(jobs[j].x && jobs[j].dy && jobs[j].y && jobs[j].dw)) return false;
+        if (jobs[j].blocks < 0 || jobs[j].blocks > 512) return false;
+    }
+    return true;
+}
+
+int sv_conv2d_wgrad_batch_slabs_supported(const sv_wgrad_batch_job* jobs, int n_jobs) {
+    return wgrad_batch_jobs_valid(jobs, n_jobs) && wgrad_nhwc_batch_ok(jobs, n_jobs) ? 1 : 0;
+}
+
+int sv_conv2d_wgrad_batch_slabs(const sv_wgrad_batch_job* jobs, int n_jobs, sv_grad_slabs* slabs_out, int dtype,
+                                sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_wgrad_batch_slabs");
+    SV_REQUIRE(slabs_out != nullptr, "sv_conv2d_wgrad_batch_slabs: null result table");
+    SV_REQUIRE(wgrad_batch_jobs_valid(jobs, n_jobs), "sv_conv2d_wgrad_batch_slabs: bad job list (1..8 jobs, tensors set)");
+    const int rc = launch_wgrad_nhwc_batch(jobs, n_jobs, to_stream(stream), slabs_out);
+    return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_wgrad_batch_slabs: a job is outside the few-channel 3x3 family") : rc;
 }
 
 // Conv2DTranspose forward is the input-gradient kernel of the described conv, plus bias and activation.

@@ -47,6 +47,30 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t to_stream(sv_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Plan-time options (sv_set_option): which of several equivalent kernel bodies or launch shapes a planner picks.  None
+// changes what an entry point computes; tests hold the bodies against each other through them and measurements sweep
+// launch shapes.  -1 (the initial value of every option) leaves the choice to the planner.  The environment is never
+// read on a launch path.
+enum SvOpt {
+    OPT_DGRAD_NHWC,      // 0: input gradients of the 3x3 family through the planar kernels
+    OPT_DGRAD_PHASE,     // 0: upsampled layers in the direct form (result pixels of the upsampled image, 2x2 sums)
+    OPT_DGRAD_PAIR,      // 0: one pixel per result column in the 8-channel layer
+    OPT_DGRAD_GRID,      // > 0: workgroups of an input-gradient launch
+    OPT_DGRAD_VALU,      // 1: planar input-gradient kernels on the vector pipe only
+    OPT_WGRAD_NHWC,      // 0: kernel gradients of the 3x3 family through the planar kernels
+    OPT_WGRAD_VALU,      // 1: planar kernel-gradient kernels on the vector pipe only
+    OPT_NETFWD_GENERIC,  // 1: the run-time-table forward kernel for every layer table
+    OPT_NETFWD_PAIR,     // 0: one sample per thread in the first layer of the fused forward
+    OPT_NETFWD_PHASE,    // 0: upsampled layers of the fused forward in the direct form
+    OPT_NETFWD_VALU,     // 1: every layer of the fused forward on the vector pipe
+    OPT_NETFWD_S,        // > 0: cap on the samples a workgroup of the fused forward carries
+    OPT_NETFWD_GRID,     // > 0: cap on the workgroups of the fused forward
+    OPT_SMALL_CONVT,     // 0: few-channel transposed convs through the implicit GEMM
+    OPT_S1_MFMA,         // 0: stride-1 SAME convs outside the few-channel family through the planar kernels
+    OPT_COUNT
+};
+int opt(int id);  // api.hip
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, never more than the work.
@@ -169,6 +193,10 @@ int launch_convt_small_bf16(const sv_conv_geom& g, const void* x, const void* w,
 // for the flush instead of being launched now.
 bool defer_reduce(const float* src, float* dst, int64_t n, int slabs, int accumulate);
 void deferred_begin();
+// For a call whose slabs live in memory the caller does not own until the flush: the calling thread's bracket is set
+// aside (returns whether one was open) so that the reduction launches at once, then put back.
+bool deferred_suspend();
+void deferred_resume(bool was);
 int deferred_flush(hipStream_t st, bool launch);
 
 }  // namespace sv

@@ -250,6 +250,14 @@ bool defer_reduce(const float* src, float* dst, int64_t n, int slabs, int accumu
     return true;
 }
 
+bool deferred_suspend() {
+    const bool was = t_defer_on;
+    t_defer_on = false;
+    return was;
+}
+
+void deferred_resume(bool was) { t_defer_on = was; }
+
 void deferred_begin() {
     t_deferred.clear();
     t_defer_on = true;

@@ -268,11 +268,7 @@ static int launch_small_any(const sv_conv_geom& g, const T* x, const T* w, const
                             hipStream_t st) {
     if (!convt_small_ok(g, 16 / (int)sizeof(T))) return 1;
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return 1;
-    static const bool off = [] {  // SPECTRUM_SMALL_CONVT=0: the general (implicit GEMM) path, for A/B measurements
-        const char* e = std::getenv("SPECTRUM_SMALL_CONVT");
-        return e != nullptr && e[0] == '0';
-    }();
-    if (off) return 1;
+    if (opt(OPT_SMALL_CONVT) == 0) return 1;  // the general (implicit GEMM) path, for A/B measurements
     if (g.KH == 4 && g.SH == 1) return launch_small_ks<4, 1, T>(g, x, w, bias, y, act, alpha, st);
     if (g.KH == 4) return launch_small_ks<4, 2, T>(g, x, w, bias, y, act, alpha, st);
     return launch_small_ks<2, 2, T>(g, x, w, bias, y, act, alpha, st);

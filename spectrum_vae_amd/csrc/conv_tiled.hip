@@ -656,7 +656,7 @@ int launch_tiled_s1(const float* x, const float* w, const float* bias, float* y,
         a.mfma = 0;
         if (K == 3 && UP == 1 && a.epi_lds && p.grid.y == 1 && p.coc == Cout && (a.Wo == 8 || a.Wo == 16) &&
             (a.Ho * a.Wo) % 32 == 0 && (p.nt & 63) == 0 && (a.bias == nullptr || epi == EPI_STORE) &&
-            (int64_t)p.S * ((a.Ho * a.Wo) >> 5) <= 4 * (p.nt >> 6) && std::getenv("SPECTRUM_DGRAD_VALU") == nullptr) {
+            (int64_t)p.S * ((a.Ho * a.Wo) >> 5) <= 4 * (p.nt >> 6) && opt(OPT_DGRAD_VALU) != 1) {
             if (epi == EPI_SUM4 && Cin == 8 && Cout == 16) a.mfma = 1;
             else if (epi == EPI_SUM4 && Cin == 16 && Cout == 32) a.mfma = 2;
             else if (epi == EPI_STORE && Cin == 32 && Cout == 16) a.mfma = 3;
@@ -1158,7 +1158,7 @@ WgradPlan plan_wgrad(int N, int Hs, int Ws, int Cin, int Cout, int K, int UP, in
     // image is summed in LDS (over the dead staging buffers) before it is written, so the LDS request covers it.
     p.mfma = K == 3 && p.co_t == 8 && ny == 1 && nz == 1 && ((Cin == 16 && Cout == 32) || (Cin == 32 && Cout == 16)) &&
              (p.slab_floats & 3) == 0 && p.slab_floats * sizeof(float) <= kLdsBudget &&
-             std::getenv("SPECTRUM_WGRAD_VALU") == nullptr;
+             opt(OPT_WGRAD_VALU) != 1;
     if (p.mfma) {
         const size_t tiles = (size_t)((9 * Cin + 15) / 16) * (Cout > 16 ? 2 : 1);
         size_t need = 2 * (tiles + 1) * 64 * sizeof(float4);  // two waves' accumulator tiles in flight between the waves
@@ -1300,11 +1300,11 @@ static void fill_wgrad_args(WgradArgs& a, const WgradPlan& p, const float* x, co
 }
 
 // Kernel (+ bias) gradients of up to kMaxWgradJobs layers: one launch for the partial sums, one for the reductions.
-int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st);  // wgrad_nhwc.hip
+int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st, sv_grad_slabs* slabs_out);  // wgrad_nhwc.hip
 
 int launch_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, hipStream_t st) {
     if (reduce) {  // the channel-last matrix-core kernel when every layer of the batch is in its family
-        const int rc = launch_wgrad_nhwc_batch(jobs, n_jobs, st);
+        const int rc = launch_wgrad_nhwc_batch(jobs, n_jobs, st, nullptr);
         if (rc <= 0) return rc;
     }
     WgradMultiArgs m{};

@@ -327,8 +327,7 @@ static int dn_launch(const DnArgs& a, int grid, size_t lds, hipStream_t st, int 
 // caller takes the planar kernels); 0: launched; < 0: error.
 int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
                       int act, float alpha, hipStream_t st) {
-    if (const char* e = std::getenv("SPECTRUM_DGRAD_NHWC"))
-        if (e[0] == '0') return 1;
+    if (opt(OPT_DGRAD_NHWC) == 0) return 1;
     if (g.KH != 3 || g.KW != 3 || g.SH != 1 || g.SW != 1 || g.up_h != g.up_w || (g.up_h != 1 && g.up_h != 2)) return 1;
     if (g.Ho != g.H || g.Wo != g.W || g.pad_t != 1 || g.pad_l != 1) return 1;
     const int H = g.H, W = g.W, CZ = g.Cout, CX = g.Cin;
@@ -344,14 +343,12 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     if ((H & 1) || y == nullptr) return 1;
     // an upsampled conv as a 4 x 4 window over the stored pixels (PH in the kernel) where the stored image holds tiles
     bool ph = g.up_h == 2 && (shape == 0 || shape == 1) && (H % 4) == 0 && (W % 16) == 0;
-    if (const char* e = std::getenv("SPECTRUM_DGRAD_PHASE"))
-        if (e[0] == '0') ph = false;
+    if (opt(OPT_DGRAD_PHASE) == 0) ph = false;
     int tps = ph ? (H / 4) * (W / 16) : (H / 2) * (W / 8);
     if (ph && (tps < 4 || (tps & (tps - 1)))) { ph = false; tps = (H / 2) * (W / 8); }
     // 8 input channels without upsampling: pixel pairs as result columns (MODE 2 in the kernel)
     bool wd = !ph && g.up_h == 1 && shape == 4 && (W % 16) == 0;
-    if (const char* e = std::getenv("SPECTRUM_DGRAD_PAIR"))
-        if (e[0] == '0') wd = false;
+    if (opt(OPT_DGRAD_PAIR) == 0) wd = false;
     if (wd) {
         const int t2 = (H / 2) * (W / 16);
         if (t2 >= 4 && !(t2 & (t2 - 1))) tps = t2;
@@ -366,7 +363,7 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     // dz, one per CU elsewhere, where more workgroups only repeat the filter loads
     int grid = shape == 0 ? 1024 : (shape == 1 ? 512 : 256);
     if (ph) grid = shape == 0 ? 512 : 256;  // a quarter of the tiles per sample: fewer, longer-lived workgroups
-    if (const char* e = std::getenv("SPECTRUM_DGRAD_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+    if (opt(OPT_DGRAD_GRID) > 0) grid = opt(OPT_DGRAD_GRID);
     if (grid > g.N) grid = g.N;
     int ns = 1;
     while (ns < 8 && lds(ns + 1) <= 64 * 1024 && (ns + 1) * units <= 256 * kDnUnits && (int64_t)(ns + 1) * grid * 2 <= g.N) ++ns;

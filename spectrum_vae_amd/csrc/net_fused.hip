@@ -999,9 +999,8 @@ constexpr size_t net_layout(NetFwdArgs& a, const sv_net_layer* layers, int n_lay
 
 static int net_fill(NetFwdArgs& a, const sv_net_layer* layers, int n_layers, int N, int H, int W, int S, int nt,
                     size_t* lds_floats) {
-    // the switches are read at every plan, so a process can compare the variants
-    auto off = [](const char* name) { const char* e = std::getenv(name); return e != nullptr && e[0] == '0'; };
-    const NetLayoutFlags flags{off("SPECTRUM_NETFWD_PAIR"), off("SPECTRUM_NETFWD_PHASE"), std::getenv("SPECTRUM_NETFWD_VALU") != nullptr};
+    // the options are read at every plan, so a process can compare the variants
+    const NetLayoutFlags flags{opt(OPT_NETFWD_PAIR) == 0, opt(OPT_NETFWD_PHASE) == 0, opt(OPT_NETFWD_VALU) == 1};
     *lds_floats = net_layout(a, layers, n_layers, H, W, S, nt, flags);
     for (int l = 0; l < n_layers; ++l) {
         const sv_net_layer& s = layers[l];
@@ -1065,7 +1064,7 @@ __global__ __launch_bounds__(256, 2) void net_fwd_cae(NetCaeArgs r) {
 
 // true when the plan's table is the compile-time one (pointers and parameter offsets aside)
 static bool net_plan_is_cae(const NetFwdArgs& p, int nt) {
-    if (std::getenv("SPECTRUM_NETFWD_GENERIC") != nullptr || nt != 256 || p.n_layers != kCaeLayers || p.S != kCae.a.S || p.w_off != kCae.a.w_off) return false;
+    if (opt(OPT_NETFWD_GENERIC) == 1 || nt != 256 || p.n_layers != kCaeLayers || p.S != kCae.a.S || p.w_off != kCae.a.w_off) return false;
     for (int l = 0; l < kCaeLayers; ++l) {
         const NetLayer &x = p.L[l], &y = kCae.a.L[l];
         if (x.Cin != y.Cin || x.Cout != y.Cout || x.Hs != y.Hs || x.Ws != y.Ws || x.up != y.up || x.pool != y.pool ||
@@ -1104,10 +1103,7 @@ NetPlan plan_net_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int
     NetPlan p{};
     p.ok = false;
     p.nt = 256;
-    static const int s_cap = [] {  // SPECTRUM_NETFWD_S=1|2|4: cap on the samples a workgroup carries (measurements)
-        const char* e = std::getenv("SPECTRUM_NETFWD_S");
-        return e != nullptr ? std::atoi(e) : 4;
-    }();
+    const int s_cap = opt(OPT_NETFWD_S) > 0 ? opt(OPT_NETFWD_S) : 4;  // cap on the samples a workgroup carries
     for (int S = 4; S >= 1; --S) {
         if (S == 3 || S > s_cap) continue;
         size_t fl = 0;
@@ -1124,10 +1120,7 @@ NetPlan plan_net_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int
     }
     if (!p.ok) return p;
     const int passes = (N + p.S - 1) / p.S;
-    static const int g_cap = [] {  // SPECTRUM_NETFWD_GRID: cap on the workgroups of the launch (measurements)
-        const char* e = std::getenv("SPECTRUM_NETFWD_GRID");
-        return e != nullptr ? std::atoi(e) : 512;
-    }();
+    const int g_cap = opt(OPT_NETFWD_GRID) > 0 ? opt(OPT_NETFWD_GRID) : 512;  // cap on the workgroups of the launch
     p.grid = passes < g_cap ? passes : g_cap;
     p.args.N = N; p.args.S = p.S; p.args.n_layers = n_layers;
     return p;

@@ -18,26 +18,34 @@ constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mu;
 static void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, looked up once per GPU
 
-// Device address of this GPU's copy of `scratch` (the current device's), or nullptr with the error text set.
-static void* static_scratch_for_current_device() {
+// Device address of this GPU's copy of `scratch` (the current device's), or nullptr with the error text set.  The first
+// call on a GPU looks the address up, which may load this file's code object and its 16 MiB variable: that must not
+// happen while `st` is being captured into a graph, so there the lookup is refused (the caller resolves the address
+// beforehand through sv_static_scratch_bytes()).
+static int static_scratch_for_current_device(hipStream_t st, bool have_stream, void** out) {
+    *out = nullptr;
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
-        fail(SV_E_LAUNCH, "sv_conv2d_wgrad_static: no usable current device (%s, device %d)", hipGetErrorString(e), dev);
-        return nullptr;
-    }
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
+        return fail(SV_E_LAUNCH, "sv_conv2d_wgrad_static: no usable current device (%s, device %d)", hipGetErrorString(e), dev);
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (g_scratch_ptr[dev] == nullptr) {
+        if (have_stream) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+                return fail(SV_E_INVALID,
+                            "sv_conv2d_wgrad_static: first use on device %d inside a stream capture; call "
+                            "sv_static_scratch_bytes() on this device before capturing", dev);
+        }
         void* p = nullptr;
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // resolves against the current device's code object
-        if (e != hipSuccess || p == nullptr) {
-            fail(SV_E_LAUNCH, "sv_conv2d_wgrad_static: hipGetSymbolAddress failed on device %d: %s", dev,
-                 hipGetErrorString(e));
-            return nullptr;
-        }
+        if (e != hipSuccess || p == nullptr)
+            return fail(SV_E_LAUNCH, "sv_conv2d_wgrad_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                        hipGetErrorString(e));
         g_scratch_ptr[dev] = p;
     }
-    return g_scratch_ptr[dev];
+    *out = g_scratch_ptr[dev];
+    return SV_OK;
 }
 
 }  // namespace sv
@@ -46,7 +54,13 @@ using namespace sv;
 
 extern "C" {
 
-size_t sv_static_scratch_bytes(void) { return kStaticScratchBytes; }
+// Also resolves the array's address on the current device (once per GPU), so that a caller about to record
+// sv_conv2d_wgrad_static into a graph can get the lookup out of the way: call this once per GPU before capturing.
+size_t sv_static_scratch_bytes(void) {
+    void* p = nullptr;
+    (void)static_scratch_for_current_device(nullptr, false, &p);
+    return kStaticScratchBytes;
+}
 
 int sv_conv2d_wgrad_static(const sv_conv_geom* g, const void* x, const void* dz, void* dw, int accumulate, int dtype,
                            sv_stream_t stream) {
@@ -57,11 +71,18 @@ int sv_conv2d_wgrad_static(const sv_conv_geom* g, const void* x, const void* dz,
                     "sv_conv2d_wgrad_static: this geometry needs %zu bytes of partial sums, the built-in scratch holds "
                     "%zu: use sv_conv2d_wgrad with a caller workspace",
                     need, kStaticScratchBytes);
-    void* ptr = static_scratch_for_current_device();
-    if (ptr == nullptr) return SV_E_LAUNCH;
+    void* ptr = nullptr;
+    const int rc0 = static_scratch_for_current_device(to_stream(stream), true, &ptr);
+    if (rc0) return rc0;
     // Nothing in the slabs has to start at zero: every partial sum that the reduction uses is written by this call's
     // producer kernel first (padding slots are read and dropped), so the previous call's contents never show.
-    return sv_conv2d_wgrad(g, x, dz, dw, accumulate, ptr, kStaticScratchBytes, dtype, stream);
+    // Inside a sv_deferred_reduce_begin / _flush bracket the sum of the slabs would be queued with its source in the
+    // shared array, which the next call overwrites before the flush: the bracket is set aside for this call, the sum
+    // launches at once.
+    const bool was = deferred_suspend();
+    const int rc = sv_conv2d_wgrad(g, x, dz, dw, accumulate, ptr, kStaticScratchBytes, dtype, stream);
+    deferred_resume(was);
+    return rc;
 }
 
 }  // extern "C"

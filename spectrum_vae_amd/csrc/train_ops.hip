@@ -76,9 +76,11 @@ __device__ __forceinline__ void fold_scalar_256(const float* __restrict__ partia
                                                 float* __restrict__ out, int accumulate, float* __restrict__ running,
                                                 float running_weight) {
     __shared__ double red[256];
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partials[b];
-    red[threadIdx.x] = s;
+    if (threadIdx.x < 256) {  // a larger block lends its first 256 threads: same order of additions
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partials[b];
+        red[threadIdx.x] = s;
+    }
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -257,6 +259,109 @@ __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ theta, fl
             state[0] = it + 1;
             reinterpret_cast<float*>(state + 1)[0] = alpha_s;
             reinterpret_cast<float*>(state + 1)[1] = lr_s;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// adam_step_k whose gradients arrive as slabs of partial sums (sv_conv2d_wgrad_batch_slabs): a workgroup of 16 x 64
+// threads owns 64 consecutive elements of one description; group g adds rows g, g + 16, ... (8 loads in flight), the
+// groups meet in LDS and group 0 adds them in index order on top of grad[i] - the order wn_reduce_multi uses, so the
+// result has the bits of the two-launch route - and applies the update.  The elements no description covers (alignment
+// gaps of the flat buffer, variables of other layer kinds) are the `rest` workgroups' share.
+constexpr int kAdamSlabJobs = 16;
+struct AdamSlabJob {
+    const float* slab;
+    int64_t w_at, b_at;  // element index of dw / db in the flat buffers (b_at < 0: no bias)
+    int slab_floats, n_dw, n_db, n_split;
+};
+struct AdamSlabArgs {
+    float *theta, *grad, *m, *v;
+    int64_t n;
+    int64_t* state;
+    float lr0, beta1, beta2, eps, decay_rate, grad_scale;
+    int decay_steps, staircase, zero_grad;
+    __bf16* theta_lp;
+    ScalarFold fold;
+    int n_jobs, rest_first, n_gaps;
+    int first[kAdamSlabJobs + 1];
+    int64_t gap_at[2 * kAdamSlabJobs + 1];
+    int64_t gap_first[2 * kAdamSlabJobs + 2];  // prefix sums of the gap lengths
+    AdamSlabJob job[kAdamSlabJobs];
+};
+
+__global__ __launch_bounds__(1024) void adam_slabs_k(AdamSlabArgs a) {
+    __shared__ float red[16][64];
+    __shared__ float alpha_s, lr_s;
+    if (a.fold.partials != nullptr && blockIdx.x == gridDim.x - 1)
+        fold_scalar_256(a.fold.partials, a.fold.n, a.fold.scale, a.fold.out, a.fold.accumulate, a.fold.running,
+                        a.fold.running_weight);
+    const int64_t it = a.state[0];
+    if (threadIdx.x == 0) adam_schedule(it, a.lr0, a.beta1, a.beta2, a.decay_steps, a.decay_rate, a.staircase, alpha_s, lr_s);
+    __syncthreads();
+    const float alpha = alpha_s;
+    auto update = [&](int64_t i, float g) {
+        float th = a.theta[i], mi = a.m[i], vi = a.v[i];
+        adam_update1(th, mi, vi, g, alpha, a.beta1, a.beta2, a.eps, a.grad_scale);
+        a.m[i] = mi;
+        a.v[i] = vi;
+        a.theta[i] = th;
+        if (a.zero_grad) a.grad[i] = 0.f;
+        if (a.theta_lp != nullptr) a.theta_lp[i] = (__bf16)th;
+    };
+    if ((int)blockIdx.x < a.rest_first) {
+        int j = 0;
+        while (j + 1 < a.n_jobs && (int)blockIdx.x >= a.first[j + 1]) ++j;
+        // the job's fields come from the kernel-argument segment at a wave-uniform offset (scalar loads); indexing the
+        // by-value table with j would make the compiler copy all of it to per-lane scratch memory first
+        typedef const __attribute__((address_space(4))) AdamSlabArgs* KArgs;
+        const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        AdamSlabJob q;
+        __builtin_memcpy(&q, &ap->job[j], sizeof(AdamSlabJob));
+        const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+        const int e = ((int)blockIdx.x - a.first[j]) * 64 + lane;
+        const int ne = q.n_dw + q.n_db;
+        float s = 0.f;
+        if (e < ne) {
+            int sp = grp;
+            for (; sp + 7 * 16 < q.n_split; sp += 8 * 16) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = q.slab[(size_t)(sp + u * 16) * q.slab_floats + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t[u];
+            }
+            for (; sp < q.n_split; sp += 16) s += q.slab[(size_t)sp * q.slab_floats + e];
+        }
+        red[grp][lane] = s;
+        __syncthreads();
+        if (grp == 0 && e < ne) {
+            const int64_t i = e < q.n_dw ? q.w_at + e : (q.b_at >= 0 ? q.b_at + (e - q.n_dw) : -1);
+            if (i >= 0) {
+                float t = a.grad[i];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) t += red[g][lane];
+                update(i, t);
+            }
+        }
+    } else {
+        const int64_t total = a.gap_first[a.n_gaps];
+        const int64_t stride = (int64_t)(gridDim.x - a.rest_first) * 1024;
+        for (int64_t p = (int64_t)((int)blockIdx.x - a.rest_first) * 1024 + threadIdx.x; p < total; p += stride) {
+            int k = 0;
+            while (k + 1 < a.n_gaps && p >= a.gap_first[k + 1]) ++k;
+            const int64_t i = a.gap_at[k] + (p - a.gap_first[k]);
+            update(i, a.grad[i]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int* ticket = reinterpret_cast<unsigned int*>(a.state + 2);
+        const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            a.state[0] = it + 1;
+            reinterpret_cast<float*>(a.state + 1)[0] = alpha_s;
+            reinterpret_cast<float*>(a.state + 1)[1] = lr_s;
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -546,6 +651,67 @@ int sv_adam_keras_step(float* theta, float* grad, float* m, float* v, int64_t n,
                        n, step_state, lr0, beta1, beta2, eps, decay_steps, decay_rate, staircase, grad_scale, zero_grad,
                        (__bf16*)theta_bf16, fold);
     return check_launch("sv_adam_keras_step");
+}
+
+int sv_adam_keras_step_slabs(float* theta, float* grad, float* m, float* v, int64_t n, int64_t* step_state, float lr0,
+                             float beta1, float beta2, float eps, int decay_steps, float decay_rate, int staircase,
+                             float grad_scale, int zero_grad, void* theta_bf16, const float* fold_partials, int fold_n,
+                             float fold_scale, float* fold_out, float* fold_running, float fold_running_weight,
+                             const sv_grad_slabs* slabs, int n_slabs, sv_stream_t stream) {
+    SV_REQUIRE(theta && grad && m && v && step_state && n > 0, "sv_adam_keras_step_slabs: bad arguments");
+    SV_REQUIRE(fold_partials == nullptr || (fold_n > 0 && fold_out != nullptr), "sv_adam_keras_step_slabs: bad fold arguments");
+    SV_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "sv_adam_keras_step_slabs: betas out of range");
+    SV_REQUIRE(slabs != nullptr && n_slabs >= 1 && n_slabs <= kAdamSlabJobs, "sv_adam_keras_step_slabs: 1..%d descriptions", kAdamSlabJobs);
+    AdamSlabArgs a{};
+    a.theta = theta; a.grad = grad; a.m = m; a.v = v; a.n = n; a.state = step_state;
+    a.lr0 = lr0; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.decay_rate = decay_rate; a.grad_scale = grad_scale;
+    a.decay_steps = decay_steps; a.staircase = staircase; a.zero_grad = zero_grad; a.theta_lp = (__bf16*)theta_bf16;
+    a.fold = ScalarFold{fold_partials, fold_n, fold_scale, fold_out, 0, fold_running, fold_running_weight};
+    a.n_jobs = n_slabs;
+    // covered ranges of the flat buffer, in ascending order, and the gaps between them
+    struct Range { int64_t at, len; };
+    Range rg[2 * kAdamSlabJobs];
+    int nr = 0, blocks = 0;
+    for (int j = 0; j < n_slabs; ++j) {
+        const sv_grad_slabs& d = slabs[j];
+        SV_REQUIRE(d.slabs && d.dw && d.n_split >= 1 && d.n_dw >= 1 && d.n_db >= 0 && d.slab_floats >= d.n_dw + d.n_db,
+                   "sv_adam_keras_step_slabs: description %d is malformed", j);
+        AdamSlabJob& q = a.job[j];
+        q.slab = (const float*)d.slabs; q.slab_floats = d.slab_floats; q.n_dw = d.n_dw; q.n_db = d.n_db; q.n_split = d.n_split;
+        q.w_at = (const float*)d.dw - grad;
+        q.b_at = d.db != nullptr ? (const float*)d.db - grad : -1;
+        SV_REQUIRE(q.w_at >= 0 && q.w_at + d.n_dw <= n, "sv_adam_keras_step_slabs: description %d: dw is not inside grad", j);
+        SV_REQUIRE(d.db == nullptr || (q.b_at >= 0 && q.b_at + d.n_db <= n),
+                   "sv_adam_keras_step_slabs: description %d: db is not inside grad", j);
+        rg[nr++] = Range{q.w_at, d.n_dw};
+        if (d.db != nullptr && d.n_db > 0) rg[nr++] = Range{q.b_at, d.n_db};
+        a.first[j] = blocks;
+        blocks += (d.n_dw + d.n_db + 63) / 64;
+    }
+    a.first[n_slabs] = blocks;
+    a.rest_first = blocks;
+    for (int i = 1; i < nr; ++i)
+        for (int k = i; k > 0 && rg[k].at < rg[k - 1].at; --k) { const Range t = rg[k]; rg[k] = rg[k - 1]; rg[k - 1] = t; }
+    int64_t at = 0, total = 0;
+    a.n_gaps = 0;
+    for (int i = 0; i <= nr; ++i) {
+        const int64_t end = i < nr ? rg[i].at : n;
+        SV_REQUIRE(end >= at, "sv_adam_keras_step_slabs: descriptions overlap");
+        if (end > at) {
+            a.gap_at[a.n_gaps] = at;
+            a.gap_first[a.n_gaps] = total;
+            total += end - at;
+            ++a.n_gaps;
+        }
+        if (i < nr) at = rg[i].at + rg[i].len;
+    }
+    a.gap_first[a.n_gaps] = total;
+    // the last workgroup carries the scalar fold: keep at least one `rest` workgroup (it has the least to do)
+    int rest = (int)ceil_div(total, 4096);
+    if (rest < 1) rest = 1;
+    if (rest > 256) rest = 256;
+    hipLaunchKernelGGL(adam_slabs_k, dim3((unsigned)(blocks + rest)), dim3(1024), 0, to_stream(stream), a);
+    return check_launch("sv_adam_keras_step_slabs");
 }
 
 int sv_dense_fwd(const void* x, const void* w, const void* bias, void* y, int M, int K, int N, int act, float alpha,

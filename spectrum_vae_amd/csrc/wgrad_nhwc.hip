@@ -35,9 +35,17 @@ struct WnArgs {
     int ns;               // samples per pass
     int slab_floats;      // 9 * Cin * Cout + Cout rounded up to 4
     int hq_log;           // log2(Ho / 4)
-    int dbg;              // measurement only: 1 skip the matrix-core loop, 2 skip the LDS stores, 4 skip the global loads
+    int dbg;              // diagnostic build only (see WN_DBG): 1 skip the matrix-core loop, 2 the LDS stores, 4 the global loads
     ActGradCoef zk;
 };
+
+// Ablation switches exist in the diagnostic build (make TRACE=1) only: they make the results invalid, so the release
+// library has no way to turn them on.
+#ifdef SV_TRACE
+#define WN_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define WN_DBG(a, bit) 0
+#endif
 
 constexpr int kWnUnits = 4;  // 16-byte pieces per thread, tensor and pass held in registers between load and store
 
@@ -201,11 +209,11 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
     for (; n0 < a.N; n0 += gx * a.ns) {
         const int ns = min(a.ns, a.N - n0);
         __syncthreads();  // zero fill landed / the previous pass's operand reads are done
-        if (!(a.dbg & 2)) store_pass(ns);
+        if (!WN_DBG(a, 2)) store_pass(ns);
         __syncthreads();
-        if (n0 + gx * a.ns < a.N && !(a.dbg & 4)) load_pass(n0 + gx * a.ns);  // in flight during this pass's arithmetic
+        if (n0 + gx * a.ns < a.N && !WN_DBG(a, 4)) load_pass(n0 + gx * a.ns);  // in flight during this pass's arithmetic
 
-        if (a.dbg & 1) continue;
+        if (WN_DBG(a, 1)) continue;
         // A wave owns the image rows oh = wave, wave + 4, ...; within a row every operand address is a per-lane register
         // (row base + the lane's constant) plus a compile-time offset, and the reads of the next row are issued before
         // the matrix-core instructions of the current one (two register sets).
@@ -462,18 +470,25 @@ static WnPlan plan_wn(const sv_wgrad_batch_job& q) {
     return p;
 }
 
-// 1: some job is outside this family or its workspace is too small for the slabs (the caller takes the planar kernels);
-// 0: launched;  < 0: error.
-int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st) {
-    if (n_jobs < 1 || n_jobs > kWnMaxJobs) return 1;
-    if (const char* e = std::getenv("SPECTRUM_WGRAD_NHWC"))
-        if (e[0] == '0') return 1;
-    WnPlan plans[kWnMaxJobs];
+// Whether launch_wgrad_nhwc_batch takes these jobs.
+bool wgrad_nhwc_batch_ok(const sv_wgrad_batch_job* jobs, int n_jobs) {
+    if (n_jobs < 1 || n_jobs > kWnMaxJobs) return false;
+    if (opt(OPT_WGRAD_NHWC) == 0) return false;
     for (int j = 0; j < n_jobs; ++j) {
-        plans[j] = plan_wn(jobs[j]);
-        if (!plans[j].ok) return 1;
-        if (jobs[j].workspace == nullptr || jobs[j].workspace_bytes < (size_t)plans[j].gx * plans[j].slab_floats * sizeof(float)) return 1;
+        const WnPlan p = plan_wn(jobs[j]);
+        if (!p.ok) return false;
+        if (jobs[j].workspace == nullptr || jobs[j].workspace_bytes < (size_t)p.gx * p.slab_floats * sizeof(float)) return false;
     }
+    return true;
+}
+
+// 1: some job is outside this family or its workspace is too small for the slabs (the caller takes the planar kernels);
+// 0: launched;  < 0: error.  slabs_out != nullptr: the slabs are NOT summed here; slabs_out[j] describes job j's slabs
+// for whoever consumes them (the optimizer launch that reads its gradients as sums of slabs).
+int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st, sv_grad_slabs* slabs_out) {
+    if (!wgrad_nhwc_batch_ok(jobs, n_jobs)) return 1;
+    WnPlan plans[kWnMaxJobs];
+    for (int j = 0; j < n_jobs; ++j) plans[j] = plan_wn(jobs[j]);
     // longest-lived workgroups first (matrix-core work per workgroup), so the launch does not end on a long one
     int ord[kWnMaxJobs];
     auto cost = [&](int j) {
@@ -498,7 +513,9 @@ int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStrea
         a.N = g.N; a.Ho = g.H; a.Wo = g.W; a.up = g.up_h; a.Hs = g.H / g.up_h; a.Ws = g.W / g.up_w;
         a.zmode = q.idx != nullptr ? 2 : 1; a.with_bias = q.db != nullptr; a.ns = p.ns; a.slab_floats = p.slab_floats; a.hq_log = p.hq_log;
         a.zk = act_grad_coef(q.act, q.alpha);
+#ifdef SV_TRACE
         if (const char* e = std::getenv("SPECTRUM_WGRAD_DBG")) a.dbg = atoi(e);
+#endif
         m.shape[s] = p.shape;
         m.first[s] = blocks;
         blocks += p.gx;
@@ -514,10 +531,18 @@ int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStrea
     hipLaunchKernelGGL(wgrad_nhwc_multi, dim3((unsigned)blocks), dim3(256), lds, st, m);
     int rc = check_launch("wgrad_nhwc_multi");
     if (rc) return rc;
-    // measurements only (bit 8 of SPECTRUM_WGRAD_DBG): time the launch above without the sum of its slabs; dw / db stay
-    // as they were
-    if (const char* e = std::getenv("SPECTRUM_WGRAD_DBG"))
+    if (slabs_out != nullptr) {
+        for (int j = 0; j < n_jobs; ++j) {
+            const sv_conv_geom& g = jobs[j].g;
+            slabs_out[j] = sv_grad_slabs{jobs[j].workspace, jobs[j].dw, jobs[j].db, plans[j].slab_floats, plans[j].gx,
+                                         9 * g.Cin * g.Cout, g.Cout};
+        }
+        return SV_OK;
+    }
+#ifdef SV_TRACE
+    if (const char* e = std::getenv("SPECTRUM_WGRAD_DBG"))  // bit 8: the launch above without the sum of its slabs
         if (atoi(e) & 8) return SV_OK;
+#endif
     hipLaunchKernelGGL(wn_reduce_multi, dim3((unsigned)rblocks), dim3(1024), 0, st, rm);
     return check_launch("wn_reduce_multi");
 }

@@ -100,6 +100,8 @@ class Model(Layer):
         # slower than the per-layer kernels at the batch sizes measured so far: opt-in.
         self.use_net_fused_bwd = False
         self._chain_cache: Dict[int, object] = {}
+        self._slabs_wanted = False   # set around the backward pass of a training step whose optimizer launch can sum slabs
+        self._pending_slabs = None   # the table that backward pass left (ops.conv2d_wgrad_batch_slabs)
         # Optional: run the weight-gradient kernels, the gradient zero-fill and the optimizer's schedule update on
         # extra HIP streams beside the forward / input-gradient chain (fit / train_on_device_batch only).  Off by
         # default: at the shapes measured so far every conv launch already occupies the LDS of all CUs, so the
@@ -430,7 +432,10 @@ class Model(Layer):
             nb = self.wgrad_batch_blocks if len(ctx.wgrad_jobs) >= 3 else 0
             for j in ctx.wgrad_jobs:  # layers with large images: fewer workgroups, each staging more samples
                 j["blocks"] = (self.wgrad_batch_blocks_large if j["g"].H * j["g"].W >= 256 else nb) if nb else 0
-            if not ctx.wgrad_finish:  # nothing else waits for the finishing launch: the batch sums its own slabs
+            if not ctx.wgrad_finish and self._slabs_wanted and self._slabs_cover(ctx.wgrad_jobs, nb):
+                # the optimizer launch that follows reads its gradients as sums of the slabs: no summing launch
+                self._pending_slabs = ops.conv2d_wgrad_batch_slabs(ctx.wgrad_jobs, blocks=nb)
+            elif not ctx.wgrad_finish:  # nothing else waits for the finishing launch: the batch sums its own slabs
                 ops.conv2d_wgrad_batch(ctx.wgrad_jobs, reduce=True, blocks=nb)
             else:
                 ops.conv2d_wgrad_batch(ctx.wgrad_jobs, reduce=False, blocks=nb)
@@ -438,6 +443,19 @@ class Model(Layer):
             ctx.wgrad_jobs = None
             return dx
         return self.backward(ctx, dy, need_dx=need_dx)
+
+    def _slabs_cover(self, jobs, nb: int) -> bool:
+        """The kernel-gradient jobs of this backward pass can stay slabs for the optimizer launch: the library has that
+        form for all of them and together they are every trainable variable of the model (nothing else writes
+        gradients), decided once per batch size."""
+        key = ("slabs", jobs[0]["g"].N, len(jobs))
+        ok = self._chain_cache.get(key)
+        if ok is None:
+            covered = sum(j["dw"].numel() + (j["db"].numel() if j.get("db") is not None else 0) for j in jobs)
+            ok = (covered == sum(v.size for v in self.trainable_variables)
+                  and ops.conv2d_wgrad_batch_slabs_supported(jobs, blocks=nb))
+            self._chain_cache[key] = ok
+        return ok
 
     def zero_grad(self):
         self._materialize()
@@ -548,7 +566,14 @@ class Model(Layer):
             ops.axpy(b["acc"], b["loss"], weight)
         if side is not None:
             main.wait_event(zeroed)
-        self.backward_raw(b["dpred"], -1, need_dx=False)
+        # without a reducer (which needs the summed gradients in the flat buffer) the optimizer launch may take the
+        # kernel gradients as slabs of partial sums
+        self._slabs_wanted = side is None and self._reducer is None and hasattr(self.optimizer, "apply_model")
+        self._pending_slabs = None
+        try:
+            self.backward_raw(b["dpred"], -1, need_dx=False)
+        finally:
+            self._slabs_wanted = False
         if side is not None:
             for sd in side:
                 done = torch.cuda.Event()
@@ -561,7 +586,8 @@ class Model(Layer):
         if self._reducer is None:
             side = self._side_stream() is not None  # with side streams the schedule update runs beside the forward pass
             fold = self._fwd_bwd(b, same_xy, weight, prepare_opt=side)
-            self.optimizer.apply_model(self, 1.0, prepared=side, zero_grads=True, fold=fold)
+            slabs, self._pending_slabs = self._pending_slabs, None
+            self.optimizer.apply_model(self, 1.0, prepared=side, zero_grads=True, fold=fold, slabs=slabs)
             return
         fold = self._fwd_bwd(b, same_xy, weight)
         scale = self._reducer.all_reduce(self._grads)
@@ -592,16 +618,24 @@ class Model(Layer):
             g = None
             if self._reducer is not None and self._reducer.capturable(self._params.device):
                 # RCCL: the all-reduce is recorded with the rest of the step (one graph launch per step)
+                calls_before = self._reducer.calls
                 try:
                     graph = torch.cuda.CUDAGraph()
                     with recording(graph, capture_error_mode="thread_local"):
                         self._train_step_body(b, same_xy, weight)
                     g = (graph, None, "collective inside")
-                except RuntimeError:  # recording the whole step failed where the probe passed: collective between graphs
-                    self._reducer._capturable = False
+                except RuntimeError as e:  # recording the whole step failed where the probe passed
+                    import logging
+                    logging.getLogger(__name__).warning("recording the data-parallel step failed on this rank: %s", e)
                     torch.cuda.synchronize()
                     self._calls.clear()
-                self._reducer.note_reduced(self._grads, -1)  # recording is not reducing
+                if self._reducer.calls != calls_before:  # the recorded body reached the all-reduce: recording is not reducing
+                    self._reducer.note_reduced(self._grads, -1)
+                # the fallback must be taken by every rank or by none: one rank replaying a graph that holds the
+                # collective while another issues it eagerly between two graphs would not meet
+                if not self._reducer.agree(g is not None, self._params.device):
+                    g = None
+                    self._reducer._capturable = False
             if g is not None:
                 pass
             elif self._reducer is None:

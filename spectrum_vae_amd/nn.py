@@ -478,9 +478,10 @@ class _ConvBase(Layer):
 
     def masked_ok(self, g) -> bool:
         """The conv can read its input through a mask while gathering it (implicit-GEMM geometries, float32)."""
-        ok = self.__dict__.get("_masked_ok")
+        cache = self.__dict__.setdefault("_masked_ok", {})  # per batch size: index limits depend on N
+        ok = cache.get(g.N)
         if ok is None:
-            ok = self._masked_ok = self.pool is None and self.up == (1, 1) and ops.conv2d_masked_supported(g)
+            ok = cache[g.N] = self.pool is None and self.up == (1, 1) and ops.conv2d_masked_supported(g)
         return ok
 
     def backward(self, ctx, dy, need_dx=True):

@@ -12,7 +12,34 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT, BF16, F32, ConvGeom, NetLayer, WgradBatchJob, WgradJob, check, lib
+from ._lib import ACT, BF16, F32, ConvGeom, GradSlabs, NetLayer, WgradBatchJob, WgradJob, check, lib
+
+
+def set_option(name: str, value: int):
+    """Plan-time option of the library (``sv_set_option``): which of several equivalent kernel bodies / launch shapes a
+    planner picks; -1 = the planner's own choice."""
+    check(lib.sv_set_option(name.encode(), int(value)), "sv_set_option")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib.sv_get_option(name.encode(), C.byref(v)), "sv_get_option")
+    return int(v.value)
+
+
+class option:
+    """``with ops.option("dgrad_nhwc", 0): ...`` - an option for the duration of a block (tests, measurements)."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name, int(value)
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
 
 
 def _stream() -> int:
@@ -232,11 +259,7 @@ def conv2d_bwd_partial(g: ConvGeom, x, dy, y, idx, act: str, alpha: float, with_
           "sv_conv2d_bwd_partial")
 
 
-def conv2d_wgrad_batch(jobs, reduce: bool = True, blocks: int = 0):
-    """jobs: list of dicts g, x, dy, y, idx, act, alpha, dw, db, ws; gradients accumulate into dw / db (reduce=False:
-    the partial sums stay in the workspaces for ``conv2d_wgrad_finish``)."""
-    if not jobs:
-        return
+def _wgrad_batch_jobs(jobs, blocks: int):
     arr = (WgradBatchJob * len(jobs))()
     for a, d in zip(arr, jobs):
         a.g = d["g"]
@@ -244,7 +267,32 @@ def conv2d_wgrad_batch(jobs, reduce: bool = True, blocks: int = 0):
         a.dw, a.db = _ptr(d["dw"]), _ptr(d.get("db"))
         a.workspace, a.workspace_bytes = _ptr(d["ws"], torch.uint8), d["ws"].numel()
         a.act, a.alpha, a.accumulate, a.blocks = ACT[d["act"]], float(d["alpha"] or 0.0), 1, d.get("blocks", blocks)
+    return arr
+
+
+def conv2d_wgrad_batch(jobs, reduce: bool = True, blocks: int = 0):
+    """jobs: list of dicts g, x, dy, y, idx, act, alpha, dw, db, ws; gradients accumulate into dw / db (reduce=False:
+    the partial sums stay in the workspaces for ``conv2d_wgrad_finish``)."""
+    if not jobs:
+        return
+    arr = _wgrad_batch_jobs(jobs, blocks)
     check(lib.sv_conv2d_wgrad_batch(arr, len(jobs), int(reduce), F32, _stream()), "sv_conv2d_wgrad_batch")
+
+
+def conv2d_wgrad_batch_slabs_supported(jobs, blocks: int = 0) -> bool:
+    """Whether ``conv2d_wgrad_batch_slabs`` takes these jobs (all of them in the few-channel 3x3 family, at most 8)."""
+    if not jobs or len(jobs) > 8:
+        return False
+    return bool(lib.sv_conv2d_wgrad_batch_slabs_supported(_wgrad_batch_jobs(jobs, blocks), len(jobs)))
+
+
+def conv2d_wgrad_batch_slabs(jobs, blocks: int = 0):
+    """The kernel / bias gradients of the jobs as slabs of partial sums left in the jobs' workspaces; returns the
+    ``sv_grad_slabs`` table for ``adam_step(..., slabs=)`` (dw / db are not touched)."""
+    arr = _wgrad_batch_jobs(jobs, blocks)
+    out = (GradSlabs * len(jobs))()
+    check(lib.sv_conv2d_wgrad_batch_slabs(arr, len(jobs), out, F32, _stream()), "sv_conv2d_wgrad_batch_slabs")
+    return out
 
 
 def conv2d_wgrad_finish(jobs):
@@ -488,19 +536,24 @@ def adam_prepare(state, lr0, beta1, beta2, decay_steps, decay_rate, staircase):
 
 
 def adam_step(theta, grad, m, v, state, lr0, beta1, beta2, eps, decay_steps, decay_rate, staircase, grad_scale=1.0,
-              zero_grad=False, theta_lp=None, fold=None):
+              zero_grad=False, theta_lp=None, fold=None, slabs=None):
     """Schedule + update in one launch; ``theta_lp``: optional bfloat16 copy of theta refreshed in the same pass;
-    ``fold``: optional pending scalar fold ``(partials, n, scale, out, running, running_weight)`` carried by the launch."""
+    ``fold``: optional pending scalar fold ``(partials, n, scale, out, running, running_weight)`` carried by the launch;
+    ``slabs``: the table ``conv2d_wgrad_batch_slabs`` returned - the gradient of the elements it covers is grad + the sum
+    of the slabs."""
     if not (theta.numel() == grad.numel() == m.numel() == v.numel()):
         raise ValueError("adam: buffer sizes differ")
     if theta_lp is not None and theta_lp.numel() != theta.numel():
         raise ValueError("adam: the bf16 copy has a different size")
-    check(lib.sv_adam_keras_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), _ptr(state, torch.int64), lr0,
-                                 beta1, beta2, eps, int(decay_steps or 0), decay_rate, int(staircase), grad_scale,
-                                 int(zero_grad), _ptr(theta_lp, torch.bfloat16) if theta_lp is not None else None,
-                                 *((_ptr(fold[0]), int(fold[1]), float(fold[2]), _ptr(fold[3]), _ptr(fold[4]),
-                                    float(fold[5])) if fold is not None else (None, 0, 0.0, None, None, 0.0)),
-                                 _stream()), "sv_adam_keras_step")
+    head = (_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), _ptr(state, torch.int64), lr0,
+            beta1, beta2, eps, int(decay_steps or 0), decay_rate, int(staircase), grad_scale,
+            int(zero_grad), _ptr(theta_lp, torch.bfloat16) if theta_lp is not None else None,
+            *((_ptr(fold[0]), int(fold[1]), float(fold[2]), _ptr(fold[3]), _ptr(fold[4]),
+               float(fold[5])) if fold is not None else (None, 0, 0.0, None, None, 0.0)))
+    if slabs is not None:
+        check(lib.sv_adam_keras_step_slabs(*head, slabs, len(slabs), _stream()), "sv_adam_keras_step_slabs")
+    else:
+        check(lib.sv_adam_keras_step(*head, _stream()), "sv_adam_keras_step")
 
 
 def adam_apply(theta, grad, m, v, state, beta1, beta2, eps, grad_scale=1.0, zero_grad=False):

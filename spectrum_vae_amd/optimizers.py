@@ -81,13 +81,17 @@ class Adam:
         self._prepare(device)
 
     # ---- the fused path: one launch over the model's whole flat parameter buffer
-    def apply_model(self, model, grad_scale: float = 1.0, prepared: bool = False, zero_grads: bool = False, fold=None):
+    def apply_model(self, model, grad_scale: float = 1.0, prepared: bool = False, zero_grads: bool = False, fold=None,
+                    slabs=None):
         """``zero_grads``: the launch also clears the model's gradient buffer (training loops whose next backward
         accumulates into it), which saves the separate fill of the next step.  ``fold``: a pending scalar fold
         ``(partials, n, scale, out, running, running_weight)`` (the loss of a forward launch that left per-workgroup
-        sums) carried by the same launch."""
+        sums) carried by the same launch.  ``slabs``: kernel / bias gradients still lying as slabs of partial sums
+        (``ops.conv2d_wgrad_batch_slabs``); the one-launch form sums them on the way in."""
         m, v = self._slots_for(model)
         st = self._ensure_state(model._params.device)
+        if slabs is not None and prepared:
+            raise ValueError("apply_model: gradient slabs need the one-launch form (prepared=False)")
         if prepared:
             if fold is not None:
                 ops.fold_scalar(fold[0], fold[1], fold[2], fold[3], False, fold[4], fold[5])
@@ -99,7 +103,7 @@ class Adam:
             sc = self.schedule
             ops.adam_step(model._params, model._grads, m, v, st, self.lr0, self.beta_1, self.beta_2, self.epsilon,
                           sc.decay_steps if sc else 0, sc.decay_rate if sc else 1.0, sc.staircase if sc else False,
-                          grad_scale, zero_grads, model._params_lp, fold)
+                          grad_scale, zero_grads, model._params_lp, fold, slabs)
             model._lp_dirty = False
         model._grads_clean = bool(zero_grads)
 

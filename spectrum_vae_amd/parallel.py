@@ -16,6 +16,7 @@ issued between them.
 """
 from __future__ import annotations
 
+import logging
 import os
 from typing import Optional
 
@@ -23,6 +24,8 @@ import torch
 import torch.distributed as dist
 
 from .nn import recording
+
+_log = logging.getLogger(__name__)
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
@@ -121,12 +124,28 @@ class GradReducer:
                 if float(t[0]) != float(self.world) ** 2 or float(t[-1]) != float(self.world) ** 2:
                     flag.zero_()
                 self._probe_graph = g  # keep the recorded collective alive as long as its communicator
-            except Exception:  # noqa: BLE001 - any failure means: keep the collective outside the graphs
+            except Exception as e:  # noqa: BLE001 - any failure means: keep the collective outside the graphs
                 flag.zero_()
+                _log.warning("GradReducer: recording the all-reduce into a HIP graph failed on this rank (%s: %s); "
+                             "every rank keeps the collective between two graphs", type(e).__name__, e)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)  # one rank failing switches every rank
             ok = bool(flag.item() > 0)
+            if not ok:
+                _log.info("GradReducer: all-reduce stays outside the step graph (probe failed on some rank)")
         self._capturable = ok
         return ok
+
+    def agree(self, ok: bool, device) -> bool:
+        """True only when ``ok`` holds on EVERY rank (a MIN all-reduce, as in the probe): a decision each rank would
+        otherwise take alone - such as falling back after a failed whole-step recording - must be the same everywhere,
+        or some ranks would replay a graph holding the collective while others issue it eagerly."""
+        if not self._collective():
+            return bool(ok)
+        flag = torch.full((1,), 1.0 if ok else 0.0, device=device)
+        if self._host_staged and flag.is_cuda:
+            flag = flag.cpu()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() > 0)
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         """Make every replica start from rank ``src``'s values (weights, BatchNorm state)."""

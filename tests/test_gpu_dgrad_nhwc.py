@@ -38,9 +38,8 @@ def reference(w, dy, y, idx, up, act):
 
 @pytest.mark.parametrize("n", [1, 3, 7, 130, 1024, 1027])
 @pytest.mark.parametrize("spec", LAYERS, ids=[f"{s[2]}to{s[3]}" for s in LAYERS])
-def test_matches_float64(spec, n, monkeypatch):
+def test_matches_float64(spec, n, sv_opts):
     from spectrum_vae_amd import ops
-    monkeypatch.delenv("SPECTRUM_DGRAD_NHWC", raising=False)
     h, w_, cin, cout, up, pooled, act = spec
     H, W = h * up, w_ * up
     rng = np.random.default_rng(n + cin * 7)
@@ -63,19 +62,18 @@ def test_matches_float64(spec, n, monkeypatch):
     dx.fill_(-3.0)
     ops.conv2d_bwd(*args)
     assert torch.equal(dx, first)  # overwrites, bit-reproducible
-    monkeypatch.setenv("SPECTRUM_DGRAD_NHWC", "0")  # the planar kernels on the same call
+    sv_opts("dgrad_nhwc", 0)  # the planar kernels on the same call
     ops.conv2d_bwd(*args)
     assert float((dx - first).abs().max()) <= 4e-6 * float(first.abs().max())
 
 
 @pytest.mark.parametrize("n", [1, 5, 130, 1027])
 @pytest.mark.parametrize("spec", [LAYERS[3], LAYERS[4]], ids=["16to8", "8to3"])
-def test_stored_pixel_form_of_upsampled_layers_agrees_with_the_direct_form(spec, n, monkeypatch):
+def test_stored_pixel_form_of_upsampled_layers_agrees_with_the_direct_form(spec, n, sv_opts):
     """A conv behind a 2x upsampling: the kernel sums a 4 x 4 window of dz per STORED pixel with tap sums as weights
-    (default) or computes the upsampled image's gradient and adds 2 x 2 windows (SPECTRUM_DGRAD_PHASE=0).  The same
+    (default) or computes the upsampled image's gradient and adds 2 x 2 windows (option dgrad_phase = 0).  The same
     mathematics in a different association: agreement to rounding, and the switch does select two bodies."""
     from spectrum_vae_amd import ops
-    monkeypatch.delenv("SPECTRUM_DGRAD_NHWC", raising=False)
     h, w_, cin, cout, up, pooled, act = spec
     rng = np.random.default_rng(n + cout)
     g = ops.conv_geom(n, h * up, w_ * up, cin, 3, 3, 1, 1, "same", cout, (up, up))
@@ -84,7 +82,7 @@ def test_stored_pixel_form_of_upsampled_layers_agrees_with_the_direct_form(spec,
     dy = torch.from_numpy(rng.standard_normal((n, h * up, w_ * up, cout)).astype(np.float32)).cuda()
     got = {}
     for phase in ("1", "0"):
-        monkeypatch.setenv("SPECTRUM_DGRAD_PHASE", phase)
+        sv_opts("dgrad_phase", int(phase))
         dx = torch.full((n, h, w_, cin), 7.0, device="cuda")
         ops.conv2d_bwd(g, None, wt, dy, y, None, dx, None, None, act, 1.0, None)
         got[phase] = dx
@@ -93,12 +91,11 @@ def test_stored_pixel_form_of_upsampled_layers_agrees_with_the_direct_form(spec,
 
 
 @pytest.mark.parametrize("n", [1, 5, 130, 1027])
-def test_pixel_pair_form_of_the_8_channel_layer_equals_the_direct_form(n, monkeypatch):
+def test_pixel_pair_form_of_the_8_channel_layer_equals_the_direct_form(n, sv_opts):
     """16 -> 8 channels back through a pooled 16 x 16 layer: rows 8..15 of the filter operand hold the filters shifted by
     one column, a result column is a pair of adjacent pixels (default), or every pixel is its own column
-    (SPECTRUM_DGRAD_PAIR=0).  The extra products have zero weights: the sums are the same, bit for bit."""
+    (option dgrad_pair = 0).  The extra products have zero weights: the sums are the same, bit for bit."""
     from spectrum_vae_amd import ops
-    monkeypatch.delenv("SPECTRUM_DGRAD_NHWC", raising=False)
     h, w_, cin, cout, up, pooled, act = LAYERS[0]
     rng = np.random.default_rng(n + 17)
     g = ops.conv_geom(n, h, w_, cin, 3, 3, 1, 1, "same", cout, (1, 1))
@@ -108,7 +105,7 @@ def test_pixel_pair_form_of_the_8_channel_layer_equals_the_direct_form(n, monkey
     idx = torch.from_numpy(rng.integers(0, 4, (n, h // 2, w_ // 2, cout)).astype(np.uint8)).cuda()
     got = {}
     for pair in ("1", "0"):
-        monkeypatch.setenv("SPECTRUM_DGRAD_PAIR", pair)
+        sv_opts("dgrad_pair", int(pair))
         dx = torch.full((n, h, w_, cin), 7.0, device="cuda")
         ops.conv2d_bwd(g, None, wt, dy, y, idx, dx, None, None, act, 1.0, None)
         got[pair] = dx

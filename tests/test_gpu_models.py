@@ -554,9 +554,9 @@ def test_whole_network_forward_matches_per_layer_path_and_oracle(n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [2, 5, 64, 1100, 2100])
-def test_forward_kernel_built_for_the_default_layer_table_equals_the_run_time_table_kernel(n, monkeypatch):
+def test_forward_kernel_built_for_the_default_layer_table_equals_the_run_time_table_kernel(n, sv_opts):
     """The run_model.py default conv stack has a forward kernel compiled for its layer table (extents and LDS layout as
-    constants); SPECTRUM_NETFWD_GENERIC selects the kernel that reads the table at run time.  Same arithmetic in the same
+    constants); the option netfwd_generic selects the kernel that reads the table at run time.  Same arithmetic in the same
     order: every layer output, the argmax bytes, the loss gradient and the loss partial sums agree bit for bit.  2100
     samples are more passes than the loss workspace has slots, so that launch takes the run-time-table kernel by itself."""
     from spectrum_vae_amd import autoencoder, ops
@@ -564,10 +564,7 @@ def test_forward_kernel_built_for_the_default_layer_table_equals_the_run_time_ta
     x = to_device_f32(data(n, seed=51 + n))
     got = {}
     for generic in (False, True):
-        if generic:
-            monkeypatch.setenv("SPECTRUM_NETFWD_GENERIC", "1")
-        else:
-            monkeypatch.delenv("SPECTRUM_NETFWD_GENERIC", raising=False)
+        sv_opts("netfwd_generic", 1 if generic else -1)
         model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
         model.build((None, 32, 32, 3))
         model._materialize()
@@ -711,20 +708,17 @@ def test_gan_steps_replayed_with_overlapped_updates_equal_the_serial_steps():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 3, 7, 130])
-def test_matrix_core_bodies_agree_with_the_vector_bodies(n, monkeypatch):
+def test_matrix_core_bodies_agree_with_the_vector_bodies(n, sv_opts):
     """The 16/32-channel layers run on MFMA tiles in the fused forward, the input-gradient and the kernel-gradient
-    kernels; the SPECTRUM_*_VALU switches select the vector bodies at plan time.  Both must give the same prediction
+    kernels; the *_valu options select the vector bodies at plan time.  Both must give the same prediction
     and gradients to rounding, also for batches that leave a pass or a wave partly empty."""
     from spectrum_vae_amd import autoencoder, losses
     from spectrum_vae_amd.losses import to_device_f32
     x = data(n, seed=23 + n)
     res = {}
     for mode in ("mfma", "valu"):
-        for var in ("SPECTRUM_NETFWD_VALU", "SPECTRUM_DGRAD_VALU", "SPECTRUM_WGRAD_VALU"):
-            if mode == "valu":
-                monkeypatch.setenv(var, "1")
-            else:
-                monkeypatch.delenv(var, raising=False)
+        for name in ("netfwd_valu", "dgrad_valu", "wgrad_valu"):
+            sv_opts(name, 1 if mode == "valu" else -1)
         model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
         model.build((None, 32, 32, 3))
         model._materialize()

@@ -71,9 +71,8 @@ def rel_err(got, want):
 
 
 @pytest.mark.parametrize("n,blocks", [(1, 0), (3, 0), (7, 2), (130, 0), (130, 16), (1024, 128), (1024, 256), (1027, 64)])
-def test_matches_float64(n, blocks, monkeypatch):
+def test_matches_float64(n, blocks):
     from spectrum_vae_amd import ops
-    monkeypatch.delenv("SPECTRUM_WGRAD_NHWC", raising=False)
     rng = np.random.default_rng(n * 31 + blocks)
     jobs, refs = make_jobs(n, rng, blocks=blocks)
     ops.conv2d_wgrad_batch(jobs, reduce=True)
@@ -92,17 +91,16 @@ def test_matches_float64(n, blocks, monkeypatch):
         assert torch.equal(j["dw"], dw1) and torch.equal(j["db"], db1)
 
 
-def test_agrees_with_the_planar_kernels(monkeypatch):
-    """SPECTRUM_WGRAD_NHWC=0 selects the planar (vector / matrix-core) bodies for the same call."""
+def test_agrees_with_the_planar_kernels(sv_opts):
+    """Option wgrad_nhwc = 0 selects the planar (vector / matrix-core) bodies for the same call."""
     from spectrum_vae_amd import ops
     rng = np.random.default_rng(77)
     jobs, _ = make_jobs(37, rng)
-    monkeypatch.delenv("SPECTRUM_WGRAD_NHWC", raising=False)
     ops.conv2d_wgrad_batch(jobs, reduce=True)
     new = [(j["dw"].clone(), j["db"].clone()) for j in jobs]
     for j in jobs:
         j["dw"].zero_(), j["db"].zero_()
-    monkeypatch.setenv("SPECTRUM_WGRAD_NHWC", "0")
+    sv_opts("wgrad_nhwc", 0)
     ops.conv2d_wgrad_batch(jobs, reduce=True)
     for j, (dw1, db1) in zip(jobs, new):
         assert float((j["dw"] - dw1).abs().max()) <= 1e-5 * float(dw1.abs().max())
@@ -118,3 +116,59 @@ def test_other_shapes_take_the_planar_kernels():
     ops.conv2d_wgrad_batch(jobs, reduce=True)
     for j, (dw, db) in zip(jobs, refs):
         assert rel_err(j["dw"], dw) < 2e-5 and rel_err(j["db"], db) < 2e-5
+
+
+@pytest.mark.parametrize("n,blocks,extra", [(5, 0, 0), (130, 16, 24), (1024, 128, 0)])
+def test_optimizer_launch_that_sums_the_slabs_equals_the_two_launch_route(n, blocks, extra):
+    """sv_conv2d_wgrad_batch_slabs leaves the partial sums in the workspaces and sv_adam_keras_step_slabs forms each
+    gradient as grad + sum of slabs on its way into the Adam update; sv_conv2d_wgrad_batch(reduce = 1) followed by
+    sv_adam_keras_step is the same arithmetic in the same order: weights, moments, the cleared gradient buffer and the
+    update count agree bit for bit, over two steps, with a non-zero gradient already in the buffer and with `extra`
+    elements that no slab covers (other variables, alignment gaps)."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(n + blocks)
+    jobs, _ = make_jobs(n, rng, blocks=blocks)
+    # lay the variables out in one flat buffer the way a model does (8-float alignment), `extra` uncovered floats in front
+    offs, at = [], extra
+    for j in jobs:
+        nw, nb = j["dw"].numel(), j["db"].numel()
+        offs.append((at, at + -(-nw // 8) * 8))
+        at += -(-nw // 8) * 8 + -(-nb // 8) * 8
+    total = at
+
+    def run(slabs_route):
+        torch.manual_seed(5)
+        theta = torch.randn(total, device="cuda")
+        grad = torch.randn(total, device="cuda") * 0.01  # something is already there: both routes add to it
+        m, v = torch.zeros(total, device="cuda"), torch.zeros(total, device="cuda")
+        state = torch.zeros(3, dtype=torch.int64, device="cuda")
+        js = []
+        for j, (wo, bo) in zip(jobs, offs):
+            jj = dict(j)
+            jj["dw"] = grad[wo:wo + j["dw"].numel()].view(j["dw"].shape)
+            jj["db"] = grad[bo:bo + j["db"].numel()]
+            js.append(jj)
+        for _ in range(2):
+            if slabs_route:
+                assert ops.conv2d_wgrad_batch_slabs_supported(js)
+                table = ops.conv2d_wgrad_batch_slabs(js)
+                ops.adam_step(theta, grad, m, v, state, 1e-3, 0.9, 0.999, 1e-7, 10, 0.96, True, 1.0, True, None, None, table)
+            else:
+                ops.conv2d_wgrad_batch(js, reduce=True)
+                ops.adam_step(theta, grad, m, v, state, 1e-3, 0.9, 0.999, 1e-7, 10, 0.96, True, 1.0, True, None, None)
+        torch.cuda.synchronize()
+        return theta, grad, m, v, state
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("theta", "grad", "m", "v", "state")):
+        assert torch.equal(x, y), name
+    assert int(a[4][0]) == 2 and float(a[1].abs().max()) == 0.0 and float(a[2].abs().max()) > 0
+
+
+def test_slabs_form_refuses_shapes_outside_the_family():
+    from spectrum_vae_amd import _lib, ops
+    rng = np.random.default_rng(4)
+    jobs, _ = make_jobs(9, rng, layers=[(16, 16, 8, 8, 1, True, "relu")])
+    assert not ops.conv2d_wgrad_batch_slabs_supported(jobs)
+    with pytest.raises(_lib.SpectrumHipError, match="outside"):
+        ops.conv2d_wgrad_batch_slabs(jobs)

@@ -30,10 +30,14 @@ def _both(g, x, dz, accumulate):
     want = start.clone()
     ops.conv2d_wgrad(g, x, dz, want, accumulate, ws)
     got = start.clone()
-    before = torch.cuda.memory_allocated()
-    ops.conv2d_wgrad_static(g, x, dz, got, accumulate)
-    assert torch.cuda.memory_allocated() == before  # nothing came from torch's allocator either
+    ops.static_scratch_bytes()  # the once-per-GPU address lookup, outside the measurement below
     torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    free_before = torch.cuda.mem_get_info()[0]
+    ops.conv2d_wgrad_static(g, x, dz, got, accumulate)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() == before  # nothing came from torch's allocator ...
+    assert torch.cuda.mem_get_info()[0] == free_before  # ... and nothing from hipMalloc inside the library
     return got, want
 
 
@@ -73,3 +77,49 @@ def test_static_scratch_refuses_what_does_not_fit():
     x = torch.zeros(1, device="cuda")
     with pytest.raises(_lib.SpectrumHipError, match="built-in scratch"):
         ops.conv2d_wgrad_static(g, x, x, x, False)
+
+
+def test_static_scratch_inside_a_deferred_reduce_bracket():
+    """Between sv_deferred_reduce_begin and _flush the slab sums of ordinary calls are queued; a queued sum whose source
+    is the shared array would be overwritten by the next static call.  The static entry point therefore reduces at once:
+    two calls of different geometry inside one bracket both give the workspace form's bits."""
+    from spectrum_vae_amd import ops
+    (big, small) = CASES[1]  # implicit GEMM with a split reduction: the path that defers
+    g1, x1, dz1 = _pair(big, 11)
+    g2, x2, dz2 = _pair(small, 12)
+    want = []
+    for g, x, dz in ((g1, x1, dz1), (g2, x2, dz2)):
+        w = torch.zeros((g.KH, g.KW, g.Cin, g.Cout), device="cuda")
+        ops.conv2d_wgrad(g, x, dz, w, False, torch.empty(ops.conv2d_wgrad_workspace(g), dtype=torch.uint8, device="cuda"))
+        want.append(w)
+    got = [torch.zeros_like(w) for w in want]
+    ops.deferred_reduce_begin()
+    try:
+        ops.conv2d_wgrad_static(g1, x1, dz1, got[0], False)
+        ops.conv2d_wgrad_static(g2, x2, dz2, got[1], False)
+    finally:
+        ops.deferred_reduce_flush(True)
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert float(want[0].abs().max()) > 0 and float(want[1].abs().max()) > 0
+
+
+def test_static_scratch_call_recorded_into_a_graph():
+    """The use case the entry point names: recorded into a HIP graph (no allocation may happen there) and replayed."""
+    from spectrum_vae_amd import ops
+    from spectrum_vae_amd.nn import recording
+    g, x, dz = _pair(CASES[0][0], 21)
+    ops.static_scratch_bytes()  # address lookup before the capture, as the header asks
+    ws = torch.empty(ops.conv2d_wgrad_workspace(g), dtype=torch.uint8, device="cuda")
+    want = torch.zeros((g.KH, g.KW, g.Cin, g.Cout), device="cuda")
+    ops.conv2d_wgrad(g, x, dz, want, False, ws)
+    got = torch.full_like(want, 5.0)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with recording(graph):
+        ops.conv2d_wgrad_static(g, x, dz, got, False)
+    for _ in range(2):
+        got.fill_(5.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
