@@ -180,6 +180,128 @@ def kernel_of_call(name: str, g):
     return None
 
 
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+
+
+def _dominant_call(table, dtype: str) -> dict:
+    """Of the conv / dense calls of one eager step, the one holding the most time, against the roof that bounds it:
+    algorithmic FLOPs (2 x MAC) against the matrix peak of the storage type, or the bytes of its operands and result
+    against HBM, whichever leaves the smaller fraction unexplained (the larger of the two fractions is reported)."""
+    esz = 2 if dtype == "bf16" else 4
+    peak_tf = BF16_MATRIX_PEAK_TFLOPS if dtype == "bf16" else FP32_MATRIX_PEAK_TFLOPS
+    best = None
+    for row in table:
+        g = row["geom"]
+        if not g or "KH" not in g:
+            continue
+        us = row["avg_us"] * row["calls_per_step"]
+        if best is None or us > best[0]:
+            best = (us, row)
+    if best is None:
+        return {}
+    row = best[1]
+    g = row["geom"]
+    fl = 2.0 * g["N"] * g["Ho"] * g["Wo"] * g["Cout"] * g["KH"] * g["KW"] * g["Cin"]
+    by = esz * (g["N"] * (g["H"] // g["up_h"]) * (g["W"] // g["up_w"]) * g["Cin"] + g["N"] * g["Ho"] * g["Wo"] * g["Cout"]
+                + g["KH"] * g["KW"] * g["Cin"] * g["Cout"])
+    t = row["avg_us"] * 1e-6
+    f_m, f_h = fl / t / 1e12 / peak_tf, by / t / 1e9 / HBM_PEAK_GBS
+    return {"call": row["call"], "geom": {k: g[k] for k in ("N", "H", "W", "Cin", "Cout", "KH", "SH", "up_h")},
+            "avg_call_us": round(row["avg_us"], 2), "calls_per_step": row["calls_per_step"],
+            "bound": "mfma" if f_m >= f_h else "hbm", "frac": round(max(f_m, f_h), 4),
+            "frac_of_matrix_peak": round(f_m, 4), "frac_of_hbm_peak": round(f_h, 4)}
+
+
+def run_secondary(device, steps: int = 30) -> dict:
+    """The other single-GPU configurations under the same clock as the headline, after its timed region: the U-Net GAN
+    step of run_unet.py:164-203 under the bf16 policy at batch 32 and 1024, the context-encoder + discriminator step of
+    run_context_encoder.py:225-260 in f32 at batch 64, and one VAEPadded (MSE + KL) step at batch 1024.  Each: best of
+    three runs of `steps` HIP-graph replays, and the dominant conv call of one eager step against its roof."""
+    from spectrum_vae_amd import autoencoder, context_encoder, losses, mixed_precision, run_context_encoder, run_unet, unet
+    from spectrum_vae_amd.data import synth_training_tensor
+    from spectrum_vae_amd.run_model import build_optimizer
+
+    def timed(fn):
+        for _ in range(6):
+            fn()
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / steps
+            best = dt if best is None or dt < best else best
+        return best
+
+    def per_call(fn_eager, dtype):
+        agg = {}
+        reps = 3
+        for _ in range(reps):
+            with OpTimer() as ot:
+                fn_eager()
+            for name, g, us in ot.table:
+                key = (name, json.dumps(g, sort_keys=True) if g else "")
+                a = agg.setdefault(key, {"us": 0.0, "calls": 0, "geom": g})
+                a["us"] += us
+                a["calls"] += 1
+        table = [{"call": k[0], "geom": v["geom"], "avg_us": v["us"] / v["calls"], "calls_per_step": v["calls"] / reps}
+                 for k, v in agg.items()]
+        return _dominant_call(table, dtype)
+
+    out = {}
+    try:
+        # ---- U-Net generator + discriminator, bf16 policy
+        mixed_precision.set_global_policy("mixed_bfloat16")
+        for B in (32, 1024):
+            Y = torch.from_numpy(synth_training_tensor(min(B, 256), 9)).to(device)
+            if B > Y.shape[0]:
+                Y = Y.repeat((B + Y.shape[0] - 1) // Y.shape[0], 1, 1, 1)[:B].contiguous()
+            Xu = Y[..., :1].contiguous()
+            gen, d2 = unet.Generator(), unet.Discriminator()
+            g1, g2 = run_unet.build_optimizer(2e-4), run_unet.build_optimizer(2e-4)
+            dt = timed(lambda: run_unet.train_step(gen, d2, g1, g2, Xu, Y))
+            dom = per_call(lambda: run_unet.train_step(gen, d2, g1, g2, Xu, Y, use_graph=False), "bf16")
+            out[f"unet_gan_step_bf16_b{B}"] = {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1),
+                                                "dtype": "bf16", "dominant": dom}
+            del gen, d2, g1, g2
+        # ---- context encoder + discriminator, f32
+        mixed_precision.set_global_policy("float32")
+        B = 64
+        X = torch.from_numpy(synth_training_tensor(B, 7)).to(device)
+        mask = torch.from_numpy(run_context_encoder.batch_random_mask(X.cpu().numpy(), 0.25, np.random.default_rng(1))).to(device)
+        ce, disc = context_encoder.ContextEncoder(), context_encoder.Discriminator()
+        o1, o2 = run_context_encoder.build_optimizer(2e-3), run_context_encoder.build_optimizer(2e-4)
+        dt = timed(lambda: run_context_encoder.train_step(ce, disc, o1, o2, X, mask))
+        dom = per_call(lambda: run_context_encoder.train_step(ce, disc, o1, o2, X, mask, use_graph=False), "f32")
+        out[f"context_encoder_step_f32_b{B}"] = {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1),
+                                                 "dtype": "f32", "dominant": dom}
+        del ce, disc, o1, o2
+        # ---- VAEPadded (no reference model uses Sampling; this build's variational form of CAEPadded), f32
+        B = 1024
+        vae = autoencoder.VAEPadded(conv_layers=3, conv_layer_multiplier=2, initial_filters=8, activation="elu",
+                                    kernel_size=3, conv_operations=1, fc_layers=2, fc_layer_size=64, latent_dimensions=8)
+        vae.build((None, 32, 32, 3))
+        vae._materialize(device)
+        vae.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
+        Xv = torch.from_numpy(synth_data(B, 77)).to(device)
+        bv = vae._step_buffers(B, (32, 32, 3))
+        ops_fill = __import__("spectrum_vae_amd.ops", fromlist=["fill"]).fill
+        ops_fill(bv["acc"], 0.0)
+        bv["x"].copy_(Xv)
+        dt = timed(lambda: vae.train_on_device_batch(bv, True, float(B)))
+        vae.use_graphs = False
+        dom = per_call(lambda: vae.train_on_device_batch(bv, True, float(B)), "f32")
+        out[f"vae_padded_step_f32_b{B}"] = {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1),
+                                            "dtype": "f32", "dominant": dom}
+    except Exception as e:  # noqa: BLE001 - the headline line must still be printed
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        mixed_precision.set_global_policy("float32")
+    return out
+
+
 def run_cpu_baseline(budget_s: float = 14.0, batch: int = PER_GPU_BATCH) -> dict:
     """The torch-CPU restatement of the same training step (oracle/torch_ref.py), timed on the host cores: at the
     bench's batch (the reported value) and at the reference loop's own batch of 32 (run_model.py:234,289)."""
@@ -223,6 +345,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the U-Net / context-encoder / VAE steps")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-out", default=None, help="write the per-call HIP-event table to this JSON file")
     args = ap.parse_args()
@@ -377,6 +500,10 @@ def main():
             with open(args.profile_out, "w") as f:
                 json.dump({"batch": bs, "per_call": table}, f, indent=1)
 
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = run_secondary(device)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = run_cpu_baseline()
@@ -406,6 +533,7 @@ def main():
             "final_loss": final_loss,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "secondary": secondary,
         }
         print(json.dumps(out))
     if world > 1:
