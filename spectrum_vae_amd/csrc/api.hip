@@ -61,6 +61,11 @@ int launch_tiled_wgrad(const float* x, const float* dz, float* dw, float* db, in
                        float zalpha = 0.f, int defer = 0, int with_bias = 0);
 int launch_wgrad_finish(const sv_wgrad_job* jobs, int n_jobs, hipStream_t st);
 int launch_wgrad_batch(const sv_wgrad_batch_job* jobs, int n_jobs, int reduce, hipStream_t st);
+// conv_s1_mfma.hip: stride-1 SAME convs on the matrix cores with channel-last LDS images (1: geometry not covered)
+bool s1_mfma_supported(const sv_conv_geom& g, int which);
+int launch_s1_fwd(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int act,
+                  float alpha, hipStream_t st);
+int launch_s1_dgrad(const sv_conv_geom& g, const float* dz, const float* w, float* dx, hipStream_t st);
 bool wgrad_nhwc_batch_ok(const sv_wgrad_batch_job* jobs, int n_jobs);  // wgrad_nhwc.hip
 int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st, sv_grad_slabs* slabs_out);
 int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
@@ -70,6 +75,15 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
 static bool tiled_shape(const sv_conv_geom& g) {
     return g.KH == g.KW && (g.KH == 3 || g.KH == 5) && g.SH == 1 && g.SW == 1 && g.pad_t == (g.KH - 1) / 2 &&
            g.pad_l == (g.KW - 1) / 2 && g.Ho == g.H && g.Wo == g.W && g.up_h == g.up_w && (g.up_h == 1 || g.up_h == 2);
+}
+
+// Whether a stride-1 SAME conv goes to the channel-last matrix-core kernel rather than the planar vector kernels: from 16
+// channels on both sides its 16-wide tiles are full (option s1_mfma: 1 forces it wherever it applies, 0 turns it off).
+static bool prefer_s1(const sv_conv_geom& g) {
+    const int o = opt(OPT_S1_MFMA);
+    if (o == 0) return false;
+    if (o == 1) return true;
+    return g.Cin % 16 == 0 && g.Cout % 16 == 0;
 }
 
 }  // namespace sv
@@ -119,6 +133,11 @@ int sv_conv2d_fwd_ws(const sv_conv_geom* g, const void* x, const void* w, const 
         return launch_fwd_bf16(*g, x, w, (const float*)bias, y, act, alpha, to_stream(stream), workspace, workspace_bytes);
     }
     if (tiled_shape(*g)) {
+        if (prefer_s1(*g)) {
+            rc = launch_s1_fwd(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, nullptr, act, alpha,
+                               to_stream(stream));
+            if (rc <= 0) return rc;
+        }
         rc = launch_tiled_s1((const float*)x, (const float*)w, (const float*)bias, (float*)y, nullptr, g->N,
                              g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, 0, 0, act, alpha,
                              to_stream(stream));
@@ -143,6 +162,10 @@ int sv_conv2d_dgrad_ws(const sv_conv_geom* g, const void* dz, const void* w, voi
         return launch_dgrad_bf16(*g, dz, w, nullptr, dx, SV_ACT_NONE, 0.f, to_stream(stream), workspace, workspace_bytes);
     }
     if (tiled_shape(*g)) {
+        if (prefer_s1(*g)) {
+            rc = launch_s1_dgrad(*g, (const float*)dz, (const float*)w, (float*)dx, to_stream(stream));
+            if (rc <= 0) return rc;
+        }
         // a conv of dz (Cout channels, logical resolution) with mirrored taps and swapped channel roles; a folded
         // upsampling turns into a 2x2 sum of the result
         rc = launch_tiled_s1((const float*)dz, (const float*)w, nullptr, (float*)dx, nullptr, g->N, g->H, g->W, g->Cout,
@@ -227,6 +250,12 @@ int sv_conv2d_pool_fwd(const sv_conv_geom* g, const void* x, const void* w, cons
     if (rc) return rc;
     SV_REQUIRE(x && w && y_pooled, "sv_conv2d_pool_fwd: null tensor");
     SV_REQUIRE(sv_conv2d_fused_supported(g, 1), "sv_conv2d_pool_fwd: shape is outside the fused family");
+    SV_REQUIRE(idx != nullptr, "sv_conv2d_pool_fwd: null argmax tensor");
+    if (prefer_s1(*g)) {
+        rc = launch_s1_fwd(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y_pooled, idx, act, alpha,
+                           to_stream(stream));
+        if (rc <= 0) return rc;
+    }
     rc = launch_tiled_s1((const float*)x, (const float*)w, (const float*)bias, (float*)y_pooled, idx, g->N,
                          g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h, 0, 1, act, alpha,
                          to_stream(stream));
