@@ -104,6 +104,11 @@ int sv_conv2d_wgrad_static(const sv_conv_geom* g, const void* x, const void* dz,
  *      only; dx == NULL: weight gradients only), so the two halves can be issued on different streams.
  *      workspace (needed when dw != NULL): sv_conv2d_wgrad_workspace_bytes(g). */
 int sv_conv2d_fused_supported(const sv_conv_geom* g, int pooled);
+/* 1 when sv_conv2d_bwd runs this geometry on the matrix-core kernels for 16..128-channel layers (the shapes of the
+ * run_model.py:164-219 grid beyond the default stack): dz is then formed once in the workspace and feeds both the
+ * input-gradient and the kernel-gradient kernel, so a caller gains nothing from batching this layer's kernel gradient
+ * with other layers' (sv_conv2d_wgrad_batch) and should call sv_conv2d_bwd with dx and dw together. */
+int sv_conv2d_s1_mfma_bwd(const sv_conv_geom* g);
 int sv_conv2d_pool_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y_pooled,
                        uint8_t* idx, int act, float alpha, int dtype, sv_stream_t stream);
 int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const void* dy, const void* y,

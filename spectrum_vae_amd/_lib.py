@@ -73,6 +73,7 @@ SIGNATURES = {
     "sv_static_scratch_bytes": (_sz, []),
     "sv_conv2d_wgrad_static": (_i, [_g, _p, _p, _p, _i, _i, _p]),
     "sv_conv2d_fused_supported": (_i, [_g, _i]),
+    "sv_conv2d_s1_mfma_bwd": (_i, [_g]),
     "sv_conv2d_pool_fwd": (_i, [_g, _p, _p, _p, _p, _p, _i, _f, _i, _p]),
     "sv_conv2d_bwd": (_i, [_g, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _sz, _i, _p]),
     "sv_convnet_supported": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i]),

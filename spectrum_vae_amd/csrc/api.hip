@@ -66,6 +66,13 @@ bool s1_mfma_supported(const sv_conv_geom& g, int which);
 int launch_s1_fwd(const sv_conv_geom& g, const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int act,
                   float alpha, hipStream_t st);
 int launch_s1_dgrad(const sv_conv_geom& g, const float* dz, const float* w, float* dx, hipStream_t st);
+// wgrad_s1_mfma.hip
+bool wgrad_s1_mfma_supported(const sv_conv_geom& g);
+size_t wgrad_s1_mfma_workspace(const sv_conv_geom& g);
+int launch_wgrad_s1_mfma(const sv_conv_geom& g, const float* x, const float* dz, float* dw, float* db, int accumulate,
+                         void* ws, size_t ws_bytes, hipStream_t st);
+int launch_form_dz(const float* dy, const float* y, const uint8_t* idx, float* dz, int N, int H, int W, int C, int act,
+                   float alpha, hipStream_t st);
 bool wgrad_nhwc_batch_ok(const sv_wgrad_batch_job* jobs, int n_jobs);  // wgrad_nhwc.hip
 int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st, sv_grad_slabs* slabs_out);
 int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
@@ -85,6 +92,16 @@ static bool prefer_s1(const sv_conv_geom& g) {
     if (o == 1) return true;
     return g.Cin % 16 == 0 && g.Cout % 16 == 0;
 }
+
+// The backward of such a layer through the matrix-core kernels: dz = dy * act'(y) (scattered through the pooling argmax)
+// is formed ONCE in the workspace and feeds both the input-gradient and the kernel-gradient kernel.
+static size_t s1_bwd_dz_bytes(const sv_conv_geom& g) {
+    return (((size_t)g.N * g.H * g.W * g.Cout * sizeof(float)) + 255) & ~(size_t)255;
+}
+static bool s1_bwd_ok(const sv_conv_geom& g) {
+    return prefer_s1(g) && s1_mfma_supported(g, 2) && wgrad_s1_mfma_supported(g);
+}
+static size_t s1_bwd_workspace(const sv_conv_geom& g) { return s1_bwd_dz_bytes(g) + wgrad_s1_mfma_workspace(g); }
 
 }  // namespace sv
 
@@ -209,6 +226,7 @@ size_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_geom* g) {
     if (tiled_shape(*g)) {
         const size_t t = tiled_wgrad_workspace(g->N, g->H / g->up_h, g->W / g->up_w, g->Cin, g->Cout, g->KH, g->up_h);
         if (t > need) need = t;
+        if (s1_bwd_ok(*g) && s1_bwd_workspace(*g) > need) need = s1_bwd_workspace(*g);
     }
     return need;
 }
@@ -243,6 +261,11 @@ int sv_conv2d_fused_supported(const sv_conv_geom* g, int pooled) {
            tiled_wgrad_supported(g->N, Hs, Ws, g->Cin, g->Cout, g->KH, g->up_h);
 }
 
+int sv_conv2d_s1_mfma_bwd(const sv_conv_geom* g) {
+    if (validate_geom(g, "sv_conv2d_s1_mfma_bwd") || !tiled_shape(*g)) return 0;
+    return s1_bwd_ok(*g) ? 1 : 0;
+}
+
 int sv_conv2d_pool_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y_pooled,
                        uint8_t* idx, int act, float alpha, int dtype, sv_stream_t stream) {
     SV_F32_ONLY(dtype, "sv_conv2d_pool_fwd");
@@ -273,6 +296,22 @@ int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const voi
     SV_REQUIRE(dw == nullptr || x != nullptr, "sv_conv2d_bwd: the kernel gradient needs x");
     const int pooled = idx != nullptr;
     SV_REQUIRE(sv_conv2d_fused_supported(g, pooled), "sv_conv2d_bwd: shape is outside the fused family");
+    if (s1_bwd_ok(*g) && workspace != nullptr && workspace_bytes >= s1_bwd_workspace(*g) &&
+        (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+        float* dz = (float*)workspace;
+        rc = launch_form_dz((const float*)dy, (const float*)y, idx, dz, g->N, g->H, g->W, g->Cout, act, alpha, to_stream(stream));
+        if (rc) return rc;
+        if (dx != nullptr) {
+            rc = launch_s1_dgrad(*g, dz, (const float*)w, (float*)dx, to_stream(stream));
+            if (rc) return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: input gradient not covered") : rc;
+        }
+        if (dw != nullptr) {
+            rc = launch_wgrad_s1_mfma(*g, (const float*)x, dz, (float*)dw, (float*)db, 1, (char*)workspace + s1_bwd_dz_bytes(*g),
+                                      workspace_bytes - s1_bwd_dz_bytes(*g), to_stream(stream));
+            if (rc) return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: kernel gradient not covered") : rc;
+        }
+        return SV_OK;
+    }
     const int zmode = pooled ? 2 : 1;
     if (dw != nullptr) {
         rc = launch_tiled_wgrad((const float*)x, (const float*)dy, (float*)dw, (float*)db, 1, workspace,

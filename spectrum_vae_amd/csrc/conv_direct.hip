@@ -291,6 +291,13 @@ int deferred_flush(hipStream_t st, bool launch) {
     return SV_OK;
 }
 
+// dst (+)= the fixed-order sum of `slabs` rows of n floats at part: queued when a deferred bracket is open, else launched
+int launch_slab_sum(const float* part, float* dst, int64_t n, int slabs, int accumulate, hipStream_t st) {
+    if (defer_reduce(part, dst, n, slabs, accumulate)) return SV_OK;
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)ceil_div(n, 64)), dim3(1024), 0, st, part, dst, n, slabs, accumulate);
+    return check_launch("wgrad_reduce");
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int validate_geom(const sv_conv_geom* g, const char* who) {
     if (g == nullptr) return fail(SV_E_INVALID, "%s: null geometry", who);

@@ -493,6 +493,16 @@ class _ConvBase(Layer):
         if self.fused_bwd and ctx.param_grads and not ctx.lp:
             dx = ctx.buf(self, "dx", tuple(x.shape)) if need_dx else None
             db = self.bias.grad if self.bias is not None else None
+            s1 = self.__dict__.setdefault("_s1_bwd", {})  # per batch size
+            if n not in s1:
+                s1[n] = ops.conv2d_s1_mfma_bwd(g)
+            if s1[n] and not ctx.side:
+                # 16..128-channel layers: one call forms dz once and runs both gradients on the matrix cores; the
+                # workspace (dz + the kernel gradient's partial sums) is this layer's own until the deferred sums ran
+                ws = ctx.buf(self, "wgrad_ws", (max(ops.conv2d_wgrad_workspace(g), 16),), torch.uint8)
+                ops.conv2d_bwd(g, x, self.kernel.data, dy, y, s.get("idx"), dx, self.kernel.grad, db, self.act, self.alpha,
+                               ws)
+                return dx
             if ctx.wgrad_jobs is not None and not ctx.side:
                 ws = ctx.buf(self, "wgrad_ws", (max(ops.conv2d_wgrad_workspace(g), 16),), torch.uint8)
                 if self.kernel_size == (3, 3):

@@ -180,6 +180,12 @@ def conv2d_fused_supported(g: ConvGeom, pooled: bool) -> bool:
     return bool(lib.sv_conv2d_fused_supported(C.byref(g), int(pooled)))
 
 
+def conv2d_s1_mfma_bwd(g: ConvGeom) -> bool:
+    """Whether ``conv2d_bwd`` takes this geometry through the matrix-core kernels of the 16..128-channel family (then
+    dx and dw are best asked for in one call)."""
+    return bool(lib.sv_conv2d_s1_mfma_bwd(C.byref(g)))
+
+
 def conv2d_pool_fwd(g: ConvGeom, x, w, bias, y_pooled, idx, act: str, alpha: float):
     check(lib.sv_conv2d_pool_fwd(C.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y_pooled), _ptr(idx, torch.uint8),
                                  ACT[act], alpha, F32, _stream()), "sv_conv2d_pool_fwd")

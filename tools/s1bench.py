@@ -77,6 +77,30 @@ def main():
                 d = float((res[0][1] - res[1][1]).abs().max() / res[0][1].abs().max())
                 same_idx = "" if not pooled else f" idx_diff={int((res[0][2] != res[1][2]).sum())}"
                 print(f"{row} {'pool' if pooled else 'fwd '} {res[0][0]:8.1f} | {res[1][0]:8.1f} ({fl / res[1][0] / 1e-6 / PEAK:.3f}) | {d:.2e}{same_idx}")
+            # whole backward of the layer: dz formed from (dy, y[, idx]), input + kernel + bias gradients
+            for pooled in (False, True):
+                if pooled and (up == 2 or cout % 4):
+                    continue
+                oh, ow = (h // 2, w_ // 2) if pooled else (h, w_)
+                yb = torch.randn(n, oh, ow, cout, device="cuda")
+                dyb = torch.randn(n, oh, ow, cout, device="cuda")
+                idxb = torch.randint(0, 4, (n, oh, ow, cout), dtype=torch.uint8, device="cuda") if pooled else None
+                if not ops.conv2d_fused_supported(g, pooled):
+                    continue
+                res = {}
+                for o in (0, 1):
+                    with ops.option("s1_mfma", o):
+                        ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device="cuda")
+                        dx = torch.zeros(n, h // up, w_ // up, cin, device="cuda")
+                        dw, db = torch.zeros_like(wt), torch.zeros(cout, device="cuda")
+
+                        def f():
+                            dw.zero_(), db.zero_()
+                            ops.conv2d_bwd(g, x, wt, dyb, yb, idxb, dx, dw, db, "elu", 1.0, ws)
+                        t = timed(f)
+                        res[o] = (t, dx.clone(), dw.clone(), db.clone())
+                d = max(float((res[0][i] - res[1][i]).abs().max() / res[0][i].abs().max()) for i in (1, 2, 3))
+                print(f"{row} {'bwdp' if pooled else 'bwd '} {res[0][0]:8.1f} | {res[1][0]:8.1f} ({2 * fl / res[1][0] / 1e-6 / PEAK:.3f}) | {d:.2e}")
             # input gradient from an explicit dz
             dz = torch.randn(n, h, w_, cout, device="cuda")
             res = {}
