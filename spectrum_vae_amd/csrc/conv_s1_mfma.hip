@@ -8,10 +8,14 @@
 // x 4 reduction channels), 16 pixels (a 2x8 or 4x4 patch holding whole pooling windows) the B operand columns.
 //
 // A workgroup (4 waves) carries `nu` units (a sample, or a band of rows of a large image) per pass:
-//  * the input of the pass sits in LDS as planes of 16 channels, [plane][unit][row][col][16], WITHOUT a halo: a lane
-//    whose tap falls outside the image reads a zero pixel instead (one select per tap and pixel tile, amortised over
-//    the channel groups), so a 4x4 image with 128 channels costs 8 KB, not the 32 KB a 5x5 halo would make of it; an
-//    upsampled input (UpSampling2D folded into the conv) is replicated while it is written to LDS;
+//  * the input of the pass sits in LDS as planes of 16 channels, [plane][unit][row][col][16], in one of two layouts.
+//    HALO: every row is followed by `pad` zero pixels (which are also the next row's left margin) and every unit by
+//    `pad` zero rows (the next unit's top margin), so a tap's operand address is the pixel's address plus ONE
+//    wave-uniform offset and the loop over the taps has no per-lane arithmetic and no branches (1.2 - 2.3x the image).
+//    Without it (deep layers, where four 4x4 x 128-channel samples must share the LDS with the filter chunks): no
+//    margins at all, a lane whose tap falls outside the image reads a zero pixel instead (one select per tap and pixel
+//    tile, amortised over the channel groups).  An upsampled input (UpSampling2D folded into the conv) is replicated
+//    while it is written to LDS;
 //  * a lane's B operand for 4 MFMAs is ONE 16-byte read (4 consecutive channels of its pixel); the row pitch carries a
 //    32-byte skew so that the 16-lane groups of a ds_read_b128 over a 2x8 / 4x4 patch hit distinct banks;
 //  * the filters stream through LDS in chunks [tap][16 reduction channels][result channel][16], double buffered, the
@@ -21,6 +25,7 @@
 //    result channels beyond 64);
 //  * results leave from the accumulators: a lane holds 4 consecutive channels of a pixel = one 16-byte NHWC store; the
 //    pooling maximum / argmax and the 2x2 sum of an upsampled layer's input gradient are two cross-lane steps.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -45,11 +50,20 @@ struct S1Args {
     int WR_log;                 // log2(waves along the result-channel tiles)
     int TW_log;                 // 3: 2x8 pixel tiles, 2: 4x4
     int tpu_log;                // log2(tiles per unit)
-    int rows_lds, pitch, plane; // window rows per unit; floats per row; floats per plane (16 zero floats first)
+    int rows_lds, pitch, plane; // window rows per unit; floats per row; floats per plane
+    int halo, prefix, ustride, row0;  // zero-padded layout; floats before the first row; rows per unit; first unit's row
     int w_floats, resident, steps, gsteps;  // floats per filter buffer; all filters in one chunk; chunks per pass; G / GC
     int srows_max, ppu, pmax;   // stored rows of a full window; staging pieces per unit (max) and per thread
     FDiv f_ppu, f_k;
+    int dbg;  // diagnostic build only (S1_DBG): 1 skip the matrix-core loop, 2 skip the staging, 4 skip the result stores
 };
+
+// Ablation switches exist in the diagnostic build (make TRACE=1) only: they make the results invalid.
+#ifdef SV_TRACE
+#define S1_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define S1_DBG(a, bit) 0
+#endif
 
 constexpr int kS1PMax = 12;  // 16-byte staging pieces per thread and pass
 constexpr int kS1PChunk = 6; // ... of which this many are in registers between their load and their LDS store
@@ -64,7 +78,7 @@ __device__ __forceinline__ float s1_dpp_ror8(float v) {  // lane ^ 8 inside a ro
 __device__ __forceinline__ int s1_dpp_xor1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
 __device__ __forceinline__ int s1_dpp_ror8_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); }
 
-template <int TI, int TJ, int VEC>
+template <int TI, int TJ, int VEC, bool HALO>
 __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
     constexpr int CPG = 4 * VEC;  // floats per pixel and plane
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
             if (VEC == 1) { pi = e / 3; ch = e - 3 * pi; }
             else { pi = e / a.RI; ch = e - pi * a.RI; }
             const int srow = sa + (pi >> ws_log), scol = pi & (a.Ws - 1);
-            float* dst = img + (VEC == 4 ? (ch >> 4) * plane + (ch & 15) : ch) + 16 + ul * rows_lds * pitch;
+            float* dst = img + (VEC == 4 ? (ch >> 4) * plane + (ch & 15) : ch) + a.prefix + (ul * a.ustride + a.row0) * pitch;
             if (a.up == 1) {
                 float* d = dst + (srow - wy0) * pitch + scol * CPG;
                 if (VEC == 1) d[0] = rv[ii].x;
@@ -154,6 +168,12 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
     constexpr int QN_log = VEC == 4 ? 2 : (VEC == 2 ? 1 : 0);  // log2(16-byte pieces per result channel and group)
     const int gc_log = a.GC == 2 ? 1 : 0;
     const int KK = K * K;
+    // Place (in 16-byte pieces) of reduction channels 4 qq .. 4 qq + 3 of result channel ro in block blk = (tap, group) of
+    // a chunk.  With 16-channel groups a 16 x 16 block is stored [qq][result channel][4], so that the A-operand read of a
+    // wave - lane (li, lk) takes piece (qq = lk, ro = li) - walks 1 KB in lane order: no bank conflicts.
+    auto w_at = [&](int blk, int ro, int qq) {
+        return VEC == 4 ? ((blk * (ROp >> 4) + (ro >> 4)) * 4 + qq) * 16 + (ro & 15) : (blk * ROp + ro) * (1 << QN_log) + qq;
+    };
     // Piece p of the chunk starting at (tap0, g0): 4 consecutive reduction channels of one result channel.  The thread ->
     // piece map follows the filters' memory order (forward: result channels are contiguous in HWIO, lanes walk them;
     // input gradient: the reduction channels are, one 16-byte load per piece); `dst` is the piece's place in the chunk.
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
             gc = r2 & (a.GC - 1);
             tc = r2 >> gc_log;
         }
-        dst = (((tc << gc_log) + gc) * ROp + ro) * (1 << QN_log) + qq;
+        dst = w_at((tc << gc_log) + gc, ro, qq);
         const int tap = tap0 + tc;
         const int ri0 = (g0 + gc) * 16 + 4 * qq;
         if (a.dgrad && (a.RI & 3) == 0) {
@@ -212,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
                 const int p = 4 * t + e;
                 const int qq = p & 3, r1 = p >> 2, gc = r1 & (a.GC - 1), ro = (r1 >> gc_log) & (ROp - 1);
                 gofs[e] = ((KK - 1) * a.RO + ro) * a.RI + gc * 16 + 4 * qq;  // tap 0 reads the last filter tap
-                ldst[e] = (gc * ROp + ro) * 4 + qq;
+                ldst[e] = w_at(gc, ro, qq);
                 if (ro >= a.RO) { gofs[e] = -1; }
             }
         } else {
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 gofs[e] = (gc * 16 + 4 * riq + e) * a.RO + 4 * ro4;              // load e: reduction channel 4 riq + e
-                ldst[e] = (gc * ROp + 4 * ro4 + e) * 4 + riq;                   // store e: result channel 4 ro4 + e
+                ldst[e] = w_at(gc, 4 * ro4 + e, riq);                            // store e: result channel 4 ro4 + e
                 if (4 * ro4 >= a.RO) gofs[e] = -1;
             }
         }
@@ -247,9 +267,33 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
         }
     };
 
-    // ---- one-time set-up: zero pixels, resident filters, bias
-    for (int g = 0; g < a.G; ++g)
-        if (threadIdx.x < 16) img[g * plane + threadIdx.x] = 0.f;
+    // HALO, banded units: the window rows that lie outside the image (top of the first band, bottom of the last) hold
+    // another band's data from the previous pass: zeros again
+    auto zero_outside = [&](int u0) {
+        const int nu = min(a.nu, a.units - u0);
+        const int rowf = W * CPG;
+        for (int ul = 0; ul < nu; ++ul) {
+            const int r0 = ((u0 + ul) & nb_mask) * a.BR, wy0 = r0 - pad;
+            const int top = max(0, -wy0), bot = max(0, wy0 + rows_lds - H);  // rows above / below the image
+            if (top + bot == 0) continue;
+            const int total = a.G * (top + bot) * rowf;
+            for (int i = threadIdx.x; i < total; i += 256) {
+                const int g = i / ((top + bot) * rowf), r = i - g * (top + bot) * rowf;
+                const int row = r / rowf, c = r - row * rowf;
+                const int lr = row < top ? row : rows_lds - bot + (row - top);
+                img[g * plane + a.prefix + (ul * a.ustride + a.row0 + lr) * pitch + c] = 0.f;
+            }
+        }
+    };
+
+    // ---- one-time set-up: zero pixels / margins, resident filters, bias
+    if (HALO) {
+        const int total = (a.G * plane) >> 2;
+        for (int i = threadIdx.x; i < total; i += 256) reinterpret_cast<float4*>(img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int g = 0; g < a.G; ++g)
+            if (threadIdx.x < 16) img[g * plane + threadIdx.x] = 0.f;
+    }
     if (a.resident) {
         float4* d = reinterpret_cast<float4*>(wl);
         for (int p = threadIdx.x; p < w_pieces; p += 256) {
@@ -259,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
             d[at] = v;
         }
     }
-    if (VEC != 4) {  // the padding channels of every pixel stay zero: clear the image once
+    if (VEC != 4 && !HALO) {  // the padding channels of every pixel stay zero: clear the image once
         const int total = plane;
         for (int i = threadIdx.x; i < total; i += 256) img[i] = 0.f;
     }
@@ -280,12 +324,15 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
         const int nu = min(a.nu, a.units - u0);
         // The pass's input: global -> registers -> LDS in one go.  (Holding the next pass's pieces in registers across
         // the arithmetic costs 48 registers and spills; the second workgroup of the CU covers this round trip.)
-        load_img(u0, 0);
+        if (!S1_DBG(a, 2)) load_img(u0, 0);
         __syncthreads();  // the previous pass's operand reads are done
-        store_img(u0, 0);
-        for (int i0 = kS1PChunk; i0 < a.pmax; i0 += kS1PChunk) {
-            load_img(u0, i0);
-            store_img(u0, i0);
+        if (!S1_DBG(a, 2)) {
+            store_img(u0, 0);
+            for (int i0 = kS1PChunk; i0 < a.pmax; i0 += kS1PChunk) {
+                load_img(u0, i0);
+                store_img(u0, i0);
+            }
+            if (HALO && banded) zero_outside(u0);
         }
         if (first && !a.resident) store_w(0);
         first = false;
@@ -307,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
             pix_n[j] = u >> a.nb_log;
             pix_y[j] = r0 + ((t >> txl) << TH_log) + ty;
             pix_x[j] = ((t & ((1 << txl) - 1)) << TW_log) + tx;
-            base[j] = 16 + (ul * rows_lds + pix_y[j] - wy0) * pitch + pix_x[j] * CPG + lk * VEC;
+            base[j] = a.prefix + (ul * a.ustride + a.row0 + pix_y[j] - wy0) * pitch + pix_x[j] * CPG + lk * VEC;
         }
         s1_v4f acc[TI][TJ];
 #pragma unroll
@@ -315,11 +362,12 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j) acc[ti][j] = s1_v4f{0.f, 0.f, 0.f, 0.f};
 
-        for (int s = 0; s < a.steps; ++s) {
+        for (int s = 0; s < (S1_DBG(a, 1) ? 0 : a.steps); ++s) {
             if (!a.resident) load_w(s + 1 < a.steps ? s + 1 : 0);  // the next chunk (of the next pass after the last step)
             const int tap0 = a.resident ? 0 : (s / a.gsteps) * a.TC;
             const int g0 = a.resident ? 0 : (s - (s / a.gsteps) * a.gsteps) * a.GC;
-            const float* wb = wl + (a.resident ? 0 : wbuf * a.w_floats) + ((wr * TI) * 16 + li) * CPG + lk * VEC;
+            const float* wb = wl + (a.resident ? 0 : wbuf * a.w_floats) +
+                              (VEC == 4 ? ((wr * TI) * 4 + lk) * 64 + li * 4 : ((wr * TI) * 16 + li) * CPG + lk * VEC);
             // iteration it = (tap tc, group gc) of the chunk; the operand reads of iteration it + 1 are issued before the
             // matrix instructions of iteration it (two register sets)
             const int n_it = a.TC * a.GC;
@@ -327,7 +375,13 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
             int boff[TJ];
             auto read_ops = [&](int it, float (&av)[TI][VEC], float (&bv)[TJ][VEC]) {
                 const int tc = it >> gcl, gc = it & (a.GC - 1);
-                if (gc == 0) {  // a new tap: where each pixel tile's lane reads (the zero pixel outside the image)
+                const float* ap = wb + it * ROp * CPG;
+                const float* bp = img + (g0 + gc) * plane;
+                if (HALO) {  // the tap is one wave-uniform offset: margins hold the zeros
+                    const int tap = tap0 + tc;
+                    const int kh = fd(tap, a.f_k), kw = tap - kh * K;
+                    bp += (kh - pad) * pitch + (kw - pad) * CPG;
+                } else if (gc == 0) {  // a new tap: where each pixel tile's lane reads (the zero pixel outside the image)
                     const int tap = tap0 + tc;
                     const int kh = fd(tap, a.f_k), kw = tap - kh * K;
                     const int dy = kh - pad, dx = kw - pad;
@@ -337,12 +391,10 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
                         boff[j] = ok ? base[j] + dy * pitch + dx * CPG : lk * VEC;
                     }
                 }
-                const float* ap = wb + it * ROp * CPG;
-                const float* bp = img + (g0 + gc) * plane;
 #pragma unroll
                 for (int ti = 0; ti < TI; ++ti) {
                     if (VEC == 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(ap + ti * 16 * CPG);
+                        const float4 v = *reinterpret_cast<const float4*>(ap + ti * 256);
                         av[ti][0] = v.x; av[ti][1 % VEC] = v.y; av[ti][2 % VEC] = v.z; av[ti][3 % VEC] = v.w;
                     } else if (VEC == 2) {
                         const float2 v = *reinterpret_cast<const float2*>(ap + ti * 16 * CPG);
@@ -354,13 +406,13 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     if (VEC == 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(bp + boff[j]);
+                        const float4 v = *reinterpret_cast<const float4*>(bp + (HALO ? base[j] : boff[j]));
                         bv[j][0] = v.x; bv[j][1 % VEC] = v.y; bv[j][2 % VEC] = v.z; bv[j][3 % VEC] = v.w;
                     } else if (VEC == 2) {
-                        const float2 v = *reinterpret_cast<const float2*>(bp + boff[j]);
+                        const float2 v = *reinterpret_cast<const float2*>(bp + (HALO ? base[j] : boff[j]));
                         bv[j][0] = v.x; bv[j][1 % VEC] = v.y;
                     } else {
-                        bv[j][0] = bp[boff[j]];
+                        bv[j][0] = bp[HALO ? base[j] : boff[j]];
                     }
                 }
             };
@@ -374,16 +426,28 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
                             acc[ti][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti][e], bv[j][e], acc[ti][j], 0, 0, 0);
             };
             float av0[TI][VEC], bv0[TJ][VEC], av1[TI][VEC], bv1[TJ][VEC];
+            // the loop body has no branch (HALO), so the wait before a set's matrix instructions counts only that set's
+            // reads and the other set's stay in flight; the last one or two iterations run behind the loop
             read_ops(0, av0, bv0);
-            for (int it = 0; it < n_it; it += 2) {
-                if (it + 1 < n_it) read_ops(it + 1, av1, bv1);
+            int it = 0;
+            for (; it + 2 < n_it; it += 2) {
+                read_ops(it + 1, av1, bv1);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_ops(av0, bv0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (it + 2 < n_it) read_ops(it + 2, av0, bv0);
+                read_ops(it + 2, av0, bv0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (it + 1 < n_it) mfma_ops(av1, bv1);
+                mfma_ops(av1, bv1);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it + 2 == n_it) {
+                read_ops(it + 1, av1, bv1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_ops(av0, bv0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_ops(av1, bv1);
+            } else {
+                mfma_ops(av0, bv0);
             }
             if (!a.resident) {
                 store_w(wbuf ^ 1);  // last read one step ago; every wave has passed that step's barrier
@@ -434,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void s1_mfma_k(S1Args a) {
                         v[r] += TW_log == 3 ? s1_dpp_ror8(v[r]) : __shfl_xor(v[r], 4, 64);
                     }
                 }
-                if (!live[j] || ro0 >= a.RO || (a.epi && !corner)) continue;
+                if (!live[j] || ro0 >= a.RO || (a.epi && !corner) || S1_DBG(a, 4)) continue;
                 const int oy = a.epi ? pix_y[j] >> 1 : pix_y[j], ox = a.epi ? pix_x[j] >> 1 : pix_x[j];
                 const size_t at = (((size_t)pix_n[j] * Ho + oy) * Wo + ox) * a.RO + ro0;
                 if ((a.RO & 3) == 0) {
@@ -502,16 +566,25 @@ static S1Plan plan_s1(int N, int H, int W, int RI, int RO, int K, int up, int ep
         }
         if (nu > N * nb) nu = N * nb;  // fewer units than a pass holds: the spare tiles idle
         const int rows_lds = nb > 1 ? BR + 2 * pad : H;
-        const int pitch = W * cpg + 8;
-        const int plane = (16 + nu * rows_lds * pitch + 3) & ~3;
         const int rop = 16 * ti * wr;
         const size_t w_all = (size_t)K * K * G * rop * cpg * sizeof(float);
         const int resident = w_all <= 36 * 1024;
         const int GC = resident ? G : (G >= 2 ? 2 : 1), TC = resident ? K * K : 1;
         const int w_floats = TC * GC * rop * cpg;
         if (!resident && w_floats / 4 > 256 * kS1WMax) continue;
-        const size_t lds = ((size_t)G * plane + (size_t)(resident ? 1 : 2) * w_floats) * sizeof(float);
-        if (lds > kS1LdsBudget) continue;
+        // the zero-padded layout where it fits (16-channel groups only), else the bare one
+        int halo = vec == 4 ? 1 : 0, pitch = 0, plane = 0, prefix = 0, ustride = 0, row0 = 0;
+        size_t lds = 0;
+        for (; halo >= 0; --halo) {
+            pitch = (W + (halo ? pad : 0)) * cpg + 8;
+            prefix = halo ? (pad * cpg > 16 ? pad * cpg : 16) : 16;
+            ustride = halo && nb == 1 ? H + pad : rows_lds;
+            row0 = halo && nb == 1 ? pad : 0;
+            plane = (prefix + (nu * ustride + row0) * pitch + 3) & ~3;
+            lds = ((size_t)G * plane + (size_t)(resident ? 1 : 2) * w_floats) * sizeof(float);
+            if (lds <= kS1LdsBudget) break;
+        }
+        if (halo < 0) continue;
         const int srows_max = up == 1 ? rows_lds : rows_lds / 2 + 1;
         const int ppu = vec == 1 ? srows_max * (W / up) * RI : srows_max * (W / up) * RI / 4;
         const int pmax = (nu * ppu + 255) / 256;
@@ -522,6 +595,7 @@ static S1Plan plan_s1(int N, int H, int W, int RI, int RO, int K, int up, int ep
         a.BR = BR; a.nb_log = __builtin_ctz((unsigned)nb); a.nu = nu; a.units = N * nb;
         a.WR_log = wr == 2 ? 1 : 0; a.TW_log = tw_log; a.tpu_log = __builtin_ctz((unsigned)(BR * W / 16));
         a.rows_lds = rows_lds; a.pitch = pitch; a.plane = plane;
+        a.halo = halo; a.prefix = prefix; a.ustride = ustride; a.row0 = row0;
         a.w_floats = w_floats; a.resident = resident; a.gsteps = G / GC; a.steps = resident ? 1 : K * K * (G / GC);
         a.srows_max = srows_max; a.ppu = ppu; a.pmax = pmax;
         a.f_ppu = fd_make(ppu); a.f_k = fd_make(K);
@@ -534,25 +608,33 @@ static S1Plan plan_s1(int N, int H, int W, int RI, int RO, int K, int up, int ep
     return p;
 }
 
-template <int TI, int TJ, int VEC>
+template <int TI, int TJ, int VEC, bool HALO>
 static int s1_launch(const S1Plan& p, hipStream_t st) {
     static bool raised = false;  // dynamic LDS beyond 64 KB needs the opt-in once per kernel
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&s1_mfma_k<TI, TJ, VEC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&s1_mfma_k<TI, TJ, VEC, HALO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS1LdsBudget);
         if (e != hipSuccess) return fail(SV_E_LAUNCH, "s1_mfma: raising the LDS limit failed: %s", hipGetErrorString(e));
         raised = true;
     }
-    hipLaunchKernelGGL((s1_mfma_k<TI, TJ, VEC>), dim3((unsigned)p.grid), dim3(256), p.lds, st, p.a);
+    hipLaunchKernelGGL((s1_mfma_k<TI, TJ, VEC, HALO>), dim3((unsigned)p.grid), dim3(256), p.lds, st, p.a);
     return check_launch("s1_mfma");
 }
 
-static int s1_dispatch(const S1Plan& p, hipStream_t st) {
-    if (p.vec == 1) return p.tj == 8 ? s1_launch<1, 8, 1>(p, st) : s1_launch<1, 4, 1>(p, st);
-    if (p.vec == 2) return p.tj == 8 ? s1_launch<1, 8, 2>(p, st) : s1_launch<1, 4, 2>(p, st);
-    if (p.ti == 1) return p.tj == 8 ? s1_launch<1, 8, 4>(p, st) : s1_launch<1, 4, 4>(p, st);
-    if (p.ti == 2) return p.tj == 4 ? s1_launch<2, 4, 4>(p, st) : s1_launch<2, 2, 4>(p, st);
-    return p.tj == 2 ? s1_launch<4, 2, 4>(p, st) : s1_launch<4, 1, 4>(p, st);
+static int s1_dispatch(S1Plan& p, hipStream_t st) {
+#ifdef SV_TRACE
+    if (const char* e = getenv("SPECTRUM_S1_DBG")) p.a.dbg = atoi(e);
+#endif
+    if (p.vec == 1) return p.tj == 8 ? s1_launch<1, 8, 1, false>(p, st) : s1_launch<1, 4, 1, false>(p, st);
+    if (p.vec == 2) return p.tj == 8 ? s1_launch<1, 8, 2, false>(p, st) : s1_launch<1, 4, 2, false>(p, st);
+    if (p.a.halo) {
+        if (p.ti == 1) return p.tj == 8 ? s1_launch<1, 8, 4, true>(p, st) : s1_launch<1, 4, 4, true>(p, st);
+        if (p.ti == 2) return p.tj == 4 ? s1_launch<2, 4, 4, true>(p, st) : s1_launch<2, 2, 4, true>(p, st);
+        return p.tj == 2 ? s1_launch<4, 2, 4, true>(p, st) : s1_launch<4, 1, 4, true>(p, st);
+    }
+    if (p.ti == 1) return p.tj == 8 ? s1_launch<1, 8, 4, false>(p, st) : s1_launch<1, 4, 4, false>(p, st);
+    if (p.ti == 2) return p.tj == 4 ? s1_launch<2, 4, 4, false>(p, st) : s1_launch<2, 2, 4, false>(p, st);
+    return p.tj == 2 ? s1_launch<4, 2, 4, false>(p, st) : s1_launch<4, 1, 4, false>(p, st);
 }
 
 static bool s1_geom(const sv_conv_geom& g) {

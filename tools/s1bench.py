@@ -39,12 +39,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", default="3,5")
+    ap.add_argument("--shapes", default="", help="cin,cout,w,up[;cin,cout,w,up...]: only these shapes")
+    ap.add_argument("--only-s1", action="store_true", help="run the matrix-core kernels only (profiling)")
     a = ap.parse_args()
+    shapes = [tuple(int(v) for v in t.split(",")) for t in a.shapes.split(";") if t] or SHAPES
+    variants = (1, 1) if a.only_s1 else (0, 1)
     n = a.batch
     torch.manual_seed(1)
     print(f"# batch {n}; us per call: planar | s1_mfma (fraction of the {PEAK / 1e12:.1f} TF f32 peak) | max rel diff")
     for k in (int(v) for v in a.k.split(",")):
-        for cin, cout, w_, up in SHAPES:
+        for cin, cout, w_, up in shapes:
             h = w_
             g = ops.conv_geom(n, h, w_, cin, k, k, 1, 1, "same", cout, (up, up))
             x = torch.randn(n, h // up, w_ // up, cin, device="cuda")
@@ -57,7 +61,7 @@ def main():
                 if pooled and (up == 2 or cout % 4):
                     continue
                 res = {}
-                for o in (0, 1):
+                for o in variants:
                     with ops.option("s1_mfma", o):
                         if pooled:
                             y = torch.zeros(n, h // 2, w_ // 2, cout, device="cuda")
@@ -74,6 +78,7 @@ def main():
                         res[o] = (t, y.clone(), None if idx is None else idx.clone())
                 if res is None:
                     continue
+                res.setdefault(0, res[1])
                 d = float((res[0][1] - res[1][1]).abs().max() / res[0][1].abs().max())
                 same_idx = "" if not pooled else f" idx_diff={int((res[0][2] != res[1][2]).sum())}"
                 print(f"{row} {'pool' if pooled else 'fwd '} {res[0][0]:8.1f} | {res[1][0]:8.1f} ({fl / res[1][0] / 1e-6 / PEAK:.3f}) | {d:.2e}{same_idx}")
@@ -88,7 +93,7 @@ def main():
                 if not ops.conv2d_fused_supported(g, pooled):
                     continue
                 res = {}
-                for o in (0, 1):
+                for o in variants:
                     with ops.option("s1_mfma", o):
                         ws = torch.empty(max(ops.conv2d_wgrad_workspace(g), 16), dtype=torch.uint8, device="cuda")
                         dx = torch.zeros(n, h // up, w_ // up, cin, device="cuda")
@@ -99,16 +104,18 @@ def main():
                             ops.conv2d_bwd(g, x, wt, dyb, yb, idxb, dx, dw, db, "elu", 1.0, ws)
                         t = timed(f)
                         res[o] = (t, dx.clone(), dw.clone(), db.clone())
+                res.setdefault(0, res[1])
                 d = max(float((res[0][i] - res[1][i]).abs().max() / res[0][i].abs().max()) for i in (1, 2, 3))
                 print(f"{row} {'bwdp' if pooled else 'bwd '} {res[0][0]:8.1f} | {res[1][0]:8.1f} ({2 * fl / res[1][0] / 1e-6 / PEAK:.3f}) | {d:.2e}")
             # input gradient from an explicit dz
             dz = torch.randn(n, h, w_, cout, device="cuda")
             res = {}
-            for o in (0, 1):
+            for o in variants:
                 with ops.option("s1_mfma", o):
                     dx = torch.zeros(n, h // up, w_ // up, cin, device="cuda")
                     t = timed(lambda: ops.conv2d_dgrad(g, dz, wt, dx))
                     res[o] = (t, dx.clone())
+            res.setdefault(0, res[1])
             d = float((res[0][1] - res[1][1]).abs().max() / res[0][1].abs().max())
             print(f"{row} dgrad {res[0][0]:8.1f} | {res[1][0]:8.1f} ({fl / res[1][0] / 1e-6 / PEAK:.3f}) | {d:.2e}")
 
