@@ -319,6 +319,13 @@ int sv_dense_fwd(const void* x, const void* w, const void* bias, void* y, int M,
 int sv_dense_dgrad(const void* dz, const void* w, void* dx, int M, int K, int N, int dtype, sv_stream_t stream);
 int sv_dense_wgrad(const void* x, const void* dz, void* dw, int accumulate, int M, int K, int N, int dtype,
                    sv_stream_t stream);
+/* sv_dense_wgrad with scratch: the reduction over the batch is cut over about 256 workgroups (a Dense kernel gradient has
+ * few result tiles and M terms per element), partial sums go through `workspace` (sv_dense_wgrad_workspace_bytes; 0: the
+ * shape gains nothing) and are added in a fixed order.  workspace == NULL or too small is not an error: the call then
+ * runs as sv_dense_wgrad does. */
+size_t sv_dense_wgrad_workspace_bytes(int M, int K, int N);
+int sv_dense_wgrad_ws(const void* x, const void* dz, void* dw, int accumulate, int M, int K, int N, void* workspace,
+                      size_t workspace_bytes, int dtype, sv_stream_t stream);
 
 /* ---- Dropout (autoencoder.py:108,177,223,331): inverted dropout with a counter-based generator;
  *      element i is kept iff hash(seed, offset + i) >= rate. */

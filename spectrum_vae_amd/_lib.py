@@ -115,6 +115,8 @@ SIGNATURES = {
     "sv_dense_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "sv_dense_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "sv_dense_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "sv_dense_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sv_dense_wgrad_ws": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _p]),
     "sv_dropout_fwd": (_i, [_p, _p, _i64, _f, _u64, _u64, _i, _p]),
     "sv_dropout_bwd": (_i, [_p, _p, _i64, _f, _u64, _u64, _i, _p]),
     "sv_reduce_sum_h_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

@@ -374,10 +374,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void gemm_k(const float* __restrict__ a, int64_t am, int64_t ak,
                                                const float* __restrict__ b, int64_t bk, int64_t bn,
                                                const float* __restrict__ bias, float* __restrict__ c, int M, int N,
-                                               int K, int act, float alpha, int accumulate) {
+                                               int K, int act, float alpha, int accumulate, int k_per_split) {
     __shared__ float As[16][64 + 4];
     __shared__ float Bs[16][64 + 4];
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    // blockIdx.z > 0 only with a cut reduction: this workgroup sums k in [kbeg, kend) and stores raw sums into slab z
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    const bool slab = gridDim.z > 1;
     // 4 waves as 2 x 2, each 32 x 32 of the tile = 2 x 2 matrix-core tiles of 16 x 16 (k step 4)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -387,33 +390,35 @@ __global__ __launch_bounds__(256) void gemm_k(const float* __restrict__ a, int64
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        // 1024 elements per tile, 4 per thread; make the unit-stride dimension the fastest-varying one
+    // 1024 elements per tile and operand, 4 per thread; the unit-stride dimension is the fastest-varying one.  The
+    // loads of step k0 + 16 are in flight while step k0 is multiplied (register prefetch).
+    float ra[4], rb[4];
+    auto load = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int id = threadIdx.x + e * 256;
-            int mm, kk;
-            if (ak == 1) {
-                kk = id & 15;
-                mm = id >> 4;
-            } else {
-                mm = id & 63;
-                kk = id >> 6;
-            }
+            const int mm = ak == 1 ? id >> 4 : id & 63, kk = ak == 1 ? id & 15 : id >> 6;
             const int gm = m0 + mm, gk = k0 + kk;
-            As[kk][mm] = (gm < M && gk < K) ? a[gm * am + gk * ak] : 0.f;
-            int nn, k2;
-            if (bk == 1) {
-                k2 = id & 15;
-                nn = id >> 4;
-            } else {
-                nn = id & 63;
-                k2 = id >> 6;
-            }
+            ra[e] = (gm < M && gk < kend) ? a[gm * am + gk * ak] : 0.f;
+            const int nn = bk == 1 ? id >> 4 : id & 63, k2 = bk == 1 ? id & 15 : id >> 6;
             const int gn = n0 + nn, gk2 = k0 + k2;
-            Bs[k2][nn] = (gn < N && gk2 < K) ? b[gk2 * bk + gn * bn] : 0.f;
+            rb[e] = (gn < N && gk2 < kend) ? b[gk2 * bk + gn * bn] : 0.f;
         }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int id = threadIdx.x + e * 256;
+            As[ak == 1 ? id & 15 : id >> 6][ak == 1 ? id >> 4 : id & 63] = ra[e];
+            Bs[bk == 1 ? id & 15 : id >> 6][bk == 1 ? id >> 4 : id & 63] = rb[e];
+        }
+    };
+    if (kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        __syncthreads();  // the previous step's operand reads are done
+        store();
         __syncthreads();
+        if (k0 + 16 < kend) load(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             float av[2], bv[2];
@@ -426,23 +431,27 @@ __global__ __launch_bounds__(256) void gemm_k(const float* __restrict__ a, int64
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
     // lane (li, lk) holds rows 4 lk .. 4 lk + 3, column li of each 16 x 16 tile
+    float* out = slab ? c + (size_t)blockIdx.z * M * N : c;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + wn + 16 * j + li;
             if (gn >= N) continue;
-            const float bb = bias != nullptr ? bias[gn] : 0.f;
+            const float bb = (!slab && bias != nullptr) ? bias[gn] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm + 16 * i + 4 * lk + r;
                 if (gm >= M) continue;
-                const float v = act_apply(acc[i][j][r] + bb, act, alpha);
-                float* cp = c + (int64_t)gm * N + gn;
-                *cp = accumulate ? *cp + v : v;
+                float* cp = out + (int64_t)gm * N + gn;
+                if (slab) {
+                    *cp = acc[i][j][r];
+                } else {
+                    const float v = act_apply(acc[i][j][r] + bb, act, alpha);
+                    *cp = accumulate ? *cp + v : v;
+                }
             }
         }
 }
@@ -451,9 +460,20 @@ int launch_gemm(const float* a, int64_t am, int64_t ak, const float* b, int64_t 
                 float* c, int M, int N, int K, int act, float alpha, int accumulate, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64));
     hipLaunchKernelGGL(gemm_k, grid, dim3(256), 0, st, a, am, ak, b, bk, bn, bias, c, M, N, K, act, alpha,
-                       accumulate);
+                       accumulate, K);
     return check_launch("gemm");
 }
+
+// How many ways the reduction of a GEMM with a small result is cut: about 256 workgroups, at least 32 terms each.
+static int gemm_splits(int M, int N, int K) {
+    const int64_t tiles = ceil_div(M, 64) * ceil_div(N, 64);
+    int64_t s = ceil_div(256, tiles);
+    const int64_t maxs = K / 32;
+    if (s > maxs) s = maxs;
+    return s < 2 ? 1 : (int)s;
+}
+
+int launch_slab_sum(const float* part, float* dst, int64_t n, int slabs, int accumulate, hipStream_t st);  // conv_direct.hip
 
 // ------------------------------------------------------------------------------------------------ Sampling + KL
 __global__ __launch_bounds__(256) void reparam_fwd_k(const float* __restrict__ mean, const float* __restrict__ logvar,
@@ -731,6 +751,34 @@ int sv_dense_dgrad(const void* dz, const void* w, void* dx, int M, int K, int N,
 }
 
 // dw[K,N] (+)= x[M,K]^T dz[M,N]
+size_t sv_dense_wgrad_workspace_bytes(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    const int s = gemm_splits(K, N, M);
+    return s > 1 ? (size_t)s * K * N * sizeof(float) : 0;
+}
+
+int sv_dense_wgrad_ws(const void* x, const void* dz, void* dw, int accumulate, int M, int K, int N, void* workspace,
+                      size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_dense_wgrad_ws");
+    SV_REQUIRE(x && dz && dw && M > 0 && K > 0 && N > 0, "sv_dense_wgrad_ws: bad arguments");
+    const int splits = gemm_splits(K, N, M);
+    const size_t need = sv_dense_wgrad_workspace_bytes(M, K, N);
+    if (splits < 2 || workspace == nullptr || workspace_bytes < need)  // not an error: the reduction then stays whole
+        return sv_dense_wgrad(x, dz, dw, accumulate, M, K, N, dtype, stream);
+    // dw[K, N] = x[M, K]^T dz[M, N]: the batch is the reduction, cut into `splits` ranges of whole 16-steps
+    const int per = (int)(ceil_div(ceil_div(M, splits), 16) * 16);
+    dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(K, 64), (unsigned)ceil_div(M, per));
+    hipLaunchKernelGGL(gemm_k, grid, dim3(256), 0, to_stream(stream), (const float*)x, (int64_t)1, (int64_t)K,
+                       (const float*)dz, (int64_t)N, (int64_t)1, (const float*)nullptr, (float*)workspace, K, N, M,
+                       SV_ACT_NONE, 0.f, 0, per);
+    int rc = check_launch("gemm (cut reduction)");
+    if (rc) return rc;
+    if (grid.z == 1) {  // a single range wrote plain sums into slab 0
+        return launch_slab_sum((const float*)workspace, (float*)dw, (int64_t)K * N, 1, accumulate, to_stream(stream));
+    }
+    return launch_slab_sum((const float*)workspace, (float*)dw, (int64_t)K * N, (int)grid.z, accumulate, to_stream(stream));
+}
+
 int sv_dense_wgrad(const void* x, const void* dz, void* dw, int accumulate, int M, int K, int N, int dtype,
                    sv_stream_t stream) {
     SV_F32_ONLY(dtype, "sv_dense_wgrad");

@@ -843,7 +843,10 @@ class Dense(Layer):
         elif pg:
             ops.bias_grad(dy, self.bias.grad, True, m, n, ws)
         if pg:
-            ops.dense_wgrad(x, dy, self.kernel.grad, True, m, k, n)
+            nbytes = ops.dense_wgrad_workspace(m, k, n)
+            # the layer's own scratch (a deferred bracket sums the partial sums at the end of the backward pass)
+            wws = ctx.buf(self, "wgrad_ws", (nbytes,), torch.uint8) if nbytes else None
+            ops.dense_wgrad(x, dy, self.kernel.grad, True, m, k, n, wws)
         if not need_dx:
             return None
         dx = ctx.buf(self, "dx", (m, k))

@@ -446,9 +446,19 @@ def dense_dgrad(dz, w, dx, m, k, n):
     check(lib.sv_dense_dgrad(_ptr(dz), _ptr(w), _ptr(dx), m, k, n, F32, _stream()), "sv_dense_dgrad")
 
 
-def dense_wgrad(x, dz, dw, accumulate: bool, m, k, n):
-    check(lib.sv_dense_wgrad(_ptr(x), _ptr(dz), _ptr(dw), int(accumulate), m, k, n, F32, _stream()),
-          "sv_dense_wgrad")
+def dense_wgrad_workspace(m: int, k: int, n: int) -> int:
+    return int(lib.sv_dense_wgrad_workspace_bytes(m, k, n))
+
+
+def dense_wgrad(x, dz, dw, accumulate: bool, m, k, n, ws: Optional[torch.Tensor] = None):
+    """``ws``: scratch of ``dense_wgrad_workspace(m, k, n)`` bytes that lets the reduction over the batch be cut over
+    many workgroups (its own until a deferred-reduce bracket is flushed)."""
+    if ws is None:
+        check(lib.sv_dense_wgrad(_ptr(x), _ptr(dz), _ptr(dw), int(accumulate), m, k, n, F32, _stream()),
+              "sv_dense_wgrad")
+    else:
+        check(lib.sv_dense_wgrad_ws(_ptr(x), _ptr(dz), _ptr(dw), int(accumulate), m, k, n, _ptr(ws, torch.uint8),
+                                    ws.numel(), F32, _stream()), "sv_dense_wgrad_ws")
 
 
 def dropout_fwd(x, y, rate, seed, offset):

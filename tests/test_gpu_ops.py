@@ -566,7 +566,8 @@ def test_concat_and_misc():
     close(dx, np.repeat(r.cpu().numpy().astype(np.float64)[:, None], 5, axis=1), tol=0)
 
 
-@pytest.mark.parametrize("mkn", [(32, 2048, 1000), (7, 33, 5), (64, 512, 64), (130, 70, 129)])
+@pytest.mark.parametrize("mkn", [(32, 2048, 1000), (7, 33, 5), (64, 512, 64), (130, 70, 129), (1024, 512, 64),
+                                 (1027, 64, 8), (300, 8, 64)])
 def test_dense(mkn):
     from spectrum_vae_amd import ops
     m, k, n = mkn
@@ -583,6 +584,16 @@ def test_dense(mkn):
     dw = torch.zeros((k, n), device="cuda")
     ops.dense_wgrad(dev(x), dev(dz), dw, True, m, k, n)
     close(dw, dw_o, what="dense wgrad")
+    # with scratch the reduction over the batch is cut over many workgroups; the sums are added to what is there
+    nbytes = ops.dense_wgrad_workspace(m, k, n)
+    assert (nbytes > 0) == (m >= 64 and k * n <= 64 * 64 * 128)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+    dw2 = torch.ones((k, n), device="cuda")
+    ops.dense_wgrad(dev(x), dev(dz), dw2, True, m, k, n, ws)
+    close(dw2, dw_o + 1.0, what="dense wgrad (cut reduction)")
+    dw3 = torch.ones((k, n), device="cuda")
+    ops.dense_wgrad(dev(x), dev(dz), dw3, True, m, k, n, ws)
+    assert torch.equal(dw2, dw3)  # fixed order of the partial sums
 
 
 def test_losses():
