@@ -21,6 +21,19 @@ namespace sv {
 
 typedef float dn_v4f __attribute__((ext_vector_type(4)));
 
+#ifdef SV_TRACE
+// diagnostic builds: thread 0 of every workgroup stores the 100 MHz wall clock at phase marks, 16 slots per workgroup
+__device__ unsigned long long* g_dn_trace = nullptr;
+__device__ __forceinline__ void dn_mark(int slot, bool drain) {
+    if (g_dn_trace == nullptr) return;
+    if (drain) __builtin_amdgcn_s_waitcnt(0);  // the phase's loads have landed
+    if (threadIdx.x == 0 && slot < 16) g_dn_trace[(size_t)blockIdx.x * 16 + slot] = wall_clock64();
+}
+#define DN_MARK(slot, drain) dn_mark(slot, drain)
+#else
+#define DN_MARK(slot, drain)
+#endif
+
 struct DnArgs {
     const float* dy;      // zmode 1: [N][H][W][CZ];  zmode 2: [N][H/2][W/2][CZ]
     const float* zy;      // activation output, extents of dy
@@ -32,6 +45,24 @@ struct DnArgs {
 };
 
 constexpr int kDnUnits = 4;  // 16-byte pieces per thread and pass held in registers between load and store
+
+// The LDS image of dz: floats from one pixel to the next (PS) and from one row to the next (RP).  The 16 lanes that one
+// LDS cycle of an operand read serves are 4 x 4 (16-byte reads), 2 x 16 (8- and 4-byte reads) (pixel, channel group)
+// pairs of a 2 x 8 pixel patch; with the channels of a pixel packed (PS = CZ) and rows packed (RP = (W + 2) PS) they
+// fall on a half or a quarter of the banks.  The strides below are the smallest that spread every such group over all
+// 64 banks (found by enumerating the lane groups of ds_read_b128 / _b64 / _b32 over candidate strides).
+constexpr int dn_pad_to(int base, int mod, int res) { return base + ((res - base % mod) + mod) % mod; }
+constexpr int dn_ps(int CZ, int MODE) {
+    return (CZ == 8 && MODE == 1) ? 10 : (CZ == 16 && MODE == 2) ? 20 : (CZ == 32 && MODE == 0) ? 40 : CZ;
+}
+constexpr int dn_rp(int CZ, int WO, int MODE) {
+    const int base = (WO + 2) * dn_ps(CZ, MODE);
+    if (CZ == 3) return MODE == 1 ? dn_pad_to(base, 16, 8) : base;
+    if (CZ == 8) return MODE == 1 ? dn_pad_to(base, 32, 16) : dn_pad_to(base, 8, 4);
+    if (CZ == 16) return MODE == 2 ? dn_pad_to(base, 64, 0) : dn_pad_to(base, 16, 8);
+    if (CZ == 32) return MODE == 0 ? dn_pad_to(base, 64, 0) : base;
+    return base;
+}
 
 __device__ __forceinline__ float dn_dpp_xor1(float v) {  // value of lane ^ 1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
@@ -58,7 +89,9 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     constexpr int NH = CZ == 3 ? 1 : CZ / (4 * VEC);              // reads per tap
     constexpr int TW = (PH || WD) ? 4 : 3, TAPS = (PH ? 4 : 3) * TW;  // window of dz pixels a result column reads
     constexpr int NSTEP = CZ == 3 ? (3 * TAPS + 3) / 4 : TAPS * NH;  // reads per pixel tile
-    constexpr int SW = WO + 2, TX = (PH || WD) ? WO / 16 : WO / 8;
+    constexpr int TX = (PH || WD) ? WO / 16 : WO / 8;
+    constexpr int PS = dn_ps(CZ, MODE), RP = dn_rp(CZ, WO, MODE);
+    static_assert(CZ == 3 || (PS % VEC == 0 && RP % 4 == 0), "operand reads and staging stores stay aligned");
     static_assert(!WD || CZ != 3, "pair form: channel counts that are multiples of 4");
     constexpr bool PING = NSTEP * VEC <= 36;                      // operand registers of two tiles fit
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -66,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     const int li = lane & 15, lk = lane >> 4;
     const int pr = li >> 3, pc = li & 7;
     const int H = a.H;
-    const int sampleZ = (H + 2) * SW * CZ;
+    const int sampleZ = (H + 2) * RP;
 
     // ---- staging of dz: source extents, registers of the pass in flight
     const int zmode = a.zmode;
@@ -101,17 +134,25 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
                 const int p = e / CZ, c = e - p * CZ;
                 const int ss = fd(p, f_hw), pp = p - ss * (s_h * s_w);
                 const int row = fd(pp, f_w), col = pp - row * s_w;
+                auto put = [](float* q, const float4& o) {
+                    if constexpr (PS % 4 == 0) {
+                        *reinterpret_cast<float4*>(q) = o;
+                    } else {  // pixels start at multiples of 8 bytes only
+                        *reinterpret_cast<float2*>(q) = make_float2(o.x, o.y);
+                        *reinterpret_cast<float2*>(q + 2) = make_float2(o.z, o.w);
+                    }
+                };
                 if (zmode != 2) {
-                    *reinterpret_cast<float4*>(smem + ss * sampleZ + ((row + 1) * SW + col + 1) * CZ + c) = v;
+                    put(smem + ss * sampleZ + (row + 1) * RP + (col + 1) * PS + c, v);
                 } else {
-                    float* q = smem + ss * sampleZ + ((2 * row + 1) * SW + 2 * col + 1) * CZ + c;
+                    float* q = smem + ss * sampleZ + (2 * row + 1) * RP + (2 * col + 1) * PS + c;
                     const uint32_t k = rk[i];
                     const uint32_t k0 = k & 0xff, k1 = (k >> 8) & 0xff, k2 = (k >> 16) & 0xff, k3 = k >> 24;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const float4 o = make_float4(k0 == (uint32_t)s ? v.x : 0.f, k1 == (uint32_t)s ? v.y : 0.f,
                                                      k2 == (uint32_t)s ? v.z : 0.f, k3 == (uint32_t)s ? v.w : 0.f);
-                        *reinterpret_cast<float4*>(q + ((s >> 1) * SW + (s & 1)) * CZ) = o;
+                        put(q + (s >> 1) * RP + (s & 1) * PS, o);
                     }
                 }
             } else {  // 3 channels, never pooled here: the 4 floats of a piece belong to 1 or 2 pixels
@@ -121,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
                     const int p = (e + t) / CZ, c = (e + t) - p * CZ;
                     const int ss = fd(p, f_hw), pp = p - ss * (s_h * s_w);
                     const int row = fd(pp, f_w), col = pp - row * s_w;
-                    smem[ss * sampleZ + ((row + 1) * SW + col + 1) * CZ + c] = vv[t];
+                    smem[ss * sampleZ + (row + 1) * RP + (col + 1) * PS + c] = vv[t];
                 }
             }
         }
@@ -129,6 +170,26 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
 
     // ---- the filters as A operands: row m = mt * 16 + li is input channel ci, reduction slot lk of read (tap, h) and
     // element j is output channel h * 4 VEC + VEC * lk + j of tap (a, b) = mirrored (kh, kw)
+    DN_MARK(0, false);
+    // The filter tensor comes in as 16-byte pieces (one round trip for the workgroup) behind the dz image; a lane then
+    // picks its operand values out of LDS.  Per-lane loads from global memory took 2-3 dependent round trips here.
+    int n0 = blockIdx.x * a.ns;
+    if (n0 < a.N) load_pass(n0);
+    const int zimg4 = (a.ns * sampleZ + 3 + 16) >> 2;  // 16-byte pieces of the dz images (and the pad behind them)
+    const float* wl = smem + 4 * zimg4;
+    {
+        constexpr int W4 = 9 * CX * CZ / 4;
+        static_assert(9 * CX * CZ % 4 == 0, "the filters are copied as 16-byte pieces");
+        float4 wv[(W4 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (W4 + 255) / 256; ++i)
+            wv[i] = reinterpret_cast<const float4*>(a.w)[min((int)threadIdx.x + i * 256, W4 - 1)];
+        for (int i = threadIdx.x; i < zimg4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < (W4 + 255) / 256; ++i)
+            if ((int)threadIdx.x + i * 256 < W4) reinterpret_cast<float4*>(smem)[zimg4 + threadIdx.x + i * 256] = wv[i];
+    }
+    __syncthreads();
     float wreg[NSTEP][VEC][MT];
     int zoff[CZ == 3 ? NSTEP : 1];  // 3 channels: reduction index kk = 4 s + lk walks (a, b, co) flattened
     // the filter value that connects window position (ta, tb) of dz with input channel ci: one mirrored tap, or (PH) the
@@ -136,10 +197,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     auto wtap = [&](int ta, int tb, int row, int co) {
         if (WD) {  // row = (pixel of the pair, channel): the odd pixel's window starts one column to the right
             const int e = row >> 3, ci = row & 7, t = tb - e;
-            return (t >= 0 && t <= 2) ? a.w[(((2 - ta) * 3 + (2 - t)) * CX + ci) * CZ + co] : 0.f;
+            return (t >= 0 && t <= 2) ? wl[(((2 - ta) * 3 + (2 - t)) * CX + ci) * CZ + co] : 0.f;
         }
         const int ci = row;
-        if (!PH) return a.w[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co];
+        if (!PH) return wl[(((2 - ta) * 3 + (2 - tb)) * CX + ci) * CZ + co];
         // kernel rows {2 - ta, 3 - ta} and columns {2 - tb, 3 - tb} inside 0..2: four loads at clamped indices, the ones
         // outside weighted 0 (a loop over the nine taps with a condition each costs nine predicated loads per value)
         float t = 0.f;
@@ -149,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
             for (int j = 0; j < 2; ++j) {
                 const int kh = 2 - ta + i, kw = 2 - tb + j;
                 const bool in = kh >= 0 && kh <= 2 && kw >= 0 && kw <= 2;
-                const float v = a.w[((min(max(kh, 0), 2) * 3 + min(max(kw, 0), 2)) * CX + ci) * CZ + co];
+                const float v = wl[((min(max(kh, 0), 2) * 3 + min(max(kw, 0), 2)) * CX + ci) * CZ + co];
                 t += in ? v : 0.f;
             }
         return t;
@@ -161,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
             const bool ok = kk < 3 * TAPS;
             const int k2 = ok ? kk : 0;
             const int ta = k2 / (3 * TW), rem = k2 - ta * (3 * TW), tb = rem / 3, co = rem - tb * 3;
-            zoff[s] = ta * SW * CZ + rem;
+            zoff[s] = ta * RP + rem;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int ci = mt * 16 + li;
@@ -185,20 +246,18 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
         }
     }
     // the lane's pixel (and channel group) inside a tile; PH: the window of stored pixel (pr, pc) starts at (2 pr, 2 pc)
-    const int lz = (PH ? 2 * (pr * SW + pc) : (WD ? pr * SW + 2 * pc : pr * SW + pc)) * CZ + (CZ == 3 ? 0 : VEC * lk);
+    const int lz = (PH ? 2 * (pr * RP + pc * PS) : (WD ? pr * RP + 2 * pc * PS : pr * RP + pc * PS)) + (CZ == 3 ? 0 : VEC * lk);
 
-    int n0 = blockIdx.x * a.ns;
-    if (n0 < a.N) load_pass(n0);
-    {
-        const int total = (a.ns * sampleZ + 3 + 16) >> 2;
-        for (int i = threadIdx.x; i < total; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    DN_MARK(1, false);
     const int tps_log = a.tps_log, tps_mask = (1 << tps_log) - 1;
+    DN_MARK(2, false);
+    [[maybe_unused]] int pass = 0;
     for (; n0 < a.N; n0 += gridDim.x * a.ns) {
         const int ns = min(a.ns, a.N - n0);
         __syncthreads();
         store_pass(ns);
         __syncthreads();
+        DN_MARK(3 + 2 * pass, false);
         if (n0 + (int)gridDim.x * a.ns < a.N) load_pass(n0 + gridDim.x * a.ns);
 
         const int ntile = (ns << tps_log) >> 2;  // tiles of this wave: tps is a multiple of 4
@@ -213,14 +272,14 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
         auto load_tile = [&](float (&zv)[NSTEP][VEC], int i) {
             int ss, oh, ow0;
             tile_pos(i, ss, oh, ow0);
-            const float* zq = smem + ss * sampleZ + (PH ? 2 : 1) * (oh * SW + ow0) * CZ + lz;  // PH: (oh, ow0) are stored pixels
+            const float* zq = smem + ss * sampleZ + (PH ? 2 : 1) * (oh * RP + ow0 * PS) + lz;  // PH: (oh, ow0) are stored pixels
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
                 if (CZ == 3) {
                     zv[s][0] = zq[zoff[s]];
                 } else {
                     const int tap = s / NH, h = s - tap * NH;
-                    const float* q = zq + ((tap / TW) * SW + tap % TW) * CZ + h * 4 * VEC;
+                    const float* q = zq + (tap / TW) * RP + (tap % TW) * PS + h * 4 * VEC;
                     if (VEC == 2) {
                         const float2 v = *reinterpret_cast<const float2*>(q);
                         zv[s][0] = v.x; zv[s][VEC - 1] = v.y;
@@ -244,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
                         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][j][mt], zv[s][j], acc[mt], 0, 0, 0);
             int ss, oh, ow0;
             tile_pos(i, ss, oh, ow0);
-            if (!live) return;  // the second tile of the last pair when a wave's tile count is odd
+            if (!live) return;
             // lane (li, lk) holds input channels mt * 16 + 4 lk .. + 3 of pixel (oh + pr, ow0 + pc)
             if (WD) {  // rows 4 lk .. 4 lk + 3 = channels 4 (lk & 1) .. + 3 of the pair's pixel lk >> 1
                 float* o = a.dx + (((size_t)(n0 + ss) * H + oh + pr) * WO + ow0 + 2 * pc + (lk >> 1)) * CX + 4 * (lk & 1);
@@ -281,8 +340,8 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
             }
         };
         if constexpr (PING) {
-            // tiles in pairs, the reads of the next tile issued before the current tile's matrix instructions; an odd
-            // count repeats the last tile's arithmetic and drops its stores, so the loop body has no branch before them
+            // tiles in pairs, the reads of the next tile issued before the current tile's matrix instructions; with an odd
+            // count the last turn reads its own tile again and skips the second half (a wave-uniform branch at its end)
             load_tile(zv0, 0);
             for (int i = 0; i < ntile; i += 2) {
                 const bool two = i + 1 < ntile;
@@ -292,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_tile(zv0, min(i + 2, ntile - 1));
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_tile(zv1, two ? i + 1 : i, two);
+                if (two) mfma_tile(zv1, i + 1, true);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -301,7 +360,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
                 mfma_tile(zv0, i, true);
             }
         }
+        DN_MARK(4 + 2 * pass, false);
+        ++pass;
     }
+    DN_MARK(15, true);
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -355,13 +417,14 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
         else wd = false;
     }
     if (tps < 4 || (tps & (tps - 1))) return 1;
-    const int64_t sampleZ = (int64_t)(H + 2) * (W + 2) * CZ;
+    const int mode = ph ? 1 : (wd ? 2 : 0);
+    const int64_t sampleZ = (int64_t)(H + 2) * dn_rp(CZ, W, mode);
     const int64_t units = (zmode == 2 ? (int64_t)(H / 2) * (W / 2) * CZ : (int64_t)H * W * CZ) / 4;
-    auto lds = [&](int ns) { return (size_t)(ns * sampleZ + 3 + 16) / 4 * 16; };
+    auto lds = [&](int ns) { return (size_t)(ns * sampleZ + 3 + 16) / 4 * 16 + (size_t)9 * CX * CZ * sizeof(float); };
     // workgroups (measured at batch 1024): one sample each for the 32-wide 3-channel image (few registers, 14 KB of LDS:
     // four workgroups share a CU and hide each other's load latencies), two per CU for the 16-wide image with 8-channel
     // dz, one per CU elsewhere, where more workgroups only repeat the filter loads
-    int grid = shape == 0 ? 1024 : (shape == 1 ? 512 : 256);
+    int grid = shape == 0 ? 1024 : ((shape == 1 || shape == 3 || shape == 4) ? 512 : 256);
     if (ph) grid = shape == 0 ? 512 : 256;  // a quarter of the tiles per sample: fewer, longer-lived workgroups
     if (opt(OPT_DGRAD_GRID) > 0) grid = opt(OPT_DGRAD_GRID);
     if (grid > g.N) grid = g.N;
@@ -384,3 +447,9 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
 }
 
 }  // namespace sv
+
+#ifdef SV_TRACE
+extern "C" int sv_debug_set_dn_trace(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sv::g_dn_trace), &buf, sizeof(buf));
+}
+#endif
