@@ -13,7 +13,7 @@ thread_local char g_last_error[512] = "";
 static std::atomic<int> g_opt[OPT_COUNT];
 static const char* const kOptNames[OPT_COUNT] = {
     "dgrad_nhwc", "dgrad_phase", "dgrad_pair", "dgrad_grid", "dgrad_valu", "wgrad_nhwc", "wgrad_valu", "netfwd_generic",
-    "netfwd_pair", "netfwd_phase", "netfwd_valu", "netfwd_s", "netfwd_grid", "small_convt", "s1_mfma"};
+    "netfwd_pair", "netfwd_phase", "netfwd_valu", "netfwd_s", "netfwd_grid", "small_convt", "s1_mfma", "wgrad_stored"};
 static const bool g_opt_init = [] {
     for (int i = 0; i < OPT_COUNT; ++i) g_opt[i].store(-1, std::memory_order_relaxed);
     return true;

@@ -67,6 +67,7 @@ enum SvOpt {
     OPT_NETFWD_GRID,     // > 0: cap on the workgroups of the fused forward
     OPT_SMALL_CONVT,     // 0: few-channel transposed convs through the implicit GEMM
     OPT_S1_MFMA,         // 0: stride-1 SAME convs outside the few-channel family through the planar kernels
+    OPT_WGRAD_STORED,    // 0: kernel gradients of upsampled layers over the pixels of the upsampled image
     OPT_COUNT
 };
 int opt(int id);  // api.hip

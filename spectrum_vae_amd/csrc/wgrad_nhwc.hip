@@ -17,6 +17,7 @@
 // sums in dw order; wn_reduce_multi adds the slabs in a fixed order (bit-reproducible, no float atomics).
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "tile_common.h"
@@ -46,6 +47,35 @@ struct WnArgs {
 #else
 #define WN_DBG(a, bit) 0
 #endif
+
+#ifdef SV_TRACE
+// diagnostic builds: thread 0 of every workgroup stores the 100 MHz wall clock at phase marks, 32 slots per workgroup:
+// 0 start, 1 LDS cleared, per pass p (the first seven) 2 + 4 p pass entered, + 1 its loads landed, + 2 staged, + 3 matrix
+// instructions done, 31 exit
+__device__ unsigned long long* g_wn_trace = nullptr;
+__device__ __forceinline__ void wn_mark(int slot, bool drain) {
+    if (g_wn_trace == nullptr) return;
+    if (drain) __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0 && slot < 32) g_wn_trace[(size_t)blockIdx.x * 32 + slot] = wall_clock64();
+}
+#define WN_MARK(slot, drain) wn_mark(slot, drain)
+#else
+#define WN_MARK(slot, drain)
+#endif
+
+// Order of one turn of a matrix-core loop: NM matrix instructions with the NR LDS reads of the NEXT turn's operands
+// placed two behind each of the first ones, so the reads issue in the shadow of the matrix pipe and the last of them
+// have the remaining instructions' time to land.
+template <int NM, int NR, int... I>
+__device__ __forceinline__ void wn_interleave_seq(std::integer_sequence<int, I...>) {
+    ((__builtin_amdgcn_sched_group_barrier(0x008, 1, 0),
+      __builtin_amdgcn_sched_group_barrier(0x100, (NR - 2 * I) >= 2 ? 2 : ((NR - 2 * I) > 0 ? (NR - 2 * I) : 0), 0)), ...);
+}
+template <int NM, int NR>
+__device__ __forceinline__ void wn_interleave() {
+    static_assert(NR <= 2 * NM, "two reads per matrix instruction at most");
+    wn_interleave_seq<NM, NR>(std::make_integer_sequence<int, NM>{});
+}
 
 constexpr int kWnUnits = 4;  // 16-byte pieces per thread, tensor and pass held in registers between load and store
 
@@ -85,6 +115,7 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
     const int p_sample = p_h * p_w * CP;
     const FDiv f_shw = fd_make(Ho * Wo), f_sw = fd_make(Wo), f_phw = fd_make(p_h * p_w), f_pw = fd_make(p_w);
 
+    WN_MARK(0, false);
     WnRegs R;
     auto load_pass = [&](int n0) {
         const int ns = min(a.ns, a.N - n0);
@@ -206,11 +237,16 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
         const int total = ((a.ns * sampleS + 3) & ~3) + a.ns * sampleP + 64;
         for (int i = threadIdx.x; i < (total >> 2); i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (; n0 < a.N; n0 += gx * a.ns) {
+    WN_MARK(1, false);
+    [[maybe_unused]] int pass = 0;
+    for (; n0 < a.N; n0 += gx * a.ns, ++pass) {
         const int ns = min(a.ns, a.N - n0);
         __syncthreads();  // zero fill landed / the previous pass's operand reads are done
+        WN_MARK(2 + 4 * pass, false);
+        WN_MARK(3 + 4 * pass, true);
         if (!WN_DBG(a, 2)) store_pass(ns);
         __syncthreads();
+        WN_MARK(4 + 4 * pass, false);
         if (n0 + gx * a.ns < a.N && !WN_DBG(a, 4)) load_pass(n0 + gx * a.ns);  // in flight during this pass's arithmetic
 
         if (WN_DBG(a, 1)) continue;
@@ -251,20 +287,27 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
             };
             // R is even (Ho / 4 is a power of two >= 2): the body has no branches, so the waits before each row's matrix
             // instructions count only that row's reads; the last turn re-reads its own row instead of running past the end
+            // few tiles: the next row's reads go between this row's matrix instructions; many tiles (the 16 / 32-channel
+            // pair, 72 accumulator registers): all reads first, which keeps the register count under the cap
+            constexpr bool MIX = NTILE <= 8;
             load_row(av0, bv0, 0);
+            if (MIX) __builtin_amdgcn_sched_barrier(0);
             for (int r = 0; r < R; r += 2) {
                 load_row(av1, bv1, r + 1);
-                __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the previous row's arithmetic
+                if (!MIX) __builtin_amdgcn_sched_barrier(0);
                 mfma_row(av0, bv0);
+                if (MIX) wn_interleave<QX * MT * NT, QX * (MT + NT)>();
                 __builtin_amdgcn_sched_barrier(0);
                 load_row(av0, bv0, min(r + 2, R - 1));
-                __builtin_amdgcn_sched_barrier(0);
+                if (!MIX) __builtin_amdgcn_sched_barrier(0);
                 mfma_row(av1, bv1);
+                if (MIX) wn_interleave<QX * MT * NT, QX * (MT + NT)>();
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         if (pshift) run(std::integral_constant<int, 1>{});
         else run(std::integral_constant<int, 0>{});
+        WN_MARK(5 + 4 * pass, false);
     }
 
     // ---- sum the 4 waves as (w0 + w1) + (w2 + w3) through LDS (the images are dead): tiles travel in their register
@@ -339,13 +382,243 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
     float* out = a.slab + (size_t)bx * a.slab_floats;
     for (int i = threadIdx.x; i < (a.slab_floats >> 2); i += 256)
         reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(img)[i];
+    WN_MARK(31, true);
+}
+
+
+// ---------------------------------------------------------------------------------------------------- stored-pixel form
+// A conv behind a 2x nearest upsampling (x_up[q] = x[q >> 1]), S = dz at the upsampled resolution, P = x as stored.
+// With q = p + k - 1 = 2 r + e the sum over the upsampled pixels p regroups over the stored pixels r:
+//   G[ta][tb][co][ci] = sum over r of dz[2 r - 1 + (ta, tb)][co] * x[r][ci]          (a 4 x 4 window of dz per stored pixel)
+//   dw[kh][kw][ci][co] = sum over eh, ew in {0, 1} of G[2 - kh + eh][2 - kw + ew][co][ci]
+// 16 instead of 4 x 9 products per stored pixel.  The GEMM rows are (ta, tb, co): wave `ta` owns the rows of its window
+// row for every pixel of the pass (the waves split the rows of the result, not the pixels, so their sums need no
+// exchange), the 4 reduction slots of an instruction are 4 consecutive stored pixels of an image row.  The four window
+// positions with ta, tb in {1, 2} tile the dz image exactly once: their operand values, summed per lane, are the bias
+// gradient.  Pixel strides of 24 floats for a 16-channel S and 48 for a 32-channel P keep the two pixel slots that share
+// an LDS cycle on different banks.
+constexpr int wn_sp_ps(int CS) { return CS == 16 ? 24 : CS; }
+constexpr int wn_sp_pps(int CP) { return CP == 32 ? 48 : CP; }
+
+template <int CS, int CP, int WO>
+__device__ __forceinline__ void wn_body_sp(const WnArgs& a, const int bx, const int gx) {
+    constexpr int TPW = CS == 3 ? 1 : CS / 4;                  // 16-row tiles of a wave: (tb, co) of its window row
+    constexpr int NT = (CP + 15) / 16;
+    constexpr int Ws = WO / 2, QX = Ws / 4, SW = WO + 2;
+    constexpr int PS = wn_sp_ps(CS), PPS = wn_sp_pps(CP);
+    constexpr int Cin = CP, Cout = CS;
+    static_assert(QX >= 1 && (CS == 3 || CS % 4 == 0), "stored rows hold whole pixel quads");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int Ho = a.Ho, Hs = a.Hs;
+    const int sampleS = (Ho + 2) * SW * PS, sampleP = Hs * Ws * PPS;
+    float* s_lds = smem;
+    float* p_lds = smem + ((a.ns * sampleS + 3) & ~3);
+    const int s_sample = Ho * WO * CS, p_sample = Hs * Ws * CP;
+    const bool s_act = a.zmode == 1;
+    const FDiv f_shw = fd_make(Ho * WO);
+
+    WN_MARK(0, false);
+    WnRegs R;
+    auto load_pass = [&](int n0) {
+        const int ns = min(a.ns, a.N - n0);
+        const int su = (ns * s_sample) >> 2, pu = (ns * p_sample) >> 2;
+        const size_t sb = (size_t)n0 * s_sample, pb = (size_t)n0 * p_sample;
+#pragma unroll
+        for (int i = 0; i < kWnUnits; ++i) {
+            const int u = min((int)threadIdx.x + i * 256, su - 1);
+            R.sv[i] = *reinterpret_cast<const float4*>(a.dy + sb + 4 * (size_t)u);
+            R.sy[i] = s_act ? *reinterpret_cast<const float4*>(a.zy + sb + 4 * (size_t)u) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int i = 0; i < kWnUnits; ++i) {
+            const int u = min((int)threadIdx.x + i * 256, pu - 1);
+            R.pv[i] = *reinterpret_cast<const float4*>(a.x + pb + 4 * (size_t)u);
+        }
+    };
+    constexpr int SEL = CS % 4 == 0 ? 1 : 4;
+    int s_at[kWnUnits][SEL], p_at[kWnUnits];
+#pragma unroll
+    for (int i = 0; i < kWnUnits; ++i) {
+        const int e = 4 * ((int)threadIdx.x + i * 256);
+#pragma unroll
+        for (int t = 0; t < SEL; ++t) {
+            const int p = (e + t) / CS, c = (e + t) - p * CS;
+            const int ss = fd(p, f_shw), pp = p - ss * (Ho * WO);
+            const int row = pp / WO, col = pp - row * WO;
+            s_at[i][t] = ss * sampleS + ((row + 1) * SW + col + 1) * PS + c;
+        }
+        p_at[i] = (e / CP) * PPS + e % CP;
+    }
+    auto store_pass = [&](int ns) {
+        const int su = (ns * s_sample) >> 2, pu = (ns * p_sample) >> 2;
+#pragma unroll
+        for (int i = 0; i < kWnUnits; ++i) {
+            if ((int)threadIdx.x + i * 256 < su) {
+                float4 v = R.sv[i];
+                if (s_act) {
+                    v.x *= act_grad_q(R.sy[i].x, a.zk); v.y *= act_grad_q(R.sy[i].y, a.zk);
+                    v.z *= act_grad_q(R.sy[i].z, a.zk); v.w *= act_grad_q(R.sy[i].w, a.zk);
+                }
+                if (CS % 4 == 0) {
+                    *reinterpret_cast<float4*>(s_lds + s_at[i][0]) = v;
+                } else {
+                    s_lds[s_at[i][0]] = v.x; s_lds[s_at[i][1 % SEL]] = v.y;
+                    s_lds[s_at[i][2 % SEL]] = v.z; s_lds[s_at[i][3 % SEL]] = v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kWnUnits; ++i)
+            if ((int)threadIdx.x + i * 256 < pu) *reinterpret_cast<float4*>(p_lds + p_at[i]) = R.pv[i];
+    };
+
+    // row t * 16 + li of the wave's block is (tb, co) = divmod(t * 16 + li, CS) (3 channels: rows 12..15 are unused and
+    // read finite neighbours); reduction slot lk is stored pixel 4 q + lk of the row, whose window starts at dz column
+    // 2 (4 q + lk) of the halo image
+    int aoff[TPW], boff[NT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int m = t * 16 + li, tb = m / CS, cs = m - tb * CS;
+        aoff[t] = wave * SW * PS + tb * PS + cs + lk * 2 * PS;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = lk * PPS + nt * 16 + li;
+
+    wn_v4f acc[TPW][NT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = wn_v4f{0.f, 0.f, 0.f, 0.f};
+    float bs = 0.f;
+    const int hs_log = a.hq_log, hs_mask = (1 << hs_log) - 1;  // Hs is a power of two
+
+    int n0 = bx * a.ns;
+    if (n0 < a.N) load_pass(n0);
+    {
+        const int total = ((a.ns * sampleS + 3) & ~3) + a.ns * sampleP + 64;
+        for (int i = threadIdx.x; i < (total >> 2); i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    WN_MARK(1, false);
+    [[maybe_unused]] int pass = 0;
+    for (; n0 < a.N; n0 += gx * a.ns, ++pass) {
+        const int ns = min(a.ns, a.N - n0);
+        __syncthreads();
+        WN_MARK(2 + 4 * pass, false);
+        WN_MARK(3 + 4 * pass, true);
+        if (!WN_DBG(a, 2)) store_pass(ns);
+        __syncthreads();
+        WN_MARK(4 + 4 * pass, false);
+        if (n0 + gx * a.ns < a.N && !WN_DBG(a, 4)) load_pass(n0 + gx * a.ns);
+        if (WN_DBG(a, 1)) continue;
+        // two stored rows per turn, the next pair's reads issued ahead of the current pair's matrix instructions
+        const int R = ns << hs_log;  // a multiple of 4
+        float av0[2][QX][TPW], bv0[2][QX][NT], av1[2][QX][TPW], bv1[2][QX][NT];
+        auto load_rows = [&](float (&av)[2][QX][TPW], float (&bv)[2][QX][NT], int r0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = r0 + j, ss = r >> hs_log, oh = r & hs_mask;
+                const float* sq = s_lds + ss * sampleS + 2 * oh * (SW * PS);
+                const float* pq = p_lds + ss * sampleP + oh * (Ws * PPS);
+#pragma unroll
+                for (int q = 0; q < QX; ++q) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[j][q][nt] = pq[boff[nt] + 4 * q * PPS];
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) av[j][q][t] = sq[aoff[t] + 8 * q * PS];
+                }
+            }
+        };
+        auto mfma_rows = [&](const float (&av)[2][QX][TPW], const float (&bv)[2][QX][NT]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < QX; ++q) {
+                    if (CS == 16) bs += av[j][q][1 % TPW] + av[j][q][2 % TPW];
+                    else if (CS == 8) bs += li >= 8 ? av[j][q][0] : av[j][q][1 % TPW];
+                    else bs += av[j][q][0];
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][q][t], bv[j][q][nt], acc[t][nt], 0, 0, 0);
+                }
+        };
+        load_rows(av0, bv0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < R; r += 4) {
+            load_rows(av1, bv1, r + 2);
+            mfma_rows(av0, bv0);
+            wn_interleave<2 * QX * TPW * NT, 2 * QX * (TPW + NT)>();
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows(av0, bv0, min(r + 4, R - 2));
+            mfma_rows(av1, bv1);
+            wn_interleave<2 * QX * TPW * NT, 2 * QX * (TPW + NT)>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        WN_MARK(5 + 4 * pass, false);
+    }
+
+    // ---- G into LDS as [window position][ci][co] (the images are dead), then every thread folds four of its values into
+    // an element of dw and writes it to the slab; the bias sums of the two inner window rows meet in LDS as well
+    bs += __shfl_xor(bs, 16, 64);
+    bs += __shfl_xor(bs, 32, 64);
+    __syncthreads();
+    float* gimg = smem;
+    float* bimg = smem + 16 * CS * CP;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + li;
+            if (CS % 4 == 0) {
+                const int m = t * 16 + 4 * lk, tb = m / CS, cs = m - tb * CS;
+                if (n < CP)
+                    *reinterpret_cast<float4*>(gimg + ((wave * 4 + tb) * CP + n) * CS + cs) =
+                        make_float4(acc[t][nt][0], acc[t][nt][1], acc[t][nt][2], acc[t][nt][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = t * 16 + 4 * lk + r, tb = m / CS, cs = m - tb * CS;
+                    if (tb < 4 && n < CP) gimg[((wave * 4 + tb) * CP + n) * CS + cs] = acc[t][nt][r];
+                }
+            }
+        }
+    if (lk == 0 && (wave == 1 || wave == 2)) bimg[(wave - 1) * 16 + li] = bs;
+    __syncthreads();
+    float* out = a.slab + (size_t)bx * a.slab_floats;
+    constexpr int NW = 9 * Cin * Cout;
+    for (int e = threadIdx.x; e < NW; e += 256) {
+        const int co = e % Cout, ci = (e / Cout) % Cin, tap = e / (Cin * Cout);
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const float* g0 = gimg + (((2 - kh) * 4 + (2 - kw)) * CP + ci) * CS + co;
+        out[e] = (g0[0] + g0[CP * CS]) + (g0[4 * CP * CS] + g0[5 * CP * CS]);
+    }
+    if ((int)threadIdx.x < Cout) {
+        const int c = threadIdx.x;
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 2; ++wv)
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {
+                // lanes whose summed rows were the window columns tb in {1, 2} of channel c
+                const bool mine = CS == 16 ? l == c : (CS == 8 ? (l & 7) == c : (l >= 3 && l < 9 && l % 3 == c));
+                if (mine) t += bimg[wv * 16 + l];
+            }
+        out[NW + c] = t;
+    } else if ((int)threadIdx.x - Cout < a.slab_floats - (NW + Cout)) {
+        out[NW + threadIdx.x] = 0.f;
+    }
+    WN_MARK(31, true);
 }
 
 constexpr int kWnMaxJobs = 8;
 struct WnMultiArgs {
     int n_jobs;
     int first[kWnMaxJobs + 1];
-    int shape[kWnMaxJobs];  // 0: 3 / 8 channels on 32-wide images, 1: 8 / 16 on 16-wide, 2: 16 / 32 on 8-wide;  + 4 when S = dz (SWAP)
+    int shape[kWnMaxJobs];  // 0: 3 / 8 channels on 32-wide images, 1: 8 / 16 on 16-wide, 2: 16 / 32 on 8-wide;  + 4 when S = dz (SWAP),
+                            // + 8 for S = dz in the stored-pixel form of an upsampled layer
     WnArgs job[kWnMaxJobs];
 };
 
@@ -365,7 +638,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_nhwc_multi(WnMultiArgs m) {
         case 2: wn_body<16, 32, 0, 8>(a, bx, gx); break;
         case 4: wn_body<3, 8, 1, 32>(a, bx, gx); break;
         case 5: wn_body<8, 16, 1, 16>(a, bx, gx); break;
-        default: wn_body<16, 32, 1, 8>(a, bx, gx); break;
+        case 6: wn_body<16, 32, 1, 8>(a, bx, gx); break;
+        case 8: wn_body_sp<3, 8, 32>(a, bx, gx); break;
+        case 9: wn_body_sp<8, 16, 16>(a, bx, gx); break;
+        default: wn_body_sp<16, 32, 8>(a, bx, gx); break;
     }
 }
 
@@ -442,14 +718,17 @@ static WnPlan plan_wn(const sv_wgrad_batch_job& q) {
     const int hq = Ho >> 2;                                    // image rows per wave
     if ((Ho & 3) || hq < 2 || (hq & (hq - 1))) return p;       // an even number of rows per wave
     p.hq_log = __builtin_ctz(hq);
-    const int64_t sampleS = (int64_t)(Ho + 2) * (Wo + 2) * cs;
-    const int64_t sampleP = swap ? (int64_t)Hs * Ws * cp : (int64_t)Ho * Wo * cp;
+    // an upsampled layer in the stored-pixel form: the stored image holds whole groups of 4 rows, a power of two of them
+    const bool sp = swap == 1 && up == 2 && opt(OPT_WGRAD_STORED) != 0 && (Hs & 3) == 0 && (Hs & (Hs - 1)) == 0;
+    if (sp) p.hq_log = __builtin_ctz(Hs);
+    const int64_t sampleS = (int64_t)(Ho + 2) * (Wo + 2) * (sp ? wn_sp_ps(cs) : cs);
+    const int64_t sampleP = sp ? (int64_t)Hs * Ws * wn_sp_pps(cp) : (swap ? (int64_t)Hs * Ws * cp : (int64_t)Ho * Wo * cp);
     const int64_t s_units = (int64_t)Ho * Wo * cs / 4;
     const int64_t p_units = (swap ? (int64_t)Hs * Ws * cp : (zmode == 2 ? (int64_t)(Ho / 2) * (Wo / 2) * cp : (int64_t)Ho * Wo * cp)) / 4;
     auto lds = [&](int ns) { return (size_t)((((int64_t)ns * sampleS + 3) & ~(int64_t)3) + ns * sampleP + 64) * sizeof(float); };
     // 128 workgroups per layer measured best at batch 1024 (768 for the six layers of the default model: fewer leave CUs
     // idle, more pay the fold and slab traffic again); a caller asking for fewer gets fewer
-    int gx = q.blocks > 0 && q.blocks < 128 ? q.blocks : 128;
+    int gx = q.blocks > 0 && q.blocks <= 512 ? q.blocks : 128;
     if (gx > g.N) gx = g.N;
     int ns = 1;
     while (ns < 8 && lds(ns + 1) <= 64 * 1024 && (ns + 1) * s_units <= 256 * kWnUnits && (ns + 1) * p_units <= 256 * kWnUnits &&
@@ -457,12 +736,12 @@ static WnPlan plan_wn(const sv_wgrad_batch_job& q) {
         ++ns;
     if (lds(ns) > 64 * 1024 || ns * s_units > 256 * kWnUnits || ns * p_units > 256 * kWnUnits) return p;
     if ((int64_t)gx * ns > g.N) gx = (g.N + ns - 1) / ns;
-    p.shape = sh + 4 * swap;
+    p.shape = sh + (sp ? 8 : 4 * swap);
     p.ns = ns;
     p.gx = gx;
     p.slab_floats = (9 * g.Cin * g.Cout + g.Cout + 3) & ~3;
     size_t need = lds(ns);
-    const size_t xch = (size_t)2 * (ntile + 1) * 64 * sizeof(float4);
+    const size_t xch = sp ? (size_t)(16 * cs * cp + 32) * sizeof(float) : (size_t)2 * (ntile + 1) * 64 * sizeof(float4);
     if (xch > need) need = xch;
     if ((size_t)p.slab_floats * sizeof(float) > need) need = (size_t)p.slab_floats * sizeof(float);
     p.lds_bytes = (need + 15) & ~(size_t)15;
@@ -548,3 +827,9 @@ int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStrea
 }
 
 }  // namespace sv
+
+#ifdef SV_TRACE
+extern "C" int sv_debug_set_wn_trace(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sv::g_wn_trace), &buf, sizeof(buf));
+}
+#endif
