@@ -108,7 +108,7 @@ class OpTimer:
                 nhwc = all(sh in ((3, 8, 32), (8, 16, 16), (16, 32, 8), (32, 16, 8), (16, 8, 16), (8, 3, 32)) for sh in shapes)
                 slabs = name.endswith("_slabs")  # one launch: the slabs stay for the optimizer launch to sum
                 info = {"jobs": nj, "flops": fl, "single_launch": slabs or not args[2], "nhwc": nhwc, "slabs": slabs}
-            elif name in ("sv_convnet_fwd", "sv_convnet_fwd_mse"):
+            elif name in ("sv_convnet_fwd", "sv_convnet_fwd_mse", "sv_convnet_fwd_mse_rows"):
                 arr, nl, n, h, w = args[0], args[1], args[2], args[3], args[4]
                 fl = 0
                 for i in range(nl):
@@ -143,7 +143,7 @@ def kernel_of_call(name: str, g):
     """(rocprof kernel name, algorithmic FLOPs) of a C-ABI call that is exactly ONE kernel launch, else None."""
     if g is None:
         return None
-    if name in ("sv_convnet_fwd", "sv_convnet_fwd_mse"):
+    if name in ("sv_convnet_fwd", "sv_convnet_fwd_mse", "sv_convnet_fwd_mse_rows"):
         # the layer table of the run_model.py defaults has a kernel built for it; other tables take the run-time-table one
         known = g.get("default_chain") and _opt("netfwd_generic") != 1
         return ("net_fwd_cae" if known else "net_fwd_s1<3>"), float(g["flops"])
@@ -383,9 +383,18 @@ def main():
     n_batches = DATASET // bs
     perm = torch.randperm(DATASET, device=device, generator=gen)
 
+    # the forward launch gathers its own batch where the model takes that form (one GPU, default stack); else a
+    # gather launch in front of the step
+    rows = model.step_rows(X, perm, bs) if model.rows_step_supported(X, bs) else None
+
     def step(i):
-        idx = perm[(i % n_batches) * bs:(i % n_batches + 1) * bs]
-        ops.gather_rows(X, idx, b["x"])
+        if rows is not None:
+            if i % n_batches == 0:
+                model.restart_rows(rows)  # 8-byte device copy once per pass over the data
+            b["rows"] = rows
+        else:
+            idx = perm[(i % n_batches) * bs:(i % n_batches + 1) * bs]
+            ops.gather_rows(X, idx, b["x"])
         model.train_on_device_batch(b, True, float(bs))
 
     # set-up, before the W warm-up steps: step 0 runs eagerly (allocates every buffer), step 1 records the HIP graphs, and

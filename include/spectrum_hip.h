@@ -141,6 +141,29 @@ int sv_convnet_fwd(const sv_net_layer* layers, int n_layers, int N, int H, int W
 int sv_convnet_fwd_mse(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
                        const float* y_true, float* dpred, float loss_scale, float* partials, int* n_partials, int dtype,
                        sv_stream_t stream);
+/* sv_convnet_fwd_mse with the shuffled batch of `model.fit(..., shuffle=True)` (run_model.py:281-289 feeds the step from
+ * a shuffled, batched dataset) gathered inside the launch instead of by a sv_gather_rows launch in front of it.  Sample
+ * n of the call is row row_index[first + n] of x_rows, first = (counter[0] - counter_base[0]) * batch_stride (0 when
+ * counter is NULL); positions are clamped into [0, n_index) and rows into [0, n_rows).  counter is a device scalar that
+ * grows by one per step - the update count in sv_adam_keras_step's step_state[0] - and counter_base a device scalar
+ * holding its value at position 0 of row_index (a device-to-device copy when an epoch's order starts): a recorded step
+ * then walks the epoch without any per-step argument.  The gathered batch is also written to x_batch ([N][H][W][Cin],
+ * float32), which is what the backward entry points and y_true (usually x_batch itself) read.
+ * sv_convnet_rows_supported: 1 when the chain takes this form (the layer table the forward kernel is built for). */
+typedef struct sv_batch_rows {
+    const float* x_rows;         /* [n_rows][H * W * Cin] float32, 16-byte aligned */
+    int64_t n_rows;
+    const int64_t* row_index;    /* [n_index] */
+    int64_t n_index;
+    const int64_t* counter;      /* device scalar or NULL */
+    const int64_t* counter_base; /* device scalar, NULL with counter */
+    int64_t batch_stride;        /* positions per step */
+    float* x_batch;              /* [N][H][W][Cin] */
+} sv_batch_rows;
+int sv_convnet_rows_supported(const sv_net_layer* layers, int n_layers, int N, int H, int W);
+int sv_convnet_fwd_mse_rows(const sv_net_layer* layers, int n_layers, int N, int H, int W, const sv_batch_rows* rows,
+                            const void* params, const float* y_true, float* dpred, float loss_scale, float* partials,
+                            int* n_partials, int dtype, sv_stream_t stream);
 
 /* ---- Whole-network backward of the same chain (the gradient tape of run_model.py:281-289 / `model.fit`): given
  *      dpred = dL/d(output of the last layer) and the y / idx tensors sv_convnet_fwd wrote, grads (+)= the gradient of

@@ -49,6 +49,14 @@ class GradSlabs(C.Structure):
                 ("n_split", C.c_int32), ("n_dw", C.c_int32), ("n_db", C.c_int32)]
 
 
+class BatchRows(C.Structure):
+    """Mirror of ``sv_batch_rows``."""
+
+    _fields_ = [("x_rows", C.c_void_p), ("n_rows", C.c_int64), ("row_index", C.c_void_p), ("n_index", C.c_int64),
+                ("counter", C.c_void_p), ("counter_base", C.c_void_p), ("batch_stride", C.c_int64),
+                ("x_batch", C.c_void_p)]
+
+
 class WgradBatchJob(C.Structure):
     """Mirror of ``sv_wgrad_batch_job``."""
 
@@ -79,6 +87,9 @@ SIGNATURES = {
     "sv_convnet_supported": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i]),
     "sv_convnet_fwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _i, _p]),
     "sv_convnet_fwd_mse": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, C.POINTER(C.c_int), _i, _p]),
+    "sv_convnet_rows_supported": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i]),
+    "sv_convnet_fwd_mse_rows": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, C.POINTER(BatchRows), _p, _p, _p, _f, _p,
+                                     C.POINTER(C.c_int), _i, _p]),
     "sv_convnet_bwd_workspace_bytes": (_sz, [C.POINTER(NetLayer), _i, _i, _i, _i, _i64]),
     "sv_convnet_bwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _p, _p, _i64, _i, _p, _sz, _i, _p]),
     "sv_conv2d_bwd_partial": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p, _sz, _i, _p]),

@@ -65,8 +65,59 @@ struct NetFwdArgs {
     float* loss_dpred;
     float* loss_partials;
     float loss_gscale;
+    // the batch gathered while it is staged (rows.row_index == null: x is the batch): sample n is row
+    // row_index[(counter[0] - counter_base[0]) * batch_stride + n] of x_rows and is also written to x_batch[n]
+    sv_batch_rows rows;
     NetLayer L[kMaxNetLayers];
 };
+
+// Staging of the network input through a row index: each sample's row is looked up once per thread (S <= 4 samples a
+// pass), its 16-byte pieces go to the planar LDS image and, as they are, to the gathered batch in global memory.
+template <int U>
+__device__ __forceinline__ void net_stage_rows(const NetFwdArgs& a, const PlanarSrc& s, const PlanarDst& d, int n0, int ns,
+                                               float* lds, int nt) {
+    const sv_batch_rows& r = a.rows;
+    const int HW = s.Hs * s.Ws, per = (HW * s.C) >> 2;  // 16-byte pieces per sample
+    const int units = ns * per;
+    const long long first = r.counter != nullptr ? (r.counter[0] - r.counter_base[0]) * r.batch_stride : 0;
+    long long row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long pos = first + n0 + min(i, ns - 1);
+        pos = pos < 0 ? 0 : (pos >= r.n_index ? r.n_index - 1 : pos);
+        row[i] = r.row_index[pos];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row[i] = row[i] < 0 ? 0 : (row[i] >= r.n_rows ? r.n_rows - 1 : row[i]);
+    const FDiv fper = fd_make(per), fC = fd_make(s.C), fHW = fd_make(HW), fW = fd_make(s.Ws);
+    float4* out = reinterpret_cast<float4*>(r.x_batch) + (size_t)n0 * per;
+    for (int u0 = threadIdx.x; u0 < units; u0 += U * nt) {
+        float4 v[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int u = min(u0 + i * nt, units - 1);
+            const int ss = fd(u, fper), off = u - ss * per;
+            const long long rw = ss == 0 ? row[0] : (ss == 1 ? row[1] : (ss == 2 ? row[2] : row[3]));
+            v[i] = reinterpret_cast<const float4*>(r.x_rows + (size_t)rw * (size_t)(HW * s.C))[off];
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int u = u0 + i * nt;
+            if (u < units) {
+                out[u] = v[i];
+                const float xv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int e = 4 * u + t;
+                    const int p = fd(e, fC), c = e - p * s.C;
+                    const int ss = fd(p, fHW), pp = p - ss * HW;
+                    const int rr = fd(pp, fW), col = pp - rr * s.Ws;
+                    stage_put<0>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, rr, col, xv[t], 0.f, 0u);
+                }
+            }
+        }
+    }
+}
 
 // ---- filters: global -> registers (prefetch) -> LDS [tap][ci][cop] followed by cop bias values ----------------------
 template <int K>
@@ -757,7 +808,8 @@ __device__ __forceinline__ void net_fwd_run(const NetFwdArgs& a, LayerOf layer, 
             src.Hs = L.Hs; src.Ws = L.Ws; src.C = L.Cin;
             const PlanarDst dst{L.Cin, L.in_plane, L.in_wp, L.in_halo};
             // 8 pieces per thread in flight: the 32 x 32 x 3 input of two samples arrives in one global round trip
-            stage_pass_m<0, 8>(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
+            if (a.rows.row_index != nullptr) net_stage_rows<8>(a, src, dst, n0, ns, smem + L.in_off, nt);
+            else stage_pass_m<0, 8>(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
             NET_MARK(25);
             net_w_store<K>(a, L, wpre, bpre, w_lds, nt);
             NET_MARK(26);
@@ -1046,6 +1098,7 @@ struct NetCaeArgs {
     float* loss_dpred;
     float* loss_partials;
     float loss_gscale;
+    sv_batch_rows rows;
     NetCaeLayerArgs rt[kCaeLayers];
 };
 
@@ -1054,6 +1107,7 @@ __global__ __launch_bounds__(256, 2) void net_fwd_cae(NetCaeArgs r) {
     NetFwdArgs a{};
     a.x = r.x; a.params = r.params; a.N = r.N; a.S = kCae.a.S; a.n_layers = kCaeLayers; a.w_off = kCae.a.w_off;
     a.loss_t = r.loss_t; a.loss_dpred = r.loss_dpred; a.loss_partials = r.loss_partials; a.loss_gscale = r.loss_gscale;
+    a.rows = r.rows;
     net_fwd_run<3, kCaeLayers>(a, [&](int l) __attribute__((always_inline)) {
         NetLayer L = kCae.a.L[l];
         L.w_off = r.rt[l].w_off; L.b_off = r.rt[l].b_off;
@@ -1749,11 +1803,18 @@ int sv_convnet_supported(const sv_net_layer* layers, int n_layers, int N, int H,
     return plan_net_fwd(layers, n_layers, N, H, W).ok ? 1 : 0;
 }
 
+// whether the launch can gather its batch through a row index: the kernel built for the default stack, whole 16-byte
+// pieces per sample, at most four samples a pass
+static bool net_rows_ok(const NetPlan& p, const sv_net_layer* layers, int H, int W) {
+    return net_plan_is_cae(p.args, p.nt) && p.S <= 4 && ((H * W * layers[0].Cin) & 3) == 0;
+}
+
 static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x,
                            const void* params, const float* y_true, float* dpred, float loss_scale, float* partials,
-                           int* n_partials, sv_stream_t stream) {
+                           int* n_partials, sv_stream_t stream, const sv_batch_rows* rows = nullptr) {
     int rc = net_validate(layers, n_layers, N, H, W, who);
     if (rc) return rc;
+    if (rows != nullptr) x = rows->x_batch;
     SV_REQUIRE(x && params, "%s: null tensor", who);
     for (int l = 0; l < n_layers; ++l) SV_REQUIRE(layers[l].y != nullptr, "%s: layer %d has no output buffer", who, l);
     NetPlan p = plan_net_fwd(layers, n_layers, N, H, W);
@@ -1779,8 +1840,11 @@ static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_la
     }
     // one workgroup per pass there: with the loss, the per-workgroup sums must fit the caller's partials buffer
     // (sv_loss_workspace_bytes: 1024 floats)
+    if (rows != nullptr && !(net_rows_ok(p, layers, H, W) && (N + p.S - 1) / p.S <= 1024))
+        return fail(SV_E_UNSUPPORTED, "%s: this layer table does not gather its batch in the launch", who);
     if (net_plan_is_cae(p.args, p.nt) && (y_true == nullptr || (N + p.S - 1) / p.S <= 1024)) {
         NetCaeArgs r{};
+        if (rows != nullptr) r.rows = *rows;
         r.x = p.args.x; r.params = p.args.params; r.N = N;
         r.loss_t = p.args.loss_t; r.loss_dpred = p.args.loss_dpred; r.loss_partials = p.args.loss_partials;
         r.loss_gscale = p.args.loss_gscale;
@@ -1811,6 +1875,28 @@ int sv_convnet_fwd_mse(const sv_net_layer* layers, int n_layers, int N, int H, i
     SV_REQUIRE(y_true && dpred && partials && n_partials, "sv_convnet_fwd_mse: null loss argument");
     return convnet_fwd_any("sv_convnet_fwd_mse", layers, n_layers, N, H, W, x, params, y_true, dpred, loss_scale, partials,
                            n_partials, stream);
+}
+
+int sv_convnet_rows_supported(const sv_net_layer* layers, int n_layers, int N, int H, int W) {
+    if (net_validate(layers, n_layers, N, H, W, "sv_convnet_rows_supported")) return 0;
+    const NetPlan p = plan_net_fwd(layers, n_layers, N, H, W);
+    return p.ok && net_rows_ok(p, layers, H, W) && (N + p.S - 1) / p.S <= 1024 ? 1 : 0;
+}
+
+int sv_convnet_fwd_mse_rows(const sv_net_layer* layers, int n_layers, int N, int H, int W, const sv_batch_rows* rows,
+                            const void* params, const float* y_true, float* dpred, float loss_scale, float* partials,
+                            int* n_partials, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_convnet_fwd_mse_rows");
+    SV_REQUIRE(y_true && dpred && partials && n_partials, "sv_convnet_fwd_mse_rows: null loss argument");
+    SV_REQUIRE(rows && rows->x_rows && rows->row_index && rows->x_batch, "sv_convnet_fwd_mse_rows: null row table");
+    SV_REQUIRE(rows->n_rows > 0 && rows->n_index >= N && rows->batch_stride >= 0,
+               "sv_convnet_fwd_mse_rows: the index list is shorter than the batch");
+    SV_REQUIRE((rows->counter == nullptr) == (rows->counter_base == nullptr),
+               "sv_convnet_fwd_mse_rows: counter and counter_base go together");
+    SV_REQUIRE(((uintptr_t)rows->x_rows % 16 == 0) && ((uintptr_t)rows->x_batch % 16 == 0),
+               "sv_convnet_fwd_mse_rows: tensors must be 16-byte aligned");
+    return convnet_fwd_any("sv_convnet_fwd_mse_rows", layers, n_layers, N, H, W, nullptr, params, y_true, dpred, loss_scale,
+                           partials, n_partials, stream, rows);
 }
 
 size_t sv_convnet_bwd_workspace_bytes(const sv_net_layer* layers, int n_layers, int N, int H, int W, int64_t n_params) {

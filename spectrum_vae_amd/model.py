@@ -102,6 +102,8 @@ class Model(Layer):
         self._chain_cache: Dict[int, object] = {}
         self._slabs_wanted = False   # set around the backward pass of a training step whose optimizer launch can sum slabs
         self._pending_slabs = None   # the table that backward pass left (ops.conv2d_wgrad_batch_slabs)
+        self._rows = None            # set around a training step whose forward launch gathers its own batch (b["rows"])
+        self.gather_in_forward = True
         # Optional: run the weight-gradient kernels, the gradient zero-fill and the optimizer's schedule update on
         # extra HIP streams beside the forward / input-gradient chain (fit / train_on_device_batch only).  Off by
         # default: at the shapes measured so far every conv launch already occupies the LDS of all CUs, so the
@@ -340,7 +342,16 @@ class Model(Layer):
         if plan is False:
             return None
         arr, bufs, h, w = plan
-        if mse is not None and bufs[-1][2] is None and tuple(mse[0].shape) == tuple(bufs[-1][1].shape):
+        if self._rows is not None:
+            # the launch gathers the batch into x (fit / rows_step_supported chose this form for this chain)
+            if not (mse is not None and mse[0] is x and ops.convnet_rows_supported(arr, n, h, w)):
+                raise RuntimeError("the forward launch cannot gather this batch; call rows_step_supported() first")
+            y_true, dpred, partials = mse
+            r = self._rows
+            rows = ops.batch_rows(r["X"], r["index"], x, self.optimizer._ensure_state(x.device), r["base"], r["stride"])
+            cnt = ops.convnet_fwd_mse_rows(arr, n, h, w, rows, self._params, y_true, dpred, 1.0, partials)
+            ctx.loss_fold = (partials, cnt, 1.0 / y_true.numel())
+        elif mse is not None and bufs[-1][2] is None and tuple(mse[0].shape) == tuple(bufs[-1][1].shape):
             y_true, dpred, partials = mse
             cnt = ops.convnet_fwd_mse(arr, n, h, w, x, self._params, y_true, dpred, 1.0, partials)
             ctx.loss_fold = (partials, cnt, 1.0 / y_true.numel())
@@ -501,6 +512,38 @@ class Model(Layer):
         self._reducer = reducer
         self._graphs.clear()
 
+    def rows_step_supported(self, X: torch.Tensor, bs: int, same_xy: bool = True) -> bool:
+        """Whether a training step at batch size ``bs`` can read its batch straight out of the resident float32 tensor
+        ``X`` through a row index (``b["rows"]`` for ``train_on_device_batch``): the one-launch forward with the fused
+        squared-error loss on an autoencoder target, one stream, no gradient reducer, an optimizer with a device-side
+        update count."""
+        if not (self.gather_in_forward and same_xy and X.is_cuda and X.dtype == torch.float32 and self.use_net_fused):
+            return False
+        if self._reducer is not None or self._side_stream() is not None or self._act_dtype != torch.float32:
+            return False
+        if not (type(self.loss) is losses_mod.MeanSquaredError and self.fuse_loss and hasattr(self.optimizer, "_ensure_state")):
+            return False
+        if tuple(X.shape[1:]) != tuple(self.input_shape_) or tuple(self.output_shape_) != tuple(self.input_shape_):
+            return False
+        chain = self._conv_chain()
+        if not chain:
+            return False
+        specs = [dict(Cin=l.input_shape_[2], Cout=l.output_shape_[2], K=3, up=l.up[0], pool=int(l.pool is not None),
+                      act=l.act, alpha=l.alpha, w_off=l.kernel.offset, b_off=l.bias.offset if l.bias is not None else -1,
+                      y=None, idx=None) for l in chain]
+        h, w = chain[0].input_shape_[0], chain[0].input_shape_[1]
+        return chain[-1].pool is None and ops.convnet_rows_supported(ops.net_layers(specs), bs, h, w)
+
+    def step_rows(self, X: torch.Tensor, index: torch.Tensor, stride: int) -> dict:
+        """The ``b["rows"]`` entry for steps that walk ``index`` (int64 rows of ``X``) ``stride`` positions at a time.
+        ``restart_rows`` marks the step about to run as position 0."""
+        base = torch.zeros(1, dtype=torch.int64, device=X.device)
+        return {"X": X, "index": index, "base": base, "stride": int(stride)}
+
+    def restart_rows(self, rows: dict):
+        """The next step reads ``index[0:batch]``: remembers the optimizer's update count (a device-to-device copy)."""
+        rows["base"].copy_(self.optimizer._ensure_state(rows["X"].device)[0:1])
+
     def _step_buffers(self, bs: int, y_shape: tuple):
         p = self._pool
         return {
@@ -549,7 +592,11 @@ class Model(Layer):
         mse = None
         if type(self.loss) is losses_mod.MeanSquaredError and self.fuse_loss and self._act_dtype == torch.float32:
             mse = (yt, b["dpred"], self._pool.get(("fit", "loss_partials"), (ops.loss_workspace_floats(),)))
-        pred = self.forward_raw(b["x"], True, side, mse)
+        self._rows = b.get("rows")
+        try:
+            pred = self.forward_raw(b["x"], True, side, mse)
+        finally:
+            self._rows = None
         fold = self._calls[-1].loss_fold
         extras = self._calls[-1].extra_losses
         if fold is not None:  # loss and its gradient left with the forward launch; the optimizer launch folds the sums
@@ -605,6 +652,9 @@ class Model(Layer):
         with the gradient all-reduce issued between them on the same stream."""
         bs = b["x"].shape[0]
         key = (bs, same_xy, float(weight), id(self.optimizer), id(self.loss), id(self._reducer))
+        if b.get("rows") is not None:
+            r = b["rows"]
+            key += (r["X"].data_ptr(), r["index"].data_ptr(), r["base"].data_ptr(), r["stride"])
         if not (self.use_graphs and self.graph_safe()):
             self._train_step_body(b, same_xy, weight)
             return
@@ -705,8 +755,15 @@ class Model(Layer):
         gen = torch.Generator(device=device)
         gen.manual_seed(self._seed if seed is None else seed)
         y_shape = tuple(Y.shape[1:])
+        # the forward launch gathers its own batch where it can (every batch size of the epoch must take that form)
+        rows = None
+        if shuffle and self.rows_step_supported(X, min(bs, n), same_xy) and (n % bs == 0 or self.rows_step_supported(X, n % bs, same_xy)):
+            rows = self.step_rows(X, torch.empty(n, dtype=torch.int64, device=device), bs)
         for epoch in range(int(epochs)):
             perm = torch.randperm(n, device=device, generator=gen) if shuffle else None
+            if rows is not None:
+                rows["index"].copy_(perm)
+                self.restart_rows(rows)
             acc = None
             for start in range(0, n, bs):
                 cur = min(bs, n - start)
@@ -715,11 +772,14 @@ class Model(Layer):
                     acc = self._pool.get(("fit", "acc"), (1,))
                     ops.fill(acc, 0.0)
                 b["acc"] = acc
-                idx = perm[start:start + cur] if perm is not None else None
-                src_x = X if idx is not None else X[start:start + cur]
-                ops.gather_rows(src_x, idx, b["x"])
-                if not same_xy:
-                    ops.gather_rows(Y if idx is not None else Y[start:start + cur], idx, b["y"])
+                if rows is not None:
+                    b["rows"] = rows
+                else:
+                    idx = perm[start:start + cur] if perm is not None else None
+                    src_x = X if idx is not None else X[start:start + cur]
+                    ops.gather_rows(src_x, idx, b["x"])
+                    if not same_xy:
+                        ops.gather_rows(Y if idx is not None else Y[start:start + cur], idx, b["y"])
                 self.train_on_device_batch(b, same_xy, float(cur))
             logs = {"loss": float(acc.item()) / n}  # one host sync per epoch
             if validation_data is not None:

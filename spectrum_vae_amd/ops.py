@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT, BF16, F32, ConvGeom, GradSlabs, NetLayer, WgradBatchJob, WgradJob, check, lib
+from ._lib import ACT, BF16, F32, BatchRows, ConvGeom, GradSlabs, NetLayer, WgradBatchJob, WgradJob, check, lib
 
 
 def set_option(name: str, value: int):
@@ -210,6 +210,40 @@ def convnet_supported(arr, n: int, h: int, w: int) -> bool:
 
 def convnet_fwd(arr, n: int, h: int, w: int, x, params):
     check(lib.sv_convnet_fwd(arr, len(arr), n, h, w, _ptr(x), _ptr(params), F32, _stream()), "sv_convnet_fwd")
+
+
+def convnet_rows_supported(arr, n: int, h: int, w: int) -> bool:
+    """Whether ``convnet_fwd_mse_rows`` takes this chain (the forward launch gathers its own batch)."""
+    return bool(lib.sv_convnet_rows_supported(arr, len(arr), n, h, w))
+
+
+def batch_rows(x_rows, row_index, x_batch, counter=None, counter_base=None, batch_stride: int = 0) -> BatchRows:
+    """``sv_batch_rows`` over device tensors: ``x_rows`` float32 [rows, ...], ``row_index`` int64 [positions],
+    ``x_batch`` float32 [N, ...] receiving the batch; ``counter`` / ``counter_base``: int64 device scalars (the
+    optimizer's update count and its value at position 0), ``batch_stride`` positions per step."""
+    if x_rows.dtype != torch.float32 or x_batch.dtype != torch.float32 or row_index.dtype != torch.int64:
+        raise TypeError("batch_rows: float32 rows / batch and an int64 index")
+    if x_rows[0].numel() != x_batch[0].numel():
+        raise ValueError("batch_rows: row sizes differ")
+    if (counter is None) != (counter_base is None):
+        raise ValueError("batch_rows: counter and counter_base go together")
+    r = BatchRows()
+    r.x_rows, r.n_rows = _ptr(x_rows), x_rows.shape[0]
+    r.row_index, r.n_index = _ptr(row_index, torch.int64), row_index.numel()
+    r.counter = _ptr(counter, torch.int64) if counter is not None else None
+    r.counter_base = _ptr(counter_base, torch.int64) if counter_base is not None else None
+    r.batch_stride, r.x_batch = int(batch_stride), _ptr(x_batch)
+    return r
+
+
+def convnet_fwd_mse_rows(arr, n: int, h: int, w: int, rows: BatchRows, params, y_true, dpred, loss_scale, partials) -> int:
+    """``convnet_fwd_mse`` on the batch the launch gathers itself (``rows``: see ``batch_rows``)."""
+    if y_true.numel() != dpred.numel() or partials.numel() < loss_workspace_floats():
+        raise ValueError("convnet_fwd_mse_rows: y_true / dpred sizes differ or the partial-sum scratch is too small")
+    cnt = C.c_int(0)
+    check(lib.sv_convnet_fwd_mse_rows(arr, len(arr), n, h, w, C.byref(rows), _ptr(params), _ptr(y_true), _ptr(dpred),
+                                      loss_scale, _ptr(partials), C.byref(cnt), F32, _stream()), "sv_convnet_fwd_mse_rows")
+    return int(cnt.value)
 
 
 def convnet_fwd_mse(arr, n: int, h: int, w: int, x, params, y_true, dpred, loss_scale, partials) -> int:
