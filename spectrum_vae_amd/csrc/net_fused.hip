@@ -71,11 +71,11 @@ struct NetFwdArgs {
     NetLayer L[kMaxNetLayers];
 };
 
-// Staging of the network input through a row index: each sample's row is looked up once per thread (S <= 4 samples a
-// pass), its 16-byte pieces go to the planar LDS image and, as they are, to the gathered batch in global memory.
+// Staging of the network input through a row index, in two halves so that the LDS zero fill runs while the loads are
+// in flight: each sample's row is looked up once per thread (S <= 4 samples a pass, at most U * nt 16-byte pieces), its
+// pieces go to the planar LDS image and, as they are, to the gathered batch in global memory.
 template <int U>
-__device__ __forceinline__ void net_stage_rows(const NetFwdArgs& a, const PlanarSrc& s, const PlanarDst& d, int n0, int ns,
-                                               float* lds, int nt) {
+__device__ __forceinline__ void net_rows_load(const NetFwdArgs& a, const PlanarSrc& s, int n0, int ns, int nt, float4 (&v)[U]) {
     const sv_batch_rows& r = a.rows;
     const int HW = s.Hs * s.Ws, per = (HW * s.C) >> 2;  // 16-byte pieces per sample
     const int units = ns * per;
@@ -89,31 +89,35 @@ __device__ __forceinline__ void net_stage_rows(const NetFwdArgs& a, const Planar
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) row[i] = row[i] < 0 ? 0 : (row[i] >= r.n_rows ? r.n_rows - 1 : row[i]);
-    const FDiv fper = fd_make(per), fC = fd_make(s.C), fHW = fd_make(HW), fW = fd_make(s.Ws);
-    float4* out = reinterpret_cast<float4*>(r.x_batch) + (size_t)n0 * per;
-    for (int u0 = threadIdx.x; u0 < units; u0 += U * nt) {
-        float4 v[U];
+    const FDiv fper = fd_make(per);
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const int u = min(u0 + i * nt, units - 1);
-            const int ss = fd(u, fper), off = u - ss * per;
-            const long long rw = ss == 0 ? row[0] : (ss == 1 ? row[1] : (ss == 2 ? row[2] : row[3]));
-            v[i] = reinterpret_cast<const float4*>(r.x_rows + (size_t)rw * (size_t)(HW * s.C))[off];
-        }
+    for (int i = 0; i < U; ++i) {
+        const int u = min((int)threadIdx.x + i * nt, units - 1);
+        const int ss = fd(u, fper), off = u - ss * per;
+        const long long rw = ss == 0 ? row[0] : (ss == 1 ? row[1] : (ss == 2 ? row[2] : row[3]));
+        v[i] = reinterpret_cast<const float4*>(r.x_rows + (size_t)rw * (size_t)(HW * s.C))[off];
+    }
+}
+template <int U>
+__device__ __forceinline__ void net_rows_store(const NetFwdArgs& a, const PlanarSrc& s, const PlanarDst& d, int n0, int ns,
+                                               float* lds, int nt, const float4 (&v)[U]) {
+    const int HW = s.Hs * s.Ws, per = (HW * s.C) >> 2;
+    const int units = ns * per;
+    const FDiv fC = fd_make(s.C), fHW = fd_make(HW), fW = fd_make(s.Ws);
+    float4* out = reinterpret_cast<float4*>(a.rows.x_batch) + (size_t)n0 * per;
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const int u = u0 + i * nt;
-            if (u < units) {
-                out[u] = v[i];
-                const float xv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    for (int i = 0; i < U; ++i) {
+        const int u = threadIdx.x + i * nt;
+        if (u < units) {
+            out[u] = v[i];
+            const float xv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int e = 4 * u + t;
-                    const int p = fd(e, fC), c = e - p * s.C;
-                    const int ss = fd(p, fHW), pp = p - ss * HW;
-                    const int rr = fd(pp, fW), col = pp - rr * s.Ws;
-                    stage_put<0>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, rr, col, xv[t], 0.f, 0u);
-                }
+            for (int t = 0; t < 4; ++t) {
+                const int e = 4 * u + t;
+                const int p = fd(e, fC), c = e - p * s.C;
+                const int ss = fd(p, fHW), pp = p - ss * HW;
+                const int rr = fd(pp, fW), col = pp - rr * s.Ws;
+                stage_put<0>(s, d, lds + (size_t)(ss * d.cpl + c) * d.plane, rr, col, xv[t], 0.f, 0u);
             }
         }
     }
@@ -798,17 +802,20 @@ __device__ __forceinline__ void net_fwd_run(const NetFwdArgs& a, LayerOf layer, 
             const NetLayer& L = layer(0);
             net_w_load<K>(a, L, wpre, bpre, nt);
             NET_MARK(23);
+            PlanarSrc src;
+            src.x = a.x; src.zy = nullptr; src.zidx = nullptr; src.mode = 0; src.zk = ActGradCoef{};
+            src.Hs = L.Hs; src.Ws = L.Ws; src.C = L.Cin;
+            const PlanarDst dst{L.Cin, L.in_plane, L.in_wp, L.in_halo};
+            const bool rows = a.rows.row_index != nullptr;
+            float4 xin[8];  // the gathered input on its way in while the arenas are cleared
+            if (rows) net_rows_load<8>(a, src, n0, ns, nt, xin);
             __syncthreads();  // the previous pass is done with every arena
             net_zero(smem + L.in_off, a.S * L.Cin * L.in_plane, nt);
             net_zero(smem + L.out_off, a.S * L.Cout * L.out_plane, nt);
             __syncthreads();
             NET_MARK(24);
-            PlanarSrc src;
-            src.x = a.x; src.zy = nullptr; src.zidx = nullptr; src.mode = 0; src.zk = ActGradCoef{};
-            src.Hs = L.Hs; src.Ws = L.Ws; src.C = L.Cin;
-            const PlanarDst dst{L.Cin, L.in_plane, L.in_wp, L.in_halo};
             // 8 pieces per thread in flight: the 32 x 32 x 3 input of two samples arrives in one global round trip
-            if (a.rows.row_index != nullptr) net_stage_rows<8>(a, src, dst, n0, ns, smem + L.in_off, nt);
+            if (rows) net_rows_store<8>(a, src, dst, n0, ns, smem + L.in_off, nt, xin);
             else stage_pass_m<0, 8>(src, dst, make_stage_job(src, n0, ns, 0, L.Cin), smem + L.in_off, nt);
             NET_MARK(25);
             net_w_store<K>(a, L, wpre, bpre, w_lds, nt);
@@ -1806,7 +1813,8 @@ int sv_convnet_supported(const sv_net_layer* layers, int n_layers, int N, int H,
 // whether the launch can gather its batch through a row index: the kernel built for the default stack, whole 16-byte
 // pieces per sample, at most four samples a pass
 static bool net_rows_ok(const NetPlan& p, const sv_net_layer* layers, int H, int W) {
-    return net_plan_is_cae(p.args, p.nt) && p.S <= 4 && ((H * W * layers[0].Cin) & 3) == 0;
+    return net_plan_is_cae(p.args, p.nt) && p.S <= 4 && ((H * W * layers[0].Cin) & 3) == 0 &&
+           p.S * ((H * W * layers[0].Cin) >> 2) <= 8 * 256;  // the pieces of a pass fit the registers of one load batch
 }
 
 static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x,

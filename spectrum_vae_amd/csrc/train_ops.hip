@@ -296,12 +296,10 @@ __global__ __launch_bounds__(1024) void adam_slabs_k(AdamSlabArgs a) {
     if (a.fold.partials != nullptr && blockIdx.x == gridDim.x - 1)
         fold_scalar_256(a.fold.partials, a.fold.n, a.fold.scale, a.fold.out, a.fold.accumulate, a.fold.running,
                         a.fold.running_weight);
+    // The schedule (one thread) and the element's parameter / moment loads do not depend on the slab sums: they are
+    // issued first, so the launch is two global round trips deep (slabs beside state, then the stores), not four.
     const int64_t it = a.state[0];
-    if (threadIdx.x == 0) adam_schedule(it, a.lr0, a.beta1, a.beta2, a.decay_steps, a.decay_rate, a.staircase, alpha_s, lr_s);
-    __syncthreads();
-    const float alpha = alpha_s;
-    auto update = [&](int64_t i, float g) {
-        float th = a.theta[i], mi = a.m[i], vi = a.v[i];
+    auto apply = [&](int64_t i, float th, float mi, float vi, float g, float alpha) {
         adam_update1(th, mi, vi, g, alpha, a.beta1, a.beta2, a.eps, a.grad_scale);
         a.m[i] = mi;
         a.v[i] = vi;
@@ -321,6 +319,9 @@ __global__ __launch_bounds__(1024) void adam_slabs_k(AdamSlabArgs a) {
         const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
         const int e = ((int)blockIdx.x - a.first[j]) * 64 + lane;
         const int ne = q.n_dw + q.n_db;
+        const int64_t i = e >= ne ? -1 : (e < q.n_dw ? q.w_at + e : (q.b_at >= 0 ? q.b_at + (e - q.n_dw) : -1));
+        float th = 0.f, mi = 0.f, vi = 0.f, g0 = 0.f;
+        if (grp == 0 && i >= 0) { th = a.theta[i]; mi = a.m[i]; vi = a.v[i]; g0 = a.grad[i]; }
         float s = 0.f;
         if (e < ne) {
             int sp = grp;
@@ -334,24 +335,25 @@ __global__ __launch_bounds__(1024) void adam_slabs_k(AdamSlabArgs a) {
             for (; sp < q.n_split; sp += 16) s += q.slab[(size_t)sp * q.slab_floats + e];
         }
         red[grp][lane] = s;
+        if (threadIdx.x == 0) adam_schedule(it, a.lr0, a.beta1, a.beta2, a.decay_steps, a.decay_rate, a.staircase, alpha_s, lr_s);
         __syncthreads();
-        if (grp == 0 && e < ne) {
-            const int64_t i = e < q.n_dw ? q.w_at + e : (q.b_at >= 0 ? q.b_at + (e - q.n_dw) : -1);
-            if (i >= 0) {
-                float t = a.grad[i];
+        if (grp == 0 && i >= 0) {
+            float t = g0;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) t += red[g][lane];
-                update(i, t);
-            }
+            for (int g = 0; g < 16; ++g) t += red[g][lane];
+            apply(i, th, mi, vi, t, alpha_s);
         }
     } else {
+        if (threadIdx.x == 0) adam_schedule(it, a.lr0, a.beta1, a.beta2, a.decay_steps, a.decay_rate, a.staircase, alpha_s, lr_s);
+        __syncthreads();
+        const float alpha = alpha_s;
         const int64_t total = a.gap_first[a.n_gaps];
         const int64_t stride = (int64_t)(gridDim.x - a.rest_first) * 1024;
         for (int64_t p = (int64_t)((int)blockIdx.x - a.rest_first) * 1024 + threadIdx.x; p < total; p += stride) {
             int k = 0;
             while (k + 1 < a.n_gaps && p >= a.gap_first[k + 1]) ++k;
             const int64_t i = a.gap_at[k] + (p - a.gap_first[k]);
-            update(i, a.grad[i]);
+            apply(i, a.theta[i], a.m[i], a.v[i], a.grad[i], alpha);
         }
     }
     __syncthreads();

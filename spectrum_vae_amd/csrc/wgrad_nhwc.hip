@@ -85,6 +85,11 @@ struct WnRegs {
     uint32_t pk[kWnUnits];
 };
 
+// Floats from one row of the S image to the next.  With 3 channels a 16-row tile reads two kernel rows of the image in
+// one LDS cycle; a pitch of 16 (mod 32) floats puts them on disjoint banks (102 floats, the packed pitch of a 34-pixel
+// row, overlaps them on three).
+constexpr int wn_rps(int CS, int WO) { return CS == 3 ? ((WO + 2) * 3 + 31 - 16) / 32 * 32 + 16 : (WO + 2) * CS; }
+
 template <int CS, int CP, int SWAP, int WO>
 __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int gx) {
     constexpr int M = 9 * CS, MT = (M + 15) / 16, NT = (CP + 15) / 16, NTILE = MT * NT;
@@ -95,8 +100,8 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int Ho = a.Ho;
-    constexpr int Wo = WO, SW = WO + 2;
-    const int sampleS = (Ho + 2) * SW * CS;
+    constexpr int Wo = WO, RPS = wn_rps(CS, WO);
+    const int sampleS = (Ho + 2) * RPS;
     const int pshift = (SWAP && a.up == 2) ? 1 : 0;            // P = x kept at its stored resolution
     const int PH = SWAP ? a.Hs : Ho, PW = SWAP ? a.Ws : Wo;
     (void)PW;
@@ -156,7 +161,7 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
             const int p = (e + t) / CS, c = (e + t) - p * CS;
             const int ss = fd(p, f_shw), pp = p - ss * (Ho * Wo);
             const int row = fd(pp, f_sw), col = pp - row * Wo;
-            s_at[i][t] = ss * sampleS + ((row + 1) * SW + col + 1) * CS + c;
+            s_at[i][t] = ss * sampleS + (row + 1) * RPS + (col + 1) * CS + c;
         }
         if (SWAP || pz != 2) {
             p_at[i] = e;  // the image is the tensor
@@ -212,9 +217,9 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 16 + li;
-        const int mm = m < M ? m : 0;
+        const int mm = m < M ? m : M - 1;  // unused rows read what the last used row reads (a broadcast, not a bank conflict)
         const int kh = mm / (3 * CS), r = mm - kh * 3 * CS;
-        aoff[mt] = kh * SW * CS + r + lk * CS;
+        aoff[mt] = kh * RPS + r + lk * CS;
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) boff[nt] = (lk >> pshift) * CP + nt * 16 + li;
@@ -260,7 +265,7 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
             float av0[QX][MT], bv0[QX][NT], av1[QX][MT], bv1[QX][NT];
             auto load_row = [&](float (&av)[QX][MT], float (&bv)[QX][NT], int r) {
                 const int ss = r >> hq_log, oh = wave + 4 * (r & hq_mask);
-                const float* sq = s_lds + ss * sampleS + oh * (SW * CS);
+                const float* sq = s_lds + ss * sampleS + oh * RPS;
                 const float* pq = p_lds + ss * sampleP + (oh >> PS) * (PWc * CP);
 #pragma unroll
                 for (int q = 0; q < QX; ++q) {
@@ -721,7 +726,7 @@ static WnPlan plan_wn(const sv_wgrad_batch_job& q) {
     // an upsampled layer in the stored-pixel form: the stored image holds whole groups of 4 rows, a power of two of them
     const bool sp = swap == 1 && up == 2 && opt(OPT_WGRAD_STORED) != 0 && (Hs & 3) == 0 && (Hs & (Hs - 1)) == 0;
     if (sp) p.hq_log = __builtin_ctz(Hs);
-    const int64_t sampleS = (int64_t)(Ho + 2) * (Wo + 2) * (sp ? wn_sp_ps(cs) : cs);
+    const int64_t sampleS = sp ? (int64_t)(Ho + 2) * (Wo + 2) * wn_sp_ps(cs) : (int64_t)(Ho + 2) * wn_rps(cs, Wo);
     const int64_t sampleP = sp ? (int64_t)Hs * Ws * wn_sp_pps(cp) : (swap ? (int64_t)Hs * Ws * cp : (int64_t)Ho * Wo * cp);
     const int64_t s_units = (int64_t)Ho * Wo * cs / 4;
     const int64_t p_units = (swap ? (int64_t)Hs * Ws * cp : (zmode == 2 ? (int64_t)(Ho / 2) * (Wo / 2) * cp : (int64_t)Ho * Wo * cp)) / 4;
