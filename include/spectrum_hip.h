@@ -165,16 +165,6 @@ int sv_convnet_fwd_mse_rows(const sv_net_layer* layers, int n_layers, int N, int
                             const void* params, const float* y_true, float* dpred, float loss_scale, float* partials,
                             int* n_partials, int dtype, sv_stream_t stream);
 
-/* ---- Whole-network backward of the same chain (the gradient tape of run_model.py:281-289 / `model.fit`): given
- *      dpred = dL/d(output of the last layer) and the y / idx tensors sv_convnet_fwd wrote, grads (+)= the gradient of
- *      every filter and bias, laid out like params (n_params floats, a multiple of 4).  The per-layer gradients with
- *      respect to activations stay on chip.  Partial sums of the workgroups go through the caller's workspace
- *      (sv_convnet_bwd_workspace_bytes; 0 = chain not supported) and are summed in a fixed order (bit-reproducible). */
-size_t sv_convnet_bwd_workspace_bytes(const sv_net_layer* layers, int n_layers, int N, int H, int W, int64_t n_params);
-int sv_convnet_bwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
-                   const void* dpred, void* grads, int64_t n_params, int accumulate, void* workspace,
-                   size_t workspace_bytes, int dtype, sv_stream_t stream);
-
 /* ---- The kernel/bias-gradient half of sv_conv2d_bwd in two steps, so that the reductions of all layers of one backward
  *      pass (the gradient tape of run_model.py:281-289) run as ONE launch: sv_conv2d_bwd_partial leaves per-workgroup
  *      partial sums in `workspace` (sv_conv2d_wgrad_workspace_bytes(g); one workspace per layer until the finish),

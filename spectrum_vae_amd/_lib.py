@@ -90,8 +90,6 @@ SIGNATURES = {
     "sv_convnet_rows_supported": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i]),
     "sv_convnet_fwd_mse_rows": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, C.POINTER(BatchRows), _p, _p, _p, _f, _p,
                                      C.POINTER(C.c_int), _i, _p]),
-    "sv_convnet_bwd_workspace_bytes": (_sz, [C.POINTER(NetLayer), _i, _i, _i, _i, _i64]),
-    "sv_convnet_bwd": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, _p, _p, _p, _i64, _i, _p, _sz, _i, _p]),
     "sv_conv2d_bwd_partial": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p, _sz, _i, _p]),
     "sv_conv2d_wgrad_finish": (_i, [C.POINTER(WgradJob), _i, _i, _p]),
     "sv_conv2d_wgrad_batch": (_i, [C.POINTER(WgradBatchJob), _i, _i, _i, _p]),

@@ -1200,601 +1200,6 @@ static int net_enable_lds(size_t bytes) {
     return SV_OK;
 }
 
-
-// =====================================================================================================================
-// Whole-network backward.  One workgroup carries ONE sample at a time through all layers, last to first; the gradient
-// with respect to each conv output (dz) never leaves LDS.  Step of layer l:
-//   staged from global: the layer's input activation a (+ the argmax bytes of the pooling that produced it) and the
-//     layer's filters, mirrored and with the channel roles swapped;
-//   dgrad (l > 0): dx = conv(dz_l, mirrored filters) with the register-tile FMA loop, then - still in registers -
-//     the 2x2 sum of a folded upsampling, the derivative of the previous activation, and the scatter to the argmax
-//     slot of a folded pooling: the result IS dz_{l-1}, written to LDS in the layout the next step reads;
-//   wgrad: a thread owns (input channel, CO_T output channels, one kernel row) and a share of the pixel strips; partial
-//     sums are folded across the strip shares by wave shuffles and added to this workgroup's slab (laid out like the
-//     flat parameter buffer), which a final kernel sums over workgroups in a fixed order (no float atomics).
-// LDS: dz_l and dz_{l-1} sit at opposite ends of one arena, the staged activation and filters between them.
-struct NetBwdLayer {
-    int Cin, Cout, Hs, Ws, up, pool, act;
-    float alpha;
-    int w_off, b_off;
-    int g_off, g_plane, g_wp;        // dz of this layer's conv output: planar [Cout][Ho + 2][g_wp] (+4), halo 1
-    int a_off, a_plane, a_wp;        // staged input activation: planar [Cin][Hs + 2][a_wp] (+4), halo 1
-    int aidx_off;                    // argmax bytes [Hs][Ws][Cin] of the pooling that produced the input (float offset)
-    int wl_off;                      // mirrored filters [tile over Cin][Cout][tap][d_co_t]
-    int prev_pool, prev_act;         // the layer that produced the input activation (prev_act < 0: none, l == 0)
-    float prev_alpha;
-    int d_co_t, d_n_cot, d_ks;       // dgrad tiling over Cin
-    int w_co_t, w_n_cot, w_pg;       // wgrad tiling over Cout, strip shares (vector path)
-    int w_mfma;                      // 1: wgrad on the matrix cores (tiles fit the per-wave budget)
-    const float* a_in;               // global: input activation [N][Hs][Ws][Cin]
-    const uint8_t* a_idx;            // global: argmax of the producing pooling, or null
-};
-struct NetBwdArgs {
-    const float* params;
-    const float* dpred;   // dL/d(output) [N][Ho][Wo][Cout] of the last layer
-    const float* y_last;  // output of the last layer (its activation derivative is applied here)
-    float* slab;          // [gridDim.x][n_params]
-    int N, n_layers, n_params, arena_floats;
-    NetBwdLayer L[kMaxNetLayers];
-};
-
-// ---- dgrad of one layer: dz_l (LDS) -> dz_{l-1} (LDS)
-template <int K, int LUP, int CO_T>
-__device__ __forceinline__ void net_layer_dgrad(const NetBwdArgs& a, const NetBwdLayer& L, const NetBwdLayer& Lp, float* smem,
-                                                int nt) {
-    constexpr int PADL = (K - 1) / 2;
-    const int Ho = L.Hs * L.up, Wo = L.Ws * L.up;  // dz_l extent; the conv of dz runs at this extent (UP = 1 indexing)
-    const int tiles_x = Wo >> 1, tiles_y = Ho >> 1;
-    const int T = tiles_x * tiles_y;
-    const int ks = L.d_ks;
-    const int per_cot = T * ks;
-    const int total = L.d_n_cot * per_cot;
-    const float* g = smem + L.g_off;
-    const float* act_in = smem + L.a_off;
-    const uint8_t* aidx = reinterpret_cast<const uint8_t*>(smem + L.aidx_off);
-    float* gp = smem + Lp.g_off;
-    const float* w_lds = smem + L.wl_off;
-    const FDiv f_percot = fd_make(per_cot), f_ks = fd_make(ks), f_tx = fd_make(tiles_x);
-    const ActGradCoef zk = act_grad_coef_dev(L.prev_act, L.prev_alpha);
-
-    for (int item0 = 0; item0 < total; item0 += nt) {
-        const int item = item0 + threadIdx.x;
-        const bool live = item < total;
-        int cot = 0, ty = 0, tx = 0, kl = 0;
-        if (live) {
-            cot = fd(item, f_percot);
-            const int r = item - cot * per_cot;
-            const int t = fd(r, f_ks);
-            kl = r - t * ks;
-            ty = fd(t, f_tx);
-            tx = t - ty * tiles_x;
-        }
-        float acc[2][2][CO_T];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int c = 0; c < CO_T; ++c) acc[i][j][c] = 0.f;
-        if (live)
-            conv_tile_fma<K, 1, CO_T>(acc, g, w_lds + cot * L.Cout * K * K * CO_T, L.g_plane, L.g_wp, 2 * ty + 1 - PADL,
-                                      2 * tx + 1 - PADL, kl, L.Cout, ks);
-        for (int o = 1; o < ks; o <<= 1) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < CO_T; ++q) acc[i][j][q] += __shfl_xor(acc[i][j][q], o, 64);
-        }
-        if (live && kl == 0) {
-            const int cg = cot * CO_T;
-#pragma unroll
-            for (int q = 0; q < CO_T; ++q) {
-                const int c = cg + q;
-                if (c >= L.Cin) continue;
-                const float* ap = act_in + (size_t)c * L.a_plane;
-                float* gq = gp + (size_t)c * Lp.g_plane;
-                if (LUP == 2) {
-                    // the 2x2 tile is one stored pixel: gradient of the folded nearest upsampling = the sum
-                    const float dy = (acc[0][0][q] + acc[0][1][q]) + (acc[1][0][q] + acc[1][1][q]);
-                    const float v = dy * act_grad_q(ap[(ty + 1) * L.a_wp + tx + 1], zk);
-                    if (!L.prev_pool) {
-                        gq[(ty + 1) * Lp.g_wp + tx + 1] = v;
-                    } else {
-                        const int k = aidx[(ty * L.Ws + tx) * L.Cin + c];
-                        float* o = gq + (2 * ty + 1) * Lp.g_wp + 2 * tx + 1;
-                        o[0] = k == 0 ? v : 0.f; o[1] = k == 1 ? v : 0.f;
-                        o[Lp.g_wp] = k == 2 ? v : 0.f; o[Lp.g_wp + 1] = k == 3 ? v : 0.f;
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int py = 2 * ty + i, px = 2 * tx + j;
-                            const float v = acc[i][j][q] * act_grad_q(ap[(py + 1) * L.a_wp + px + 1], zk);
-                            if (!L.prev_pool) {
-                                gq[(py + 1) * Lp.g_wp + px + 1] = v;
-                            } else {
-                                const int k = aidx[(py * L.Ws + px) * L.Cin + c];
-                                float* o = gq + (2 * py + 1) * Lp.g_wp + 2 * px + 1;
-                                o[0] = k == 0 ? v : 0.f; o[1] = k == 1 ? v : 0.f;
-                                o[Lp.g_wp] = k == 2 ? v : 0.f; o[Lp.g_wp + 1] = k == 3 ? v : 0.f;
-                            }
-                        }
-                }
-            }
-        }
-    }
-}
-
-// ---- wgrad of one layer: sums over the pixels of the sample in LDS, added to the workgroup's slab
-// Strips are 4 output pixels wide and start one pixel LEFT of a multiple of 4 so that the dz reads are 16-byte aligned
-// inside the halo-1 layout (the extra first pixel of a row is halo: zero).
-template <int K, int UP, int CO_T>
-__device__ __forceinline__ void net_layer_wgrad(const NetBwdArgs& a, const NetBwdLayer& L, float* smem, float* slab, int nt) {
-    static_assert(K == 3, "kernel rows are spread over threads for 3x3 filters");
-    const int Ho = L.Hs * UP, Wo = L.Ws * UP;
-    const int PG = L.w_pg;
-    const int combos = L.Cin * L.w_n_cot;
-    const int t = threadIdx.x;
-    const int pg = t & (PG - 1);
-    const int r = t / PG;  // PG is a power of two
-    const int kh = r % K, combo = r / K;
-    const bool live = combo < combos;
-    const int ci = live ? combo / L.w_n_cot : 0;
-    const int cot = live ? combo - ci * L.w_n_cot : 0;
-    const int spr = (Wo >> 2) + 1;  // strips per row
-    const int nstrips = Ho * spr;
-    const FDiv f_spr = fd_make(spr);
-    const float* g = smem + L.g_off + (size_t)cot * CO_T * L.g_plane;
-    const float* xa = smem + L.a_off + (size_t)ci * L.a_plane;
-
-    // accumulators as (even pixel, odd pixel) pairs: two independent chains per filter tap, one v_pk_fma_f32 per pair
-    v2f acc2[K][CO_T];
-    float accb[CO_T];
-#pragma unroll
-    for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-        for (int q = 0; q < CO_T; ++q) acc2[kw][q] = v2f{0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < CO_T; ++q) accb[q] = 0.f;
-    const bool do_bias = live && ci == 0 && kh == 0 && L.b_off >= 0;
-    // the owner lane's slab entries: loaded now, so the round trip hides behind the strip loop
-#ifdef SV_EXP_NOSLAB
-    const bool owner = live && pg == 0 && a.N < 0;
-#else
-    const bool owner = live && pg == 0;
-#endif
-    const int co0 = cot * CO_T;
-    float sl[K][CO_T], slb[CO_T];
-    if (owner) {
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-            const float* o = slab + L.w_off + ((size_t)(kh * K + kw) * L.Cin + ci) * L.Cout + co0;
-#pragma unroll
-            for (int q = 0; q < CO_T; ++q) sl[kw][q] = co0 + q < L.Cout ? o[q] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < CO_T; ++q) slb[q] = (do_bias && co0 + q < L.Cout) ? slab[L.b_off + co0 + q] : 0.f;
-    }
-
-    if (live) {
-#pragma unroll 2
-        for (int w = pg; w < nstrips; w += PG) {
-            const int oh = fd(w, f_spr);
-            const int ow0 = (w - oh * spr) << 2;  // stored column of the strip's first pixel (logical column ow0 - 1)
-            const int lr = oh + kh - 1;           // logical input row of this kernel row
-            float xv[6];                          // logical input columns ow0 - 2 .. ow0 + 3
-            if (UP == 1) {
-                const float* xp = xa + (lr + 1) * L.a_wp + ow0;
-                const float4 v4 = *reinterpret_cast<const float4*>(xp);
-                xv[0] = xp[-1]; xv[1] = v4.x; xv[2] = v4.y; xv[3] = v4.z; xv[4] = v4.w; xv[5] = xp[4];
-            } else {
-                const float* xp = xa + ((lr >> 1) + 1) * L.a_wp + (ow0 >> 1);
-                const float2 v2 = *reinterpret_cast<const float2*>(xp);
-                const float v3 = xp[2];
-                xv[0] = v2.x; xv[1] = v2.x; xv[2] = v2.y; xv[3] = v2.y; xv[4] = v3; xv[5] = v3;
-            }
-            const float* zp = g + (oh + 1) * L.g_wp + ow0;
-            v2f z01[CO_T], z23[CO_T];
-#pragma unroll
-            for (int q = 0; q < CO_T; ++q) {
-                const float4 v4 = *reinterpret_cast<const float4*>(zp + q * L.g_plane);
-                z01[q] = v2f{v4.x, v4.y};
-                z23[q] = v2f{v4.z, v4.w};
-            }
-            if (do_bias) {
-#pragma unroll
-                for (int q = 0; q < CO_T; ++q) accb[q] += (z01[q].x + z01[q].y) + (z23[q].x + z23[q].y);
-            }
-            // input pairs (x[c], x[c + 1]) for c = 0..4: tap kw multiplies pixels j, j + 1 with x[kw + j], x[kw + j + 1]
-            v2f xp2[5];
-#pragma unroll
-            for (int c = 0; c < 5; ++c) xp2[c] = v2f{xv[c], xv[c + 1]};
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                for (int q = 0; q < CO_T; ++q) {
-                    acc2[kw][q] = __builtin_elementwise_fma(xp2[kw], z01[q], acc2[kw][q]);
-                    acc2[kw][q] = __builtin_elementwise_fma(xp2[kw + 2], z23[q], acc2[kw][q]);
-                }
-        }
-    }
-    float acc[K][CO_T];
-#pragma unroll
-    for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-        for (int q = 0; q < CO_T; ++q) acc[kw][q] = acc2[kw][q].x + acc2[kw][q].y;
-    // fold the strip shares (adjacent lanes), then the owner lane adds to the slab
-#ifdef SV_EXP_NOFOLD
-    for (int o = 1; o < PG && a.N < 0; o <<= 1) {
-#else
-    for (int o = 1; o < PG; o <<= 1) {
-#endif
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-            for (int q = 0; q < CO_T; ++q) acc[kw][q] += __shfl_xor(acc[kw][q], o, 64);
-#pragma unroll
-        for (int q = 0; q < CO_T; ++q) accb[q] += __shfl_xor(accb[q], o, 64);
-    }
-    if (owner) {
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-            float* o = slab + L.w_off + ((size_t)(kh * K + kw) * L.Cin + ci) * L.Cout + co0;
-#pragma unroll
-            for (int q = 0; q < CO_T; ++q)
-                if (co0 + q < L.Cout) o[q] = sl[kw][q] + acc[kw][q];
-        }
-        if (do_bias) {
-#pragma unroll
-            for (int q = 0; q < CO_T; ++q)
-                if (co0 + q < L.Cout) slab[L.b_off + co0 + q] = slb[q] + accb[q];
-        }
-    }
-}
-
-// ---- wgrad on the matrix cores: dW[(tap, ci)][co] = sum over pixels of X[(tap, ci)][pixel] * dZ[pixel][co] as
-// 16x16x4 f32 MFMA tiles (exact f32 arithmetic; M = 9*Cin + 1: the extra row of ones yields the bias gradient,
-// N = Cout, K = 4 consecutive pixels of a row per instruction).  The tiles are dealt round-robin to the four waves;
-// each wave walks ALL pixels of the sample for its tiles, so nothing is folded across threads, and the finished tile
-// is added to the workgroup's slab (entries prefetched before the pixel loop).
-// Lane l feeds A[row l % 16][k l / 16] and B[k l / 16][col l % 16] and receives D[row 4 * (l / 16) + r][col l % 16].
-typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kWgTiles = 5;  // tiles per wave
-
-template <int K, int UP, int NS>
-__device__ __forceinline__ void net_wgrad_mfma_ns(const NetBwdArgs& a, const NetBwdLayer& L, float* smem, float* slab) {
-    constexpr int U = 4;  // pixel strips per unrolled iteration: U * NS independent LDS-read -> MFMA chains in flight
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int Ho = L.Hs * UP, Wo = L.Ws * UP;
-    const int M = K * K * L.Cin;
-    const int NT = (L.Cout + 15) >> 4;
-    const float* xa = smem + L.a_off;
-    const float* g = smem + L.g_off;
-    const FDiv fNT = fd_make(NT), fCin = fd_make(L.Cin), fK = fd_make(K);
-
-    v4f acc[NS];
-    int xb[NS], zb[NS], khm[NS], kwm[NS];
-    float amul[NS], aadd[NS], bmul[NS];
-    float sl[NS][4];
-    int so[NS][4];  // slab offset of D[4 * lk + r][li], -1: nothing to add
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int t = wave + 4 * s;
-        const int mt = fd(t, fNT), nt = t - mt * NT;
-        const int m = mt * 16 + li;
-        const bool is_w = m < M;
-        const int tap = is_w ? fd(m, fCin) : 0, ci = is_w ? m - tap * L.Cin : 0;
-        const int kh = fd(tap, fK), kw = tap - kh * K;
-        khm[s] = kh - 1; kwm[s] = kw - 1;
-        xb[s] = UP == 1 ? ci * L.a_plane + kh * L.a_wp + kw : ci * L.a_plane;
-        amul[s] = is_w ? 1.f : 0.f;          // padded rows contribute nothing ...
-        aadd[s] = m == M ? 1.f : 0.f;        // ... except the row of ones behind the filter rows
-        const int n = nt * 16 + li;
-        const bool b_ok = n < L.Cout;
-        zb[s] = (b_ok ? n : 0) * L.g_plane + L.g_wp + 1 + lk;
-        bmul[s] = b_ok ? 1.f : 0.f;
-        acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int mr = mt * 16 + 4 * lk + r;
-            int o = -1;
-            if (b_ok) {
-                if (mr < M) o = L.w_off + mr * L.Cout + n;
-                else if (mr == M && L.b_off >= 0) o = L.b_off + n;
-            }
-            so[s][r] = o;
-            sl[s][r] = o >= 0 ? slab[o] : 0.f;
-        }
-    }
-#ifdef SV_EXP_MARKS
-    if (L.Cin == 16 && L.Cout == 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); NET_MARK(24); asm volatile("" ::: "memory"); }
-#endif
-    for (int oh = 0; oh < Ho; ++oh) {
-        const int rowz = oh * L.g_wp;
-        const int rowx = oh * L.a_wp + lk;
-        for (int c0 = 0; c0 < Wo; c0 += 4 * U) {
-            float av[U][NS], bv[U][NS];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + 4 * u;  // first pixel of the strip (wave-uniform)
-                const bool on = c < Wo;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    int xi;
-                    if (UP == 1) xi = xb[s] + rowx + c;
-                    else xi = xb[s] + (((oh + khm[s]) >> 1) + 1) * L.a_wp + ((c + lk + kwm[s]) >> 1) + 1;
-                    av[u][s] = on ? xa[xi] : 0.f;
-                    bv[u][s] = on ? g[zb[s] + rowz + c] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaf(av[u][s], amul[s], aadd[s]), bv[u][s] * bmul[s], acc[s], 0, 0, 0);
-        }
-    }
-#ifdef SV_EXP_MARKS
-    if (L.Cin == 16 && L.Cout == 32) { asm volatile("s_nop 0" : "+v"(acc[0]) :: "memory"); NET_MARK(25); asm volatile("" ::: "memory"); }
-#endif
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (so[s][r] >= 0) slab[so[s][r]] = sl[s][r] + acc[s][r];
-#ifdef SV_EXP_MARKS
-    if (L.Cin == 16 && L.Cout == 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); NET_MARK(26); asm volatile("" ::: "memory"); }
-#endif
-}
-
-template <int K, int UP>
-__device__ __forceinline__ void net_layer_wgrad_mfma(const NetBwdArgs& a, const NetBwdLayer& L, float* smem, float* slab) {
-    const int wave = threadIdx.x >> 6;
-    const int tiles = ((K * K * L.Cin + 1 + 15) >> 4) * ((L.Cout + 15) >> 4);
-    const int ns = wave < tiles ? (tiles - wave + 3) >> 2 : 0;  // tiles wave, wave + 4, ... (wave-uniform)
-    switch (ns) {
-        case 1: net_wgrad_mfma_ns<K, UP, 1>(a, L, smem, slab); break;
-        case 2: net_wgrad_mfma_ns<K, UP, 2>(a, L, smem, slab); break;
-        case 3: net_wgrad_mfma_ns<K, UP, 3>(a, L, smem, slab); break;
-        case 4: net_wgrad_mfma_ns<K, UP, 4>(a, L, smem, slab); break;
-        case 5: net_wgrad_mfma_ns<K, UP, 5>(a, L, smem, slab); break;
-        default: break;
-    }
-}
-
-__device__ __forceinline__ void lds_zero(float* p, int floats, int nt) {
-    float4* z = reinterpret_cast<float4*>(p);
-    for (int i = threadIdx.x; i < (floats >> 2); i += nt) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// mirrored filters of layer L for its dgrad: tile over Cin, channel index over Cout
-template <int K>
-__device__ __forceinline__ void net_wflip_stage(const NetBwdArgs& a, const NetBwdLayer& L, float* smem, int nt) {
-    const float* w = a.params + L.w_off;
-    float* w_lds = smem + L.wl_off;
-    if ((L.Cout & 3) == 0 && (L.w_off & 3) == 0) {
-        const int c4n = L.Cout >> 2;
-        const int units = K * K * L.Cin * c4n;
-        const FDiv f4 = fd_make(c4n), fCin = fd_make(L.Cin);
-#pragma unroll 4
-        for (int u = threadIdx.x; u < units; u += nt) {
-            const int r = fd(u, f4), c4 = u - r * c4n;
-            const int tap = fd(r, fCin), ci = r - tap * L.Cin;
-            const float4 v = *reinterpret_cast<const float4*>(w + ((size_t)tap * L.Cin + ci) * L.Cout + 4 * c4);
-            const int mt = K * K - 1 - tap;
-            const int st = K * K * L.d_co_t;
-            float* q = w_lds + (L.d_co_t == 8 ? w_lds_index<K, 8>(ci, 4 * c4, mt, L.Cout) : w_lds_index<K, 4>(ci, 4 * c4, mt, L.Cout));
-            q[0] = v.x; q[st] = v.y; q[2 * st] = v.z; q[3 * st] = v.w;
-        }
-    } else {
-        const int units = K * K * L.Cin * L.Cout;
-        const FDiv fC = fd_make(L.Cout), fCin = fd_make(L.Cin);
-#pragma unroll 4
-        for (int u = threadIdx.x; u < units; u += nt) {
-            const int r = fd(u, fC), co = u - r * L.Cout;
-            const int tap = fd(r, fCin), ci = r - tap * L.Cin;
-            const int mt = K * K - 1 - tap;
-            w_lds[L.d_co_t == 8 ? w_lds_index<K, 8>(ci, co, mt, L.Cout) : w_lds_index<K, 4>(ci, co, mt, L.Cout)] = w[u];
-        }
-    }
-}
-
-template <int K>
-__global__ __launch_bounds__(256, 2) void net_bwd_s1(NetBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nt = blockDim.x;
-    float* slab = a.slab + (size_t)blockIdx.x * a.n_params;
-    for (int i = threadIdx.x; i < (a.n_params >> 2); i += nt) reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    NET_MARK(0);
-    for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
-        __syncthreads();  // the previous sample is done with the arena; the slab zero fill has been issued
-        {   // dz of the last layer = dL/dy * act'(y)
-            const NetBwdLayer& L = a.L[a.n_layers - 1];
-            const int Ho = L.Hs * L.up, Wo = L.Ws * L.up;
-            lds_zero(smem + L.g_off, L.Cout * L.g_plane, nt);
-            __syncthreads();
-            PlanarSrc src;
-            src.x = a.dpred; src.zy = a.y_last; src.zidx = nullptr; src.mode = 1; src.zk = act_grad_coef_dev(L.act, L.alpha);
-            src.Hs = Ho; src.Ws = Wo; src.C = L.Cout;
-            const PlanarDst dst{L.Cout, L.g_plane, L.g_wp, 1};
-            stage_pass(src, dst, make_stage_job(src, n, 1, 0, L.Cout), smem + L.g_off, nt);
-        }
-        const bool tr = n == (int)blockIdx.x;  // diagnostic marks: first sample of the workgroup only
-        if (tr) NET_MARK(1);
-        for (int l = a.n_layers - 1; l >= 0; --l) {
-            const NetBwdLayer& L = a.L[l];
-            // zero what this step writes sparsely: the staged activation (halo), the mirrored filters (padded
-            // channels) and the next dz (halo)
-            lds_zero(smem + L.a_off - 4, L.Cin * L.a_plane + 4, nt);  // incl. the slack a strip's first read touches
-            if (l > 0) {
-                lds_zero(smem + L.wl_off, L.d_n_cot * L.d_co_t * K * K * L.Cout, nt);
-                lds_zero(smem + a.L[l - 1].g_off, a.L[l - 1].Cout * a.L[l - 1].g_plane, nt);
-            }
-            __syncthreads();
-            {
-                PlanarSrc src;
-                src.x = L.a_in; src.zy = nullptr; src.zidx = nullptr; src.mode = 0; src.zk = ActGradCoef{};
-                src.Hs = L.Hs; src.Ws = L.Ws; src.C = L.Cin;
-                const PlanarDst dst{L.Cin, L.a_plane, L.a_wp, 1};
-                stage_pass(src, dst, make_stage_job(src, n, 1, 0, L.Cin), smem + L.a_off, nt);
-                if (l > 0) {
-                    net_wflip_stage<K>(a, L, smem, nt);
-                    if (L.prev_pool) {
-                        const int nb = L.Hs * L.Ws * L.Cin;  // bytes; a multiple of 4 (Hs, Ws even)
-                        const uint32_t* gsrc = reinterpret_cast<const uint32_t*>(L.a_idx + (size_t)n * nb);
-                        uint32_t* d = reinterpret_cast<uint32_t*>(smem + L.aidx_off);
-                        for (int i = threadIdx.x; i < (nb >> 2); i += nt) d[i] = gsrc[i];
-                    }
-                }
-            }
-            __syncthreads();
-            if (tr) NET_MARK(2 + 3 * (a.n_layers - 1 - l));
-            if (l > 0) {
-                if (L.up == 1) {
-                    if (L.d_co_t == 8) net_layer_dgrad<K, 1, 8>(a, L, a.L[l - 1], smem, nt);
-                    else net_layer_dgrad<K, 1, 4>(a, L, a.L[l - 1], smem, nt);
-                } else {
-                    if (L.d_co_t == 8) net_layer_dgrad<K, 2, 8>(a, L, a.L[l - 1], smem, nt);
-                    else net_layer_dgrad<K, 2, 4>(a, L, a.L[l - 1], smem, nt);
-                }
-            }
-#ifdef SV_EXP_MARKS
-            __syncthreads();
-#endif
-            if (tr) NET_MARK(3 + 3 * (a.n_layers - 1 - l));
-            if (L.w_mfma) {
-                if (L.up == 1) net_layer_wgrad_mfma<K, 1>(a, L, smem, slab);
-                else net_layer_wgrad_mfma<K, 2>(a, L, smem, slab);
-            } else if (L.up == 1) {
-                if (L.w_co_t == 8) net_layer_wgrad<K, 1, 8>(a, L, smem, slab, nt);
-                else net_layer_wgrad<K, 1, 4>(a, L, smem, slab, nt);
-            } else {
-                if (L.w_co_t == 8) net_layer_wgrad<K, 2, 8>(a, L, smem, slab, nt);
-                else net_layer_wgrad<K, 2, 4>(a, L, smem, slab, nt);
-            }
-            __syncthreads();
-            if (tr) NET_MARK(4 + 3 * (a.n_layers - 1 - l));
-        }
-    }
-}
-
-// out[i] (+)= sum over workgroups of slab[b][i], fixed order
-__global__ __launch_bounds__(256) void net_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int n_params,
-                                                       int n_split, int accumulate) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (i < n_params) {
-        int sp = grp;
-        for (; sp + 7 * 4 < n_split; sp += 8 * 4) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(sp + u * 4) * n_params + i];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; sp < n_split; sp += 4) s += slab[(size_t)sp * n_params + i];
-    }
-    red[grp][lane] = s;
-    __syncthreads();
-    if (grp == 0 && i < n_params) {
-        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        out[i] = accumulate ? out[i] + t : t;
-    }
-}
-
-struct NetBwdPlan {
-    bool ok;
-    int grid;
-    size_t lds_bytes;
-    NetBwdArgs args;
-};
-
-NetBwdPlan plan_net_bwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, int n_params) {
-    NetBwdPlan p{};
-    p.ok = false;
-    NetBwdArgs& a = p.args;
-    const int nt = 256;
-    int h = H, w = W;
-    size_t gsz[kMaxNetLayers], asz[kMaxNetLayers], wsz[kMaxNetLayers], isz[kMaxNetLayers];
-    for (int l = 0; l < n_layers; ++l) {
-        const sv_net_layer& s = layers[l];
-        NetBwdLayer& L = a.L[l];
-        L.Cin = s.Cin; L.Cout = s.Cout; L.Hs = h; L.Ws = w; L.up = s.up; L.pool = s.pool; L.act = s.act; L.alpha = s.alpha;
-        L.w_off = (int)s.w_off; L.b_off = (int)s.b_off;
-        const int Ho = h * s.up, Wo = w * s.up;
-        if (Wo & 3) return p;  // strips of 4 pixels
-        L.g_wp = (Wo + 2 + 3) & ~3;
-        L.g_plane = (Ho + 2) * L.g_wp + 4;
-        L.a_wp = (w + 2 + 3) & ~3;
-        L.a_plane = (h + 2) * L.a_wp + 4;
-        L.prev_pool = l > 0 ? layers[l - 1].pool : 0;
-        L.prev_act = l > 0 ? layers[l - 1].act : SV_ACT_NONE;
-        L.prev_alpha = l > 0 ? layers[l - 1].alpha : 0.f;
-        L.d_co_t = s.Cin > 4 ? 8 : 4;
-        L.d_n_cot = (s.Cin + L.d_co_t - 1) / L.d_co_t;
-        const int T = (Ho / 2) * (Wo / 2);
-        int ks = 1;
-        while (ks < 8 && s.Cout / (2 * ks) >= 2 && (int64_t)L.d_n_cot * T * ks < nt) ks <<= 1;
-        L.d_ks = ks;
-        L.w_co_t = s.Cout > 4 ? 8 : 4;
-        L.w_n_cot = (s.Cout + L.w_co_t - 1) / L.w_co_t;
-        const int combos3 = s.Cin * L.w_n_cot * 3;
-        L.w_mfma = ((9 * s.Cin + 1 + 15) / 16) * ((s.Cout + 15) / 16) <= 4 * kWgTiles;
-        if (!L.w_mfma && combos3 > nt) return p;
-        int pg = 1;
-        while (pg * 2 * combos3 <= nt && pg < 64) pg <<= 1;
-        L.w_pg = pg;
-        L.a_in = l == 0 ? nullptr : (const float*)layers[l - 1].y;
-        L.a_idx = (l > 0 && layers[l - 1].pool) ? layers[l - 1].idx : nullptr;
-        if (l > 0 && layers[l - 1].pool && L.a_idx == nullptr) return p;
-        gsz[l] = ((size_t)s.Cout * L.g_plane + 3) & ~(size_t)3;
-        asz[l] = ((size_t)s.Cin * L.a_plane + 3) & ~(size_t)3;
-        wsz[l] = l > 0 ? (size_t)L.d_n_cot * L.d_co_t * 9 * s.Cout : 0;
-        isz[l] = L.prev_pool ? (((size_t)h * w * s.Cin + 15) / 16) * 4 : 0;  // floats, 16-byte granules
-        h = s.pool ? Ho / 2 : Ho;
-        w = s.pool ? Wo / 2 : Wo;
-    }
-    // arena: dz_l at the bottom for even l, at the top for odd l; the staged tensors of step l in between
-    size_t arena = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        const size_t need = gsz[l] + (l > 0 ? gsz[l - 1] : 0) + asz[l] + wsz[l] + isz[l] + 8;
-        if (need > arena) arena = need;
-    }
-    arena = (arena + 3) & ~(size_t)3;
-    if (arena * sizeof(float) > 80 * 1024) return p;
-    for (int l = 0; l < n_layers; ++l) a.L[l].g_off = (int)((l & 1) ? arena - gsz[l] : 4);  // 4 floats of slack below
-    for (int l = 0; l < n_layers; ++l) {
-        NetBwdLayer& L = a.L[l];
-        const size_t bottom = 4 + ((l & 1) ? (l > 0 ? gsz[l - 1] : 0) : gsz[l]);
-        L.a_off = (int)(bottom + 4);
-        L.wl_off = (int)(L.a_off + asz[l]);
-        L.aidx_off = (int)(L.wl_off + wsz[l]);
-    }
-    a.N = N; a.n_layers = n_layers; a.n_params = n_params; a.arena_floats = (int)arena + 8;
-    p.lds_bytes = ((arena + 8) * sizeof(float) + 15) & ~(size_t)15;
-    p.grid = N < 512 ? N : 512;
-    p.ok = true;
-    return p;
-}
-
-static int net_bwd_enable_lds() {
-    static bool done = false;
-    if (done) return SV_OK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&net_bwd_s1<3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return fail(SV_E_LAUNCH, "net_bwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
-    done = true;
-    return SV_OK;
-}
-
 }  // namespace sv
 
 using namespace sv;
@@ -1905,45 +1310,6 @@ int sv_convnet_fwd_mse_rows(const sv_net_layer* layers, int n_layers, int N, int
                "sv_convnet_fwd_mse_rows: tensors must be 16-byte aligned");
     return convnet_fwd_any("sv_convnet_fwd_mse_rows", layers, n_layers, N, H, W, nullptr, params, y_true, dpred, loss_scale,
                            partials, n_partials, stream, rows);
-}
-
-size_t sv_convnet_bwd_workspace_bytes(const sv_net_layer* layers, int n_layers, int N, int H, int W, int64_t n_params) {
-    if (net_validate(layers, n_layers, N, H, W, "sv_convnet_bwd_workspace_bytes") || n_params < 4 || (n_params & 3)) return 0;
-    NetBwdPlan p = plan_net_bwd(layers, n_layers, N, H, W, (int)n_params);
-    return p.ok ? (size_t)p.grid * (size_t)n_params * sizeof(float) : 0;
-}
-
-int sv_convnet_bwd(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x, const void* params,
-                   const void* dpred, void* grads, int64_t n_params, int accumulate, void* workspace,
-                   size_t workspace_bytes, int dtype, sv_stream_t stream) {
-    SV_F32_ONLY(dtype, "sv_convnet_bwd");
-    int rc = net_validate(layers, n_layers, N, H, W, "sv_convnet_bwd");
-    if (rc) return rc;
-    SV_REQUIRE(x && params && dpred && grads, "sv_convnet_bwd: null tensor");
-    SV_REQUIRE(n_params >= 4 && (n_params & 3) == 0 && n_params <= INT32_MAX / 512, "sv_convnet_bwd: n_params must be a multiple of 4");
-    for (int l = 0; l < n_layers; ++l) {
-        SV_REQUIRE(layers[l].y != nullptr, "sv_convnet_bwd: layer %d has no saved output", l);
-        SV_REQUIRE(layers[l].w_off + (int64_t)9 * layers[l].Cin * layers[l].Cout <= n_params, "sv_convnet_bwd: layer %d: filter outside the parameter buffer", l);
-        SV_REQUIRE(layers[l].b_off < 0 || layers[l].b_off + layers[l].Cout <= n_params, "sv_convnet_bwd: layer %d: bias outside the parameter buffer", l);
-    }
-    NetBwdPlan p = plan_net_bwd(layers, n_layers, N, H, W, (int)n_params);
-    if (!p.ok) return fail(SV_E_UNSUPPORTED, "sv_convnet_bwd: chain outside the fused family");
-    const size_t need = (size_t)p.grid * (size_t)n_params * sizeof(float);
-    if (workspace == nullptr || workspace_bytes < need)
-        return fail(SV_E_WORKSPACE, "sv_convnet_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
-    rc = net_bwd_enable_lds();
-    if (rc) return rc;
-    p.args.params = (const float*)params;
-    p.args.dpred = (const float*)dpred;
-    p.args.y_last = (const float*)layers[n_layers - 1].y;
-    p.args.slab = (float*)workspace;
-    p.args.L[0].a_in = (const float*)x;
-    hipLaunchKernelGGL((net_bwd_s1<3>), dim3((unsigned)p.grid), dim3(256), p.lds_bytes, to_stream(stream), p.args);
-    rc = check_launch("net_bwd_s1");
-    if (rc) return rc;
-    hipLaunchKernelGGL(net_slab_reduce, dim3((unsigned)ceil_div(n_params, 64)), dim3(256), 0, to_stream(stream),
-                       (const float*)workspace, (float*)grads, (int)n_params, p.grid, accumulate);
-    return check_launch("net_slab_reduce");
 }
 
 }  // extern "C"

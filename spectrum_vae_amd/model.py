@@ -92,13 +92,11 @@ class Model(Layer):
         # one launch per backward pass for all kernel / bias gradient slab sums (SPECTRUM_DEFER_REDUCES=0: per layer)
         self.defer_reduces = os.environ.get("SPECTRUM_DEFER_REDUCES", "1") != "0"
         self.fuse_loss = True  # MeanSquaredError evaluated inside the one-launch forward, folded by the optimizer launch
-        # measured at batch 1024 (step time in ms for large / small = 256/256: 0.297, 128/256: 0.291, 128/128: 0.292, 64/256: 0.321)
-        self.wgrad_batch_blocks_large = int(os.environ.get("SPECTRUM_WGRAD_BLOCKS_LARGE", "128"))  # layers of >= 256 pixels
-        self.wgrad_batch_blocks = int(os.environ.get("SPECTRUM_WGRAD_BLOCKS", "256"))  # workgroups per layer when >= 3 layers share the batched kernel-gradient launch
+        # workgroups per layer when >= 3 layers share the batched kernel-gradient launch (128 each measured best at batch
+        # 1024: tools/wgrad_ab.py sweeps other splits)
+        self.wgrad_batch_blocks_large = 128  # layers of >= 256 pixels
+        self.wgrad_batch_blocks = 128
         self.defer_wgrad_reduce = True  # one reduction launch for the kernel gradients of all fused conv layers
-        # The whole backward as one launch (sv_convnet_bwd) is correct but, with one sample in flight per workgroup,
-        # slower than the per-layer kernels at the batch sizes measured so far: opt-in.
-        self.use_net_fused_bwd = False
         self._chain_cache: Dict[int, object] = {}
         self._slabs_wanted = False   # set around the backward pass of a training step whose optimizer launch can sum slabs
         self._pending_slabs = None   # the table that backward pass left (ops.conv2d_wgrad_batch_slabs)
@@ -425,18 +423,6 @@ class Model(Layer):
 
     def _backward_raw(self, ctx, dy: torch.Tensor, need_dx: bool):
         self._grads_clean = False
-        net = getattr(ctx, "net", None)
-        if net is not None and self.use_net_fused_bwd and not need_dx and ctx.param_grads:
-            (arr, bufs, h, w), x = net
-            n = x.shape[0]
-            key = ("bwd_ws", n)
-            nbytes = self._chain_cache.get(key)
-            if nbytes is None:
-                nbytes = self._chain_cache[key] = ops.convnet_bwd_workspace(arr, n, h, w, self._params.numel())
-            if nbytes > 0:
-                dyt = dy.as_subclass(torch.Tensor).contiguous()
-                ops.convnet_bwd(arr, n, h, w, x, self._params, dyt, self._grads, True, self._pool.workspace(nbytes))
-                return None
         if self.defer_wgrad_reduce and ctx.param_grads and ctx.wgrad_jobs is None:
             ctx.wgrad_jobs, ctx.wgrad_finish = [], []
             dx = self.backward(ctx, dy, need_dx=need_dx)

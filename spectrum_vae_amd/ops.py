@@ -284,15 +284,6 @@ def scalar_program(statements):
     check(lib.sv_scalar_program(n, outs, acc, nt, terms, weights, _stream()), "sv_scalar_program")
 
 
-def convnet_bwd_workspace(arr, n: int, h: int, w: int, n_params: int) -> int:
-    return int(lib.sv_convnet_bwd_workspace_bytes(arr, len(arr), n, h, w, n_params))
-
-
-def convnet_bwd(arr, n: int, h: int, w: int, x, params, dpred, grads, accumulate: bool, ws: torch.Tensor):
-    check(lib.sv_convnet_bwd(arr, len(arr), n, h, w, _ptr(x), _ptr(params), _ptr(dpred), _ptr(grads), params.numel(),
-                             int(accumulate), _ptr(ws, torch.uint8), ws.numel(), F32, _stream()), "sv_convnet_bwd")
-
-
 def conv2d_bwd_partial(g: ConvGeom, x, dy, y, idx, act: str, alpha: float, with_bias: bool, ws: torch.Tensor):
     check(lib.sv_conv2d_bwd_partial(C.byref(g), _ptr(x), _ptr(dy), _ptr(y), _ptr(idx, torch.uint8), ACT[act], alpha,
                                     int(with_bias), _ptr(ws, torch.uint8), ws.numel(), F32, _stream()),

@@ -4,6 +4,8 @@ Bars (the north star's): activations and gradients at relative error <= 1e-4 (fp
 within 1e-3 over 100 fixed-seed optimizer steps.  Relative error of a tensor is
 max|hip - ref| / max(max|ref|, floor) with a small floor so all-zero gradients do not divide by zero.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -340,16 +342,78 @@ def test_fit_predict_history_and_early_stopping():
     assert len(h2.history["loss"]) == 4  # epoch 0 sets the best, epochs 1-3 do not improve
 
 
-def assert_first_updates_agree(variables, w0, ref_params, frac=0.98):
+def roundoff_floor(g64, g32, k=32.0):
+    """Per element, ``k`` times the largest difference between the float32 and the float64 gradient of the CPU twin
+    inside the element's tensor: what float32 arithmetic alone moves a gradient of that tensor by.  Returns
+    (|g64| flattened, floor flattened)."""
+    mags, floors = [], []
+    for a, b in zip(g64, g32):
+        a = a.detach().numpy().astype(np.float64)
+        b = b.detach().numpy().astype(np.float64)
+        mags.append(np.abs(a).ravel())
+        floors.append(np.full(a.size, k * np.abs(a - b).max()))
+    return np.concatenate(mags), np.concatenate(floors)
+
+
+def moments_of(model, opt):
+    return opt._slots_for(model)[0].cpu().numpy().copy()
+
+
+def engine_grads(model, opt, m_before):
+    """The gradient the engine's optimizer launch consumed, recovered from its first moments:
+    m_after = beta_1 * m_before + (1 - beta_1) * g."""
+    m_after = opt._slots_for(model)[0].cpu().numpy()
+    g = (m_after - opt.beta_1 * m_before) / (1.0 - opt.beta_1)
+    return [g[v.offset:v.offset + v.size].reshape(v.shape) for v in model.trainable_variables]
+
+
+def activation_flip(g_engine, g64, g32, tol=1e-4):
+    """True when some tensor of the engine's gradient misses the float64 twin's by more than ``tol`` of the tensor's
+    largest entry AND by more than 10x what the float32 twin misses it by (BatchNorm over a handful of positions makes
+    some tensors ill-conditioned for every float32 evaluation; the floor of ``roundoff_floor`` covers those).
+    Round-off stays two orders below ``tol`` (1e-6 measured); what reaches it is a ReLU whose input is a few ulps from
+    zero taking the other branch in float32 - one unit's whole contribution appears or vanishes, in that layer's
+    tensors and, diluted, in every layer upstream.  TensorFlow's float32 graph is exposed to the same flips."""
+    flipped = False
+    for i, (a, b, c) in enumerate(zip(g_engine, g64, g32)):
+        b, c = b.detach().numpy(), c.detach().numpy()
+        top = float(np.abs(b).max())
+        e_hip, e_cpu = float(np.abs(a - b).max()) / top, float(np.abs(c - b).max()) / top
+        if e_hip > max(tol, 10.0 * e_cpu):
+            flipped = True
+            if os.environ.get("SV_TEST_VERBOSE"):
+                print(f"tensor {i} {tuple(a.shape)}: engine {e_hip:.1e}, float32 twin {e_cpu:.1e} of the largest entry")
+    return flipped
+
+
+def assert_first_updates_agree(variables, w0, ref_params, frac=0.98, significant=None):
     """Adam's first update is -lr * g / (|g| + eps'): it has the size of the learning rate whatever |g| is, so a
     weight whose true gradient is zero (a conv bias feeding a BatchNorm: the mean subtraction cancels it) moves
-    by +-lr with the sign of float32 round-off noise - in TensorFlow as much as here.  The check is therefore
-    element-wise over ALL weights together: at least ``frac`` of them must take the same step as the CPU
-    restatement to within 5 %."""
+    by +-lr with the sign of float32 round-off noise - in TensorFlow as much as here.  Element-wise over ALL weights
+    together at least ``frac`` of them must take the same step as the CPU restatement to within 5 %; ``significant``
+    (``roundoff_floor`` of the twin's float64 and float32 gradients) names the weights whose gradient stands above
+    that noise, and of those EVERY one must - to within 5 % of its update plus 0.5 % of the largest update in its
+    tensor (the size of the learning rate): after the first step an update is -alpha * m / (sqrt(v) + eps) with m a
+    difference of gradients of either sign, which can cancel to a few ulps of the float32 weight itself."""
     d_hip = np.concatenate([(v.numpy() - a).ravel() for v, a in zip(variables, w0)])
     d_ref = np.concatenate([(p.detach().numpy() - a).ravel() for p, a in zip(ref_params, w0)])
     ok = np.abs(d_hip - d_ref) <= 0.05 * np.abs(d_ref) + 1e-9
     assert ok.mean() >= frac, f"only {ok.mean():.4f} of the first updates agree"
+    if significant is not None:
+        mag, floor = significant
+        sig = mag > floor
+        assert sig.mean() >= 0.2, f"only {sig.mean():.3f} of the gradients stand above the float32 round-off floor"
+        sizes = np.cumsum([0] + [int(np.prod(a.shape)) for a in w0])
+        step = np.concatenate([np.full(sizes[t + 1] - sizes[t], np.abs(d_ref[sizes[t]:sizes[t + 1]]).max())
+                               for t in range(len(w0))])
+        bad = sig & (np.abs(d_hip - d_ref) > 0.05 * np.abs(d_ref) + 0.005 * step)
+        if bad.any() and os.environ.get("SV_TEST_VERBOSE"):
+            for i in np.nonzero(bad)[0][:12]:
+                t = int(np.searchsorted(sizes, i, side="right") - 1)
+                print("tensor", t, tuple(w0[t].shape), "g", mag[i], "floor", floor[i], "tensor max g", mag[sizes[t]:sizes[t + 1]].max(),
+                      "d_hip", d_hip[i], "d_ref", d_ref[i])
+        assert not bad.any(), (f"{int(bad.sum())} of {int(sig.sum())} weights with a gradient above the round-off floor "
+                               f"disagree; worst |g| / floor {float((mag[bad] / floor[bad]).max()):.1f}")
 
 
 def resync_twin(model, opt, ref, ref_opt):
@@ -373,7 +437,8 @@ def resync_twin(model, opt, ref, ref_opt):
 
 
 def ref_ce_step(ce, disc, opt_ce, opt_d, X, mask, l2w=0.999):
-    """CPU restatement of run_context_encoder.train_step (run_context_encoder.py:225-260)."""
+    """CPU restatement of run_context_encoder.train_step (run_context_encoder.py:225-260).  Without optimizers: the two
+    gradient lists (context encoder, discriminator) instead of an update."""
     for p in ce.params + disc.params:
         p.grad = None
     pred = ce(X * (1 - mask), training=True)
@@ -384,6 +449,9 @@ def ref_ce_step(ce, disc, opt_ce, opt_d, X, mask, l2w=0.999):
     total = l2 * l2w + dl * (1 - l2w)
     d_grads = torch.autograd.grad(dl, disc.params, retain_graph=True)
     c_grads = torch.autograd.grad(l2, ce.params)
+    ref_ce_step.last_grads = (list(c_grads), list(d_grads))
+    if opt_ce is None:
+        return ref_ce_step.last_grads
     opt_d.apply_gradients(d_grads)
     opt_ce.apply_gradients(c_grads)
     return float(dl), float(l2), float(total)
@@ -406,25 +474,40 @@ def test_context_encoder_train_step_trajectory():
     rce = RefSequential(e + d, (32, 32, 3), dtype=torch.float64)
     rd = RefSequential(omodels.discriminator(), (32, 32, 3), dtype=torch.float64)
     load_into_ref(rce, ce); load_into_ref(rd, disc)
+    # float32 copies of the twin: the difference between their gradients and the float64 ones is the round-off floor
+    e32, d32_ = omodels.context_encoder()
+    rce32 = RefSequential(e32 + d32_, (32, 32, 3), dtype=torch.float32)
+    rd32 = RefSequential(omodels.discriminator(), (32, 32, 3), dtype=torch.float32)
     LR = 2e-4
     oce, od = build_optimizer(learning_rate=LR * 10), build_optimizer(learning_rate=LR)
     roce = KerasAdam(rce.params, LR * 10, beta1=0.5, decay_steps=50, decay_rate=0.96)
     rod = KerasAdam(rd.params, LR, beta1=0.5, decay_steps=50, decay_rate=0.96)
     Xt, Mt = torch.from_numpy(X).double(), torch.from_numpy(mask).double()
+    flips = 0
     for step in range(8):
         sl = slice((step % 4) * 16, (step % 4 + 1) * 16)
         w0 = [v.numpy() for v in ce.trainable_variables + disc.trainable_variables]
+        mc, md = moments_of(ce, oce), moments_of(disc, od)
         got = [float(v) for v in train_step(ce, disc, oce, od, X[sl], mask[sl])]
+        g_eng = engine_grads(ce, oce, mc) + engine_grads(disc, od, md)
+        nce = len(rce.params)
+        rce32.load_params(w0[:nce]); rd32.load_params(w0[nce:])
+        c32, d32 = ref_ce_step(rce32, rd32, None, None, Xt[sl].float(), Mt[sl].float())
         want = ref_ce_step(rce, rd, roce, rod, Xt[sl], Mt[sl])
+        c64, d64 = ref_ce_step.last_grads
         for name, g, w in zip(("disc", "l2", "total"), got, want):
             assert abs(g - w) <= 1e-4 * max(1.0, abs(w)), (step, name, g, w)
-        # the update of every weight tensor: same direction and size as the twin's
-        assert_first_updates_agree(ce.trainable_variables + disc.trainable_variables, w0, rce.params + rd.params)
+        # the update of every weight tensor: same direction and size as the twin's - of every weight whose gradient
+        # stands above round-off, unless a ReLU took the other branch in this step (see activation_flip)
+        flipped = activation_flip(g_eng, c64 + d64, c32 + d32)
+        flips += int(flipped)
+        assert_first_updates_agree(ce.trainable_variables + disc.trainable_variables, w0, rce.params + rd.params,
+                                   significant=None if flipped else roundoff_floor(c64 + d64, c32 + d32))
         for v, s in zip(disc.non_trainable_variables, rd.state):  # D's BatchNorm saw the real and the generated batch
             assert rel(v.numpy(), s.numpy()) <= 1e-4, (step, v.name)
         resync_twin(ce, oce, rce, roce)
         resync_twin(disc, od, rd, rod)
-    assert oce.iterations == 8 and od.iterations == 8
+    assert oce.iterations == 8 and od.iterations == 8 and flips <= 1
 
 
 def ref_unet_step(gen, disc, opt_g, opt_d, X, y, lam=100.0):
@@ -440,6 +523,9 @@ def ref_unet_step(gen, disc, opt_g, opt_d, X, y, lam=100.0):
     d_loss = torch_ref.bce_logits(torch.ones_like(z_real), z_real) + torch_ref.bce_logits(torch.zeros_like(z_fake), z_fake)
     d_grads = torch.autograd.grad(d_loss, disc.params, retain_graph=True)
     g_grads = torch.autograd.grad(g_total, gen.params)
+    ref_unet_step.last_grads = (list(g_grads), list(d_grads))
+    if opt_g is None:  # the two gradient lists (generator, discriminator) instead of an update
+        return ref_unet_step.last_grads
     opt_d.apply_gradients(d_grads)
     opt_g.apply_gradients(g_grads)
     return float(d_loss), float(g_total), float(gan), float(l1)
@@ -472,22 +558,34 @@ def test_unet_gan_train_step():
     gen.build((None, 32, 32, 1)); disc.build((None, 32, 32, 4))
     gen._materialize(); disc._materialize()
     rg, rd = omodels.RefUNet(dtype=torch.float64), RefUNetDisc(torch.float64)
+    rg32, rd32 = omodels.RefUNet(dtype=torch.float32), RefUNetDisc(torch.float32)  # their gradients measure the round-off floor
     rg.load_params([v.numpy() for v in gen.trainable_variables])
     rd.seq.load_params([v.numpy() for v in disc.trainable_variables])
     og, od = build_optimizer(learning_rate=2e-4), build_optimizer(learning_rate=2e-4)
     rog = KerasAdam(rg.params, 2e-4, beta1=0.5, decay_steps=10, decay_rate=0.96)
     rod = KerasAdam(rd.params, 2e-4, beta1=0.5, decay_steps=10, decay_rate=0.96)
     Xt, yt = torch.from_numpy(X).double(), torch.from_numpy(y).double()
+    flips = 0
     for step in range(8):
         sl = slice((step % 3) * 16, (step % 3 + 1) * 16)
         w0 = [v.numpy() for v in gen.trainable_variables + disc.trainable_variables]
+        mg, md = moments_of(gen, og), moments_of(disc, od)
         got = [float(v) for v in train_step(gen, disc, og, od, X[sl], y[sl])]
+        g_eng = engine_grads(gen, og, mg) + engine_grads(disc, od, md)
+        ng = len(rg.params)
+        rg32.load_params(w0[:ng]); rd32.seq.load_params(w0[ng:])
+        g32, d32 = ref_unet_step(rg32, rd32, None, None, Xt[sl].float(), yt[sl].float())
         want = ref_unet_step(rg, rd, rog, rod, Xt[sl], yt[sl])
+        g64, d64 = ref_unet_step.last_grads
         for name, g, w in zip(("disc", "gen_total", "gan", "l1"), got, want):
             assert abs(g - w) <= 1e-4 * max(1.0, abs(w)), (step, name, g, w)
-        assert_first_updates_agree(gen.trainable_variables + disc.trainable_variables, w0, rg.params + rd.params)
+        flipped = activation_flip(g_eng, g64 + d64, g32 + d32)
+        flips += int(flipped)
+        assert_first_updates_agree(gen.trainable_variables + disc.trainable_variables, w0, rg.params + rd.params,
+                                   significant=None if flipped else roundoff_floor(g64 + d64, g32 + d32))
         resync_twin(gen, og, rg, rog)
         resync_twin(disc, od, rd.seq, rod)
+    assert flips <= 1
 
 
 def test_keras_surface_apply_gradients_and_losses():
@@ -635,75 +733,6 @@ def test_fit_with_loss_inside_the_forward_launch_equals_the_separate_loss():
         hist[fuse] = (np.array(h.history["loss"]), model._params.cpu().numpy().copy())
     assert np.allclose(hist[True][0], hist[False][0], rtol=1e-5)
     assert np.abs(hist[True][1] - hist[False][1]).max() < 1e-5
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 5, 64, 1100])
-def test_whole_network_backward_matches_per_layer_path(n):
-    """Gradients of the one-launch backward against the per-layer kernels, for MSE against the input."""
-    from spectrum_vae_amd import autoencoder, losses
-    from spectrum_vae_amd.losses import to_device_f32
-    x = data(n, seed=11 + n)
-    grads = {}
-    for fused in (True, False):
-        model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
-        model.use_net_fused_bwd = fused
-        model.build((None, 32, 32, 3))
-        model._materialize()
-        model.compile(optimizer=None, loss=losses.MeanSquaredError())
-        assert model.use_net_fused
-        xt = to_device_f32(x)
-        model.zero_grad()
-        pred = model.forward_raw(xt, True)
-        loss = torch.zeros(1, device=xt.device)
-        dpred = torch.empty_like(pred)
-        model.loss.value_and_grad(xt, pred, loss, dpred, 1.0)
-        model.backward_raw(dpred, -1, need_dx=False)
-        if fused:
-            assert model._chain_cache.get(("bwd_ws", n), 0) > 0
-        grads[fused] = model._grads.cpu().numpy().copy()
-    scale = np.abs(grads[False]).max()
-    assert np.abs(grads[True] - grads[False]).max() <= 2e-5 * scale
-
-
-def test_gan_steps_replayed_with_overlapped_updates_equal_the_serial_steps():
-    """The captured steps fork the generator-side work onto a second stream (disjoint buffers); replaying them must
-    give, bit for bit, the losses and weights of the same steps issued serially without a graph."""
-    from spectrum_vae_amd import context_encoder, run_context_encoder, run_unet, unet
-    full = data(48)
-    rng = np.random.default_rng(3)
-    mask = run_context_encoder.batch_random_mask(full, 0.25, rng).astype(np.float32)
-
-    def run_ce(use_graph):
-        ce, disc = context_encoder.ContextEncoder(), context_encoder.Discriminator()
-        ce.build((None, 32, 32, 3)); disc.build((None, 32, 32, 3))
-        ce._materialize(); disc._materialize()
-        o1, o2 = run_context_encoder.build_optimizer(2e-3), run_context_encoder.build_optimizer(2e-4)
-        out = []
-        for step in range(5):
-            sl = slice((step % 3) * 16, (step % 3 + 1) * 16)
-            out.append([float(v) for v in run_context_encoder.train_step(ce, disc, o1, o2, full[sl], mask[sl],
-                                                                         use_graph=use_graph)])
-        return out, [v.numpy() for v in ce.trainable_variables + disc.trainable_variables + disc.non_trainable_variables]
-
-    def run_unet_gan(use_graph):
-        gen, disc = unet.Generator(), unet.Discriminator()
-        gen.build((None, 32, 32, 1)); disc.build((None, 32, 32, 4))
-        gen._materialize(); disc._materialize()
-        o1, o2 = run_unet.build_optimizer(2e-4), run_unet.build_optimizer(2e-4)
-        X = full[..., :1].copy()
-        out = []
-        for step in range(5):
-            sl = slice((step % 3) * 16, (step % 3 + 1) * 16)
-            out.append([float(v) for v in run_unet.train_step(gen, disc, o1, o2, X[sl], full[sl], use_graph=use_graph)])
-        return out, [v.numpy() for v in gen.trainable_variables + disc.trainable_variables + disc.non_trainable_variables]
-
-    for run in (run_ce, run_unet_gan):
-        losses_g, weights_g = run(True)
-        losses_s, weights_s = run(False)
-        assert losses_g == losses_s, run.__name__
-        for a, b in zip(weights_g, weights_s):
-            assert np.array_equal(a, b), run.__name__
 
 
 @pytest.mark.gpu

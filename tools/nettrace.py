@@ -24,18 +24,11 @@ m._materialize(torch.device("cuda"))
 x = torch.rand(n, 32, 32, 3, device="cuda")
 from spectrum_vae_amd import losses  # noqa: E402
 m.compile(optimizer=None, loss=losses.MeanSquaredError())
-bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd"
 
 
 def run():
     m.zero_grad()
-    pred = m.forward_raw(x, bwd)
-    if bwd:
-        tr.zero_()
-        loss = torch.zeros(1, device=x.device)
-        dpred = torch.empty_like(pred)
-        m.loss.value_and_grad(x, pred, loss, dpred, 1.0)
-        m.backward_raw(dpred, -1, need_dx=False)
+    m.forward_raw(x, False)
 
 
 for _ in range(3):
@@ -49,19 +42,13 @@ t = tr.cpu().numpy().reshape(-1, 32)
 t = t[t[:, 0] != 0]
 t0 = t[:, 0].min()
 names = ["start", "x staged"] + [f"L{l} {w}" for l in range(6) for w in ("ready", "computed", "copied")]
-if bwd:
-    names = ["start", "dz staged"] + [f"L{5 - l} {w}" for l in range(6) for w in ("staged", "dgrad", "wgrad")]
 prev = None
 for s, nm in enumerate(names):
     v = (t[:, s] - t0) / 100.0
     d = "" if prev is None else f"   (+{np.median(v - prev):6.2f})"
     print(f"{nm:14s} min {v.min():7.2f} med {np.median(v):7.2f} max {v.max():7.2f}{d}")
     prev = v
-if bwd and t[:, 24].any():
-    for s_, nm in ((24, "e3 wgrad prologue done"), (25, "mfma loop done"), (26, "slab stored")):
-        v = (t[:, s_] - t0) / 100.0
-        print(f"{nm:22s} med {np.median(v):7.2f}")
-if not bwd and t[:, 20].any():
+if t[:, 20].any():
     for s_, nm in ((20, "L1: next layer set up"), (21, "L1: copy-out issued")):
         v = (t[:, s_] - t0) / 100.0
         print(f"{nm:26s} med {np.median(v):7.2f}   after 'L1 computed': {np.median(v - (t[:, 6] - t0) / 100.0):6.2f}")
