@@ -38,17 +38,39 @@ def grads_of(model):
     return [v.grad.detach().cpu().numpy().copy() for v in model.trainable_variables]
 
 
-def _ref_pass(ref, x, tgt, dtype):
+def _ref_pass(ref, x, tgt, dtype, dropout_masks=None):
     xt = torch.from_numpy(np.asarray(x, np.float32)).to(dtype)
     for p in ref.params:
         p.grad = None
-    pr = ref(xt, training=True)
+    masks = None if dropout_masks is None else {k: v.to(dtype) for k, v in dropout_masks.items()}
+    pr = ref(xt, training=True, dropout_masks=masks)
     loss = torch_ref.mse(torch.from_numpy(tgt).to(dtype), pr)
     loss.backward()
     return pr.detach().numpy(), float(loss), [p.grad.numpy().copy() for p in ref.params]
 
 
-def check_fwd_bwd(model, ref, x, tol=1e-4, target=None, ref64=None):
+def engine_dropout_masks(model, ref_layers, batch):
+    """Keep masks (0 / 1, float32) the model's Dropout layers will draw in their NEXT training call, keyed by the
+    position of the matching dropout entry in the oracle's layer list: the engine's mask is a pure function of
+    (seed, offset, element index) - sv_dropout_fwd on a tensor of ones returns keep / (1 - rate)."""
+    from spectrum_vae_amd import ops
+    from spectrum_vae_amd.nn import Dropout
+    drops = [l for seq in model._sequentials() for l in seq.layers if isinstance(l, Dropout) and l.rate > 0]
+    slots = [i for i, l in enumerate(ref_layers) if l["type"] == "dropout" and l["rate"] > 0]
+    assert len(drops) == len(slots) and drops, "every dropout of the model has its entry in the oracle's list"
+    masks = {}
+    for l, li in zip(drops, slots):
+        shape = (batch,) + tuple(l.input_shape_)
+        ones = torch.ones(shape, device="cuda")
+        y = torch.empty_like(ones)
+        ops.dropout_fwd(ones, y, l.rate, l.seed + 7919 * l.stream_id, l.calls * ones.numel())
+        keep = (y != 0).float().cpu()
+        assert abs(float(keep.mean()) - (1.0 - l.rate)) < 0.15, "the mask keeps about 1 - rate of the units"
+        masks[li] = keep
+    return masks
+
+
+def check_fwd_bwd(model, ref, x, tol=1e-4, target=None, ref64=None, dropout_layers=None):
     """Training forward, loss, gradient of every weight, BatchNorm state, inference forward.
 
     The bar is the float32 CPU restatement at ``tol``.  Gradients upstream of a BatchNorm are sums with heavy
@@ -63,18 +85,20 @@ def check_fwd_bwd(model, ref, x, tol=1e-4, target=None, ref64=None):
     load_into_ref(ref, model)
     tgt = np.asarray(x if target is None else target, np.float32)
     model.zero_grad()
+    # dropout: the masks of the training call about to run, replayed in the CPU restatement
+    masks = engine_dropout_masks(model, dropout_layers, x.shape[0]) if dropout_layers is not None else None
     pred = model.forward_raw(xd, True)
     out = torch.empty(1, device="cuda")
     dpred = torch.empty_like(pred)
     losses.MeanSquaredError().value_and_grad(to_device_f32(tgt), pred, out, dpred)
     pred_host = pred.cpu().numpy()
     model.backward_raw(dpred, -1, need_dx=False)
-    pr, loss, g32 = _ref_pass(ref, x, tgt, torch.float32)
+    pr, loss, g32 = _ref_pass(ref, x, tgt, torch.float32, masks)
     g64 = None
     if ref64 is not None:
         state32 = [s.clone() for s in ref.state]
         load_into_ref(ref64, model)
-        _, _, g64 = _ref_pass(ref64, x, tgt, torch.float64)
+        _, _, g64 = _ref_pass(ref64, x, tgt, torch.float64, masks)
     assert rel(pred_host, pr) <= tol, "training forward"
     assert abs(float(out) - loss) <= tol * max(1.0, abs(loss)), "loss"
     for i, (v, g) in enumerate(zip(model.trainable_variables, grads_of(model))):
@@ -171,6 +195,39 @@ def test_cae1d_and_classifiers():
     a = autoencoder.AE(dropout=0.0)
     enc, dec = omodels.ae(dropout=0.0)
     check_fwd_bwd(a, RefSequential(enc + dec, (32, 3)), data(4)[:, 0])
+
+
+def test_classifier_and_cae1d_with_dropout_replayed():
+    """Training passes with dropout ON: the engine's keep masks (sv_dropout_fwd's (seed, offset) stream) are replayed in
+    the CPU restatement, so forward, loss and every gradient are compared with the units actually dropped.
+    CNNPadded at its constructor defaults (autoencoder.py:129-181, dropout 0.5) and CAE1D at its constructor defaults
+    (autoencoder.py:275-394: three blocks of two (1, 3) valid convs, latent 8, dropout 0.5) on the narrowest input its
+    width arithmetic accepts, 36 columns (36 -> 16 -> 6 -> 1)."""
+    from spectrum_vae_amd import autoencoder
+    x = data(8)
+    m = autoencoder.CNNPadded()
+    layers = omodels.cnnpadded()
+    tgt = np.random.default_rng(2).standard_normal((8, 1)).astype(np.float32)
+    check_fwd_bwd(m, RefSequential(layers, (32, 32, 3)), x, target=tgt, dropout_layers=layers)
+    # a second call draws the next masks of the stream: different units, still in agreement
+    first = engine_dropout_masks(m, layers, 8)
+    check_fwd_bwd(m, RefSequential(layers, (32, 32, 3)), x, target=tgt, dropout_layers=layers)
+    assert any(not torch.equal(a, b) for a, b in zip(first.values(), engine_dropout_masks(m, layers, 8).values()))
+    x36 = np.concatenate([data(8), data(8, seed=5)[:, :, :4]], axis=2)
+    c = autoencoder.CAE1D(input_shape=(32, 36, 3))
+    enc, dec = omodels.cae1d(input_shape=(32, 36, 3))
+    c.build((None, 32, 36, 3))
+    assert c.output_shape_ == (32, 36, 3)
+    tgt = np.random.default_rng(3).standard_normal((8, 32, 36, 3)).astype(np.float32)
+    check_fwd_bwd(c, RefSequential(enc + dec, (32, 36, 3)), x36, target=tgt, dropout_layers=enc + dec)
+
+
+def test_cae1d_at_its_constructor_defaults_fails_as_the_reference_does():
+    """autoencoder.py:277-294 with nothing overridden: 32 columns shrink 32 -> 14 -> 5 -> (1 after two valid (1, 3)
+    convs), which the third (1, 2) pooling cannot halve - Keras raises while building the encoder; so does this model."""
+    from spectrum_vae_amd import autoencoder
+    with pytest.raises(ValueError):
+        autoencoder.CAE1D().build((None, 32, 32, 3))
 
 
 def test_unet_matches_oracle():
