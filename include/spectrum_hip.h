@@ -320,6 +320,31 @@ int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int a
                          int accumulate, int act_in, float alpha_in, float* dbias_in, int dbias_accumulate, int64_t rows,
                          int C, int groups, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream);
 
+/* BatchNormalization whose batch statistics run over the rows of EVERY data-parallel replica (the reference trains on one
+ * device, run_context_encoder.py:225-260; N replicas at batch B then equal one device at batch N * B), as the layer's three
+ * steps with the replicas' exchange - the caller's, e.g. RCCL - between them:
+ *   forward:  sv_batchnorm_sync_moments -> moments[groups][3][C] (double): rows, mean, sum of squared deviations about it;
+ *             all-gather, combine (count-weighted means; deviations + count * (mean - combined mean)^2), invstd =
+ *             1 / sqrt(var + eps), moving statistics: the caller;  sv_batchnorm_sync_fwd_apply normalises with them.
+ *   backward: sv_batchnorm_sync_bwd_sums -> sums[groups][2][C] = column sums of dy' and dy' * xhat over this replica's rows
+ *             (dy' = dy * act_out'(y_act)), and dgamma / dbeta (+)= those same local sums;  all-reduce (sum) of sums;
+ *             sv_batchnorm_sync_bwd_apply forms dx with the summed sums and all_rows_per_group = the rows of a statistics
+ *             group over all replicas.  Other arguments as in sv_batchnorm_act_fwd_train / sv_batchnorm_act_bwd. */
+int sv_batchnorm_sync_moments(const void* x, double* moments, int64_t rows, int C, int groups, void* workspace,
+                              size_t workspace_bytes, int dtype, sv_stream_t stream);
+int sv_batchnorm_sync_fwd_apply(const void* x, const float* gamma, const float* beta, const float* mean,
+                                const float* invstd, void* y, int64_t rows, int C, int groups, int act, float alpha,
+                                int dtype, sv_stream_t stream);
+int sv_batchnorm_sync_bwd_sums(const void* x, const void* dy, const void* y_act, int act_out, float alpha_out,
+                               const float* mean, const float* invstd, float* sums, float* dgamma, float* dbeta,
+                               int accumulate, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
+                               int dtype, sv_stream_t stream);
+int sv_batchnorm_sync_bwd_apply(const void* x, const void* dy, const void* y_act, int act_out, float alpha_out,
+                                const float* gamma, const float* mean, const float* invstd, const float* sums,
+                                int64_t all_rows_per_group, void* dx, int act_in, float alpha_in, float* dbias_in,
+                                int dbias_accumulate, int64_t rows, int C, int groups, void* workspace,
+                                size_t workspace_bytes, int dtype, sv_stream_t stream);
+
 /* ---- Concatenate on the channel axis (unet.py:144): y[r] = [a[r], b[r]] and its split backward */
 int sv_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int Ca, int Cb, int dtype,
                            sv_stream_t stream);

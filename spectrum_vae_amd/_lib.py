@@ -117,6 +117,11 @@ SIGNATURES = {
     "sv_batchnorm_workspace_bytes": (_sz, [_i64, _i, _i]),
     "sv_batchnorm_act_fwd_train": (_i, [_p] * 8 + [_i64, _i, _f, _f, _i, _i, _i, _f, _p, _sz, _i, _p]),
     "sv_batchnorm_act_fwd_infer": (_i, [_p] * 6 + [_i64, _i, _f, _i, _f, _i, _p]),
+    "sv_batchnorm_sync_moments": (_i, [_p, _p, _i64, _i, _i, _p, _sz, _i, _p]),
+    "sv_batchnorm_sync_fwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _f, _i, _p]),
+    "sv_batchnorm_sync_bwd_sums": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _sz, _i, _p]),
+    "sv_batchnorm_sync_bwd_apply": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _p, _i64, _p, _i, _f, _p, _i, _i64, _i, _i, _p,
+                                         _sz, _i, _p]),
     "sv_batchnorm_act_bwd": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _i, _i64, _i, _i, _p, _sz,
                                   _i, _p]),
     "sv_concat_channels_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),

@@ -451,6 +451,27 @@ __global__ __launch_bounds__(1024) void bn_finalize_k(const T* __restrict__ x, c
     }
 }
 
+// The fold of pass 1 for statistics that are combined ACROSS replicas afterwards: per group and channel the count, the
+// mean and the sum of squared deviations about that mean, in double (the combination adds the between-replica term
+// count * (mean - global mean)^2, which needs the means to full precision).
+template <typename T>
+__global__ __launch_bounds__(1024) void bn_local_moments_k(const T* __restrict__ x, const float* __restrict__ part, int nblocks,
+                                                            double* __restrict__ moments, int64_t rows, int C, int groups) {
+    for (int g = 0; g < groups; ++g) {
+        int c;
+        double sq[2];
+        const bool mine = fold_cols<2, double>(part + (int64_t)g * nblocks * 2 * C, nblocks, C, c, sq);
+        __syncthreads();
+        if (!mine) continue;
+        const double m = (double)rows, dmean = sq[0] / m;
+        double m2 = sq[1] - sq[0] * dmean;
+        if (m2 < 0.0) m2 = 0.0;
+        moments[((int64_t)g * 3 + 0) * C + c] = m;
+        moments[((int64_t)g * 3 + 1) * C + c] = (double)(float)x[(int64_t)g * rows * C + c] + dmean;
+        moments[((int64_t)g * 3 + 2) * C + c] = m2;
+    }
+}
+
 // y = (x - mean) * invstd * gamma + beta   (mean/invstd either saved batch stats or derived from moving stats)
 // A following activation layer may ride along (act != ACT_NONE): it sees the normalised value in its storage type, as it
 // would coming from a separate launch.
@@ -625,9 +646,10 @@ template <typename T>
 __global__ void bn_bwd_apply_k(const T* __restrict__ x, const T* __restrict__ dy,
                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ stats2,
-                               T* __restrict__ dx, int64_t rows, int C, int groups, int vec) {
+                               T* __restrict__ dx, int64_t rows, int C, int groups, int vec, float invm_all) {
     const int64_t total = rows * C * groups, group_elems = rows * C;  // rows: per statistics group
-    const float invm = 1.f / (float)rows;
+    // invm_all > 0: the sums in stats2 run over the rows of every replica (1 / their number), not over this launch's
+    const float invm = invm_all > 0.f ? invm_all : 1.f / (float)rows;
     if (vec) {
         constexpr int VN = 16 / sizeof(T);
         const int64_t nv = total / VN;
@@ -721,7 +743,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ stats2, T* __restrict__ dx,
                                                             int act_in, float alpha_in, float* __restrict__ partb,
-                                                            int64_t rows, int C, int64_t rows_per_block, int vec) {
+                                                            int64_t rows, int C, int64_t rows_per_block, int vec,
+                                                            float invm_all) {
     extern __shared__ float sm[];
     {  // blockIdx.y = statistics group
         const int64_t go = (int64_t)blockIdx.y * rows * C;
@@ -737,7 +760,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_k(const T* __restrict__
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
-    const float invm = 1.f / (float)rows;
+    const float invm = invm_all > 0.f ? invm_all : 1.f / (float)rows;
     if (vec) {
         BnBwdApplyOp<T> op{x, dy, yact, dx, gamma, mean, invstd, stats2, act_out, alpha_out, act_in, alpha_in, invm, C};
         row_sweep_vec<T, 1>(op, partb, r0, r1, C, sm);
@@ -1220,13 +1243,16 @@ int sv_batchnorm_fwd_infer(const void* x, const float* gamma, const float* beta,
                                       stream);
 }
 
-int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int act_out, float alpha_out, const float* gamma,
+// phase 0: the whole backward; 1: the column sums only (stats2 -> sums_io, dgamma / dbeta); 2: the input gradient from
+// the sums in sums_io (summed over every replica, `all_rows` rows per statistics group among them)
+static int bn_bwd_impl(int phase, float* sums_io, int64_t all_rows, const void* x, const void* dy, const void* y_act,
+                       int act_out, float alpha_out, const float* gamma,
                          const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta,
                          int accumulate, int act_in, float alpha_in, float* dbias_in, int dbias_accumulate, int64_t rows,
                          int C, int groups, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
     SV_F32_OR_BF16(dtype, "sv_batchnorm_bwd");
-    SV_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && rows > 0 && C > 0 &&
-                   C <= kMaxC,
+    SV_REQUIRE(x && dy && save_mean && save_invstd && rows > 0 && C > 0 && C <= kMaxC &&
+                   (phase == 2 || (dgamma && dbeta)) && (phase == 1 || (dx && gamma)),
                "sv_batchnorm_bwd: bad arguments (C=%d)", C);
     SV_REQUIRE(groups >= 1 && groups <= 64 && rows % groups == 0,
                "sv_batchnorm_bwd: %lld rows do not split into %d statistics groups", (long long)rows, groups);
@@ -1238,20 +1264,26 @@ int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int a
     if (rc) return rc;
     hipStream_t st = to_stream(stream);
     size_t lds;
-    const int vec = row_vec(dtype, C, 2, 512 * sizeof(float), &lds, {x, dy, y_act, dx});
-    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_stats_k<T>, dim3(p.nblocks, groups), dim3(256), lds, st, (const T*)x,
-                                        (const T*)dy, save_mean, save_invstd, part, rows_g, C, p.rows_per_block,
-                                        (const T*)y_act, act_out, alpha_out, vec););
-    rc = check_launch("bn_bwd_stats");
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_fold_k, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
-                       accumulate, C, groups);
-    rc = check_launch("bn_bwd_fold");
-    if (rc) return rc;
+    const int vec = row_vec(dtype, C, 2, 512 * sizeof(float), &lds, {x, dy, y_act, dx ? dx : x});
+    if (phase != 2) {
+        if (phase == 1) stats2 = sums_io;
+        SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_stats_k<T>, dim3(p.nblocks, groups), dim3(256), lds, st, (const T*)x,
+                                            (const T*)dy, save_mean, save_invstd, part, rows_g, C, p.rows_per_block,
+                                            (const T*)y_act, act_out, alpha_out, vec););
+        rc = check_launch("bn_bwd_stats");
+        if (rc) return rc;
+        hipLaunchKernelGGL(bn_bwd_fold_k, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st, part, p.nblocks, stats2, dgamma, dbeta,
+                           accumulate, C, groups);
+        rc = check_launch("bn_bwd_fold");
+        if (rc || phase == 1) return rc;
+    } else {
+        stats2 = sums_io;
+    }
+    const float invm_all = phase == 2 ? 1.f / (float)all_rows : 0.f;
     if (y_act == nullptr && act_in == SV_ACT_NONE && dbias_in == nullptr) {
         SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_k<T>, dim3(ew_grid(rows * C / 4 + 1, 256, 8192)), dim3(256), 0, st,
                                             (const T*)x, (const T*)dy, gamma, save_mean, save_invstd, stats2, (T*)dx, rows_g, C,
-                                            groups, vec););
+                                            groups, vec, invm_all););
         return check_launch("bn_bwd_apply");
     }
     const ColPlan pa = bn_apply_plan(rows_g, C);
@@ -1260,7 +1292,7 @@ int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int a
     SV_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_rows_k<T>, dim3(pa.nblocks, groups), dim3(256), lds_a, st, (const T*)x,
                                         (const T*)dy, (const T*)y_act, act_out, alpha_out, gamma, save_mean, save_invstd,
                                         stats2, (T*)dx, act_in, alpha_in, dbias_in ? partb : nullptr, rows_g, C,
-                                        pa.rows_per_block, vec_a););
+                                        pa.rows_per_block, vec_a, invm_all););
     rc = check_launch("bn_bwd_apply_rows");
     if (rc || dbias_in == nullptr) return rc;
     const int slabs = groups * pa.nblocks;
@@ -1268,6 +1300,76 @@ int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int a
     hipLaunchKernelGGL(fold_partials_k, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st, partb, dbias_in, slabs, C,
                        dbias_accumulate);
     return check_launch("bn_bwd/bias fold");
+}
+
+int sv_batchnorm_act_bwd(const void* x, const void* dy, const void* y_act, int act_out, float alpha_out, const float* gamma,
+                         const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta,
+                         int accumulate, int act_in, float alpha_in, float* dbias_in, int dbias_accumulate, int64_t rows,
+                         int C, int groups, void* workspace, size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    return bn_bwd_impl(0, nullptr, 0, x, dy, y_act, act_out, alpha_out, gamma, save_mean, save_invstd, dx, dgamma, dbeta,
+                       accumulate, act_in, alpha_in, dbias_in, dbias_accumulate, rows, C, groups, workspace, workspace_bytes,
+                       dtype, stream);
+}
+
+// ---- BatchNorm with statistics over every data-parallel replica: the layer in three steps with the replicas' exchange
+// (an all-gather of the moments, an all-reduce of the two backward sums: the caller's) between them
+int sv_batchnorm_sync_moments(const void* x, double* moments, int64_t rows, int C, int groups, void* workspace,
+                              size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_F32_OR_BF16(dtype, "sv_batchnorm_sync_moments");
+    SV_REQUIRE(x && moments && rows > 0 && C > 0 && C <= kMaxC, "sv_batchnorm_sync_moments: bad arguments (C=%d)", C);
+    SV_REQUIRE(groups >= 1 && groups <= 64 && rows % groups == 0,
+               "sv_batchnorm_sync_moments: %lld rows do not split into %d statistics groups", (long long)rows, groups);
+    const int64_t rows_g = rows / groups;
+    ColPlan p = col_plan(rows_g, C);
+    float *part = nullptr, *folded = nullptr, *partb = nullptr;
+    int rc = bn_ws(workspace, workspace_bytes, rows_g, C, groups, &part, &folded, &partb, "sv_batchnorm_sync_moments");
+    if (rc) return rc;
+    hipStream_t st = to_stream(stream);
+    size_t lds;
+    const int vec = row_vec(dtype, C, 2, 512 * sizeof(float), &lds, {x});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_stats_k<T>, dim3(p.nblocks, groups), dim3(256), lds, st, (const T*)x, part, rows_g,
+                                        C, p.rows_per_block, vec););
+    rc = check_launch("bn_stats");
+    if (rc) return rc;
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_local_moments_k<T>, dim3((unsigned)ceil_div(C, 64)), dim3(64 * kFoldWaves), 0, st,
+                                        (const T*)x, part, p.nblocks, moments, rows_g, C, groups););
+    return check_launch("bn_local_moments");
+}
+
+int sv_batchnorm_sync_fwd_apply(const void* x, const float* gamma, const float* beta, const float* mean,
+                                const float* invstd, void* y, int64_t rows, int C, int groups, int act, float alpha,
+                                int dtype, sv_stream_t stream) {
+    SV_F32_OR_BF16(dtype, "sv_batchnorm_sync_fwd_apply");
+    SV_REQUIRE(x && gamma && beta && mean && invstd && y && rows > 0 && C > 0 && groups >= 1 && rows % groups == 0,
+               "sv_batchnorm_sync_fwd_apply: bad arguments");
+    const int64_t total = rows * C;
+    size_t unused;
+    const int vec = row_vec(dtype, C, 0, 0, &unused, {x, y});
+    SV_WITH_T(dtype, hipLaunchKernelGGL(bn_apply_k<T>, dim3(ew_grid(total / 4 + 1, 256, 8192)), dim3(256), 0, to_stream(stream),
+                                        (const T*)x, gamma, beta, mean, invstd, 0, 0.f, (T*)y, total, C, act, alpha,
+                                        rows / groups * C, vec););
+    return check_launch("sv_batchnorm_sync_fwd_apply");
+}
+
+int sv_batchnorm_sync_bwd_sums(const void* x, const void* dy, const void* y_act, int act_out, float alpha_out,
+                               const float* mean, const float* invstd, float* sums, float* dgamma, float* dbeta,
+                               int accumulate, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
+                               int dtype, sv_stream_t stream) {
+    SV_REQUIRE(sums != nullptr, "sv_batchnorm_sync_bwd_sums: null sums");
+    return bn_bwd_impl(1, sums, 0, x, dy, y_act, act_out, alpha_out, nullptr, mean, invstd, nullptr, dgamma, dbeta, accumulate,
+                       SV_ACT_NONE, 0.f, nullptr, 0, rows, C, groups, workspace, workspace_bytes, dtype, stream);
+}
+
+int sv_batchnorm_sync_bwd_apply(const void* x, const void* dy, const void* y_act, int act_out, float alpha_out,
+                                const float* gamma, const float* mean, const float* invstd, const float* sums,
+                                int64_t all_rows_per_group, void* dx, int act_in, float alpha_in, float* dbias_in,
+                                int dbias_accumulate, int64_t rows, int C, int groups, void* workspace,
+                                size_t workspace_bytes, int dtype, sv_stream_t stream) {
+    SV_REQUIRE(sums != nullptr && all_rows_per_group >= rows / (groups > 0 ? groups : 1),
+               "sv_batchnorm_sync_bwd_apply: the sums must cover at least this replica's rows");
+    return bn_bwd_impl(2, const_cast<float*>(sums), all_rows_per_group, x, dy, y_act, act_out, alpha_out, gamma, mean, invstd,
+                       dx, nullptr, nullptr, 0, act_in, alpha_in, dbias_in, dbias_accumulate, rows, C, groups, workspace,
+                       workspace_bytes, dtype, stream);
 }
 
 int sv_batchnorm_bwd(const void* x, const void* dy, const float* gamma, const float* save_mean,

@@ -388,6 +388,8 @@ class Model(Layer):
                 self._refresh_lp()
             x = self._to_act(x, ctx.slot)
         ctx.loss_fold = None
+        if training and self._reducer is not None and getattr(self._reducer, "sync_batchnorm", False):
+            ctx.sync_bn = self._reducer
         ctx.bn_groups = int(bn_groups)  # the batch is this many independent BatchNorm groups (see CallCtx)
         self._last_ctx = ctx
         if fold_mask:  # the first layer that runs takes the request (a Conv2D folds it into its gathers)
@@ -445,6 +447,8 @@ class Model(Layer):
         """The kernel-gradient jobs of this backward pass can stay slabs for the optimizer launch: the library has that
         form for all of them and together they are every trainable variable of the model (nothing else writes
         gradients), decided once per batch size."""
+        if not jobs:
+            return False
         key = ("slabs", jobs[0]["g"].N, len(jobs))
         ok = self._chain_cache.get(key)
         if ok is None:
@@ -703,8 +707,15 @@ class Model(Layer):
 
     def graph_safe(self) -> bool:
         """A step can be frozen into a HIP graph when no layer needs fresh host-side arguments per call."""
-        from .nn import Dropout
-        return not any(isinstance(l, Dropout) and l.rate > 0 for l in self._all_layers())
+        from .nn import BatchNormalization, Dropout
+        layers = self._all_layers()
+        if any(isinstance(l, Dropout) and l.rate > 0 for l in layers):
+            return False
+        red = self._reducer
+        if red is not None and getattr(red, "sync_batchnorm", False) and any(isinstance(l, BatchNormalization) for l in layers):
+            # the statistics exchange sits inside the forward and backward passes: recordable only where the collective is
+            return red.capturable(self._params.device)
+        return True
 
     def _to_resident(self, a, device):
         """Training data lives in HBM in its original precision (float64 stays float64; the batch gather

@@ -229,6 +229,8 @@ class CallCtx:
         # BatchNorm statistics groups: the batch is this many equal consecutive parts, each normalised on its own (a
         # discriminator called on [real; generated] in one pass instead of twice)
         self.bn_groups = 1
+        # a parallel.GradReducer with sync_batchnorm: BatchNorm statistics run over the rows of every replica
+        self.sync_bn = None
 
     def buf(self, layer, role, shape, dtype=None):
         return self.pool.get((id(layer), role, self.slot), shape, self.dtype if dtype is None else dtype)
@@ -244,6 +246,7 @@ class CallCtx:
         groups = self.bn_groups
         v = CallCtx(self.pool, ("grp", g, self.slot), self.training, self.dtype)
         v.param_grads = self.param_grads
+        v.sync_bn = self.sync_bn
         for key, d in self.saved.items():
             nd = {}
             for name, t in d.items():
@@ -705,6 +708,21 @@ class BatchNormalization(Layer):
             mean = ctx.buf(self, "mean", (g, c), torch.float32)
             invstd = ctx.buf(self, "invstd", (g, c), torch.float32)
             ws = ctx.pool.workspace(ops.batchnorm_workspace(rows, c, g))
+            if ctx.sync_bn is not None:
+                # statistics over the rows of every replica: local moments, the replicas' exchange, then the apply launch
+                mom = ctx.buf(self, "moments", (g, 3, c), torch.float64)
+                ops.batchnorm_sync_moments(x, mom, rows, c, g, ws)
+                m_all, inv_all, var, total = ctx.sync_bn.combine_moments(mom, self.epsilon)
+                mean.copy_(m_all)
+                invstd.copy_(inv_all)
+                for k in range(g):  # one moving-statistics update per group, in order
+                    v = var[k] * total[k] / (total[k] - 1.0) if self.unbiased else var[k]
+                    self.moving_mean.data.mul_(self.momentum).add_(m_all[k], alpha=1.0 - self.momentum)
+                    self.moving_variance.data.mul_(self.momentum).add_(v.float(), alpha=1.0 - self.momentum)
+                ops.batchnorm_sync_fwd_apply(x, self.gamma.data, self.beta.data, mean, invstd, y, rows, c, g, act, alpha)
+                ctx.saved[id(self)] = {"x": x, "y": y, "mean": mean, "invstd": invstd,
+                                       "all_rows": rows // g * ctx.sync_bn.world}
+                return y
             ops.batchnorm_act_fwd_train(x, self.gamma.data, self.beta.data, y, mean, invstd, self.moving_mean.data,
                                         self.moving_variance.data, rows, c, self.epsilon, self.momentum, self.unbiased,
                                         g, act, alpha, ws)
@@ -736,6 +754,15 @@ class BatchNormalization(Layer):
             if conv.bias is not None and ctx.param_grads:
                 dbias = conv.bias.grad
             ctx.saved[id(conv)]["dz_done"] = True
+        if "all_rows" in s:  # statistics over every replica: so are the two sums of the input gradient
+            sums = ctx.buf(self, "bwd_sums", (g, 2, c), torch.float32)
+            yact = s["y"] if act_out is not None else None
+            ops.batchnorm_sync_bwd_sums(x, dy, yact, act_out, alpha_out, s["mean"], s["invstd"], sums, dg, db, acc, rows, c,
+                                        g, ws)
+            ctx.sync_bn.all_reduce_small(sums)
+            ops.batchnorm_sync_bwd_apply(x, dy, yact, act_out, alpha_out, self.gamma.data, s["mean"], s["invstd"], sums,
+                                         s["all_rows"], dx, act_in, alpha_in, dbias, True, rows, c, g, ws)
+            return dx
         ops.batchnorm_act_bwd(x, dy, s["y"] if act_out is not None else None, act_out, alpha_out, self.gamma.data,
                               s["mean"], s["invstd"], dx, dg, db, acc, act_in, alpha_in, dbias, True, rows, c, g, ws)
         return dx

@@ -452,6 +452,42 @@ def batchnorm_act_bwd(x, dy, y_act, act_out, alpha_out: float, gamma, save_mean,
                                    _dt(x), _stream()), "sv_batchnorm_act_bwd")
 
 
+def batchnorm_sync_moments(x, moments, rows, c, groups: int, ws):
+    """Per group and channel (rows, mean, sum of squared deviations) of this replica's rows into ``moments``
+    (float64 [groups, 3, C]); see ``parallel.GradReducer.combine_moments`` for the exchange."""
+    if moments.dtype != torch.float64 or moments.numel() != groups * 3 * c:
+        raise ValueError("batchnorm_sync_moments: moments must be float64 [groups][3][C]")
+    check(lib.sv_batchnorm_sync_moments(_aptr(x), _ptr(moments, torch.float64), rows, c, groups, _ptr(ws, torch.uint8),
+                                        ws.numel(), _dt(x), _stream()), "sv_batchnorm_sync_moments")
+
+
+def batchnorm_sync_fwd_apply(x, gamma, beta, mean, invstd, y, rows, c, groups: int, act, alpha: float):
+    check(lib.sv_batchnorm_sync_fwd_apply(_aptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _aptr(y, x, "y"),
+                                          rows, c, groups, ACT[act], alpha, _dt(x), _stream()),
+          "sv_batchnorm_sync_fwd_apply")
+
+
+def batchnorm_sync_bwd_sums(x, dy, y_act, act_out, alpha_out: float, mean, invstd, sums, dgamma, dbeta, accumulate: bool,
+                            rows, c, groups: int, ws):
+    if sums.dtype != torch.float32 or sums.numel() != groups * 2 * c:
+        raise ValueError("batchnorm_sync_bwd_sums: sums must be float32 [groups][2][C]")
+    check(lib.sv_batchnorm_sync_bwd_sums(_aptr(x), _aptr(dy, x, "dy"),
+                                         _aptr(y_act, x, "y_act") if y_act is not None else None, ACT[act_out], alpha_out,
+                                         _ptr(mean), _ptr(invstd), _ptr(sums), _ptr(dgamma), _ptr(dbeta), int(accumulate),
+                                         rows, c, groups, _ptr(ws, torch.uint8), ws.numel(), _dt(x), _stream()),
+          "sv_batchnorm_sync_bwd_sums")
+
+
+def batchnorm_sync_bwd_apply(x, dy, y_act, act_out, alpha_out: float, gamma, mean, invstd, sums, all_rows_per_group: int,
+                             dx, act_in, alpha_in: float, dbias_in, dbias_accumulate: bool, rows, c, groups: int, ws):
+    check(lib.sv_batchnorm_sync_bwd_apply(_aptr(x), _aptr(dy, x, "dy"),
+                                          _aptr(y_act, x, "y_act") if y_act is not None else None, ACT[act_out], alpha_out,
+                                          _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(sums), int(all_rows_per_group),
+                                          _aptr(dx, x, "dx"), ACT[act_in], alpha_in, _ptr(dbias_in), int(dbias_accumulate),
+                                          rows, c, groups, _ptr(ws, torch.uint8), ws.numel(), _dt(x), _stream()),
+          "sv_batchnorm_sync_bwd_apply")
+
+
 def concat_channels_fwd(a, b, y, rows, ca, cb):
     check(lib.sv_concat_channels_fwd(_aptr(a), _aptr(b, a, "b"), _aptr(y, a, "y"), rows, ca, cb, _dt(a), _stream()),
           "sv_concat_channels_fwd")

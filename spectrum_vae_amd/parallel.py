@@ -50,8 +50,12 @@ class GradReducer:
     """Sum-all-reduce of a flat gradient buffer.  ``all_reduce`` returns the factor the optimizer must apply
     to the summed gradient (1 / world_size)."""
 
-    def __init__(self, group=None, bucket_bytes: int = 8 << 20, force_collective: Optional[bool] = None):
+    def __init__(self, group=None, bucket_bytes: int = 8 << 20, force_collective: Optional[bool] = None,
+                 sync_batchnorm: bool = False):
         self.group = group
+        # BatchNormalization layers of a model this reducer is attached to take their batch statistics (and the two
+        # sums of their backward pass) over the rows of every replica: N replicas at batch B equal one at batch N * B
+        self.sync_batchnorm = bool(sync_batchnorm)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.calls = 0
         self.bytes = 0
@@ -146,6 +150,39 @@ class GradReducer:
             flag = flag.cpu()
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(flag.item() > 0)
+
+    def all_reduce_small(self, t: torch.Tensor):
+        """In-place sum of a small device tensor over the replicas (BatchNorm's backward sums), on the current stream."""
+        if self._collective():
+            if self._host_staged and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def combine_moments(self, moments: torch.Tensor, eps: float):
+        """``moments`` float64 [groups, 3, C] = (rows, mean, sum of squared deviations) of this replica.  Returns
+        (mean float32 [groups, C], invstd float32 [groups, C], biased variance float64, rows of all replicas per group) of
+        the rows of EVERY replica: count-weighted mean, and deviations + count * (mean - combined mean)^2, in float64."""
+        if self._collective():
+            if self._host_staged:  # gloo gathers host tensors, into a list
+                h = moments.cpu() if moments.is_cuda else moments.contiguous()
+                parts = [torch.empty_like(h) for _ in range(self.world)]
+                dist.all_gather(parts, h, group=self.group)
+                allm = torch.stack(parts).to(moments.device)
+            else:
+                allm = torch.empty((self.world,) + tuple(moments.shape), dtype=moments.dtype, device=moments.device)
+                dist.all_gather_into_tensor(allm, moments.contiguous(), group=self.group)
+        else:
+            allm = moments.unsqueeze(0)
+        n, mean_r, m2_r = allm[:, :, 0], allm[:, :, 1], allm[:, :, 2]
+        total = n.sum(0)
+        mean = (n * mean_r).sum(0) / total
+        m2 = (m2_r + n * (mean_r - mean) ** 2).sum(0)
+        var = m2 / total
+        return mean.float(), torch.rsqrt(var + eps).float(), var, total
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         """Make every replica start from rank ``src``'s values (weights, BatchNorm state)."""

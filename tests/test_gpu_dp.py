@@ -20,13 +20,13 @@ def _free_port():
     return p
 
 
-def _run(world, bpr, steps, out, worker="dp_hip_worker.py"):
+def _run(world, bpr, steps, out, worker="dp_hip_worker.py", extra=()):
     """``worker`` dp_hip_worker.py: (bpr, steps) are its batch-per-rank and step count; dp_gan_worker.py: they are its
     BACKEND and SHARDS arguments."""
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(r), str(world), port, out,
-                               str(bpr), str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               str(bpr), str(steps), *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     for p in procs:
         try:
@@ -56,6 +56,23 @@ def test_two_ranks_at_batch_b_equal_one_rank_at_batch_2b(tmp_path):
     moved = np.max(np.abs(s0["params"])) > 0 and steps * 5e-4 > 1e-4
     assert moved
 
+
+
+@pytest.mark.parametrize("kind", ["cae_bn", "disc"])
+def test_synchronised_batchnorm_two_ranks_equal_one_rank_at_twice_the_batch(tmp_path, kind):
+    """BatchNormalization with the reducer's sync_batchnorm: statistics (forward) and the two sums of the input gradient
+    (backward) run over the rows of both ranks, so two ranks at batch B are one process at batch 2 B - weights, losses
+    and the moving statistics to 1e-5 - for CAEPadded(batch_norm=True) and context_encoder.Discriminator."""
+    steps, bpr = 4, 32
+    d2, d1 = tmp_path / "w2", tmp_path / "w1"
+    d2.mkdir(); d1.mkdir()
+    r0, r1 = _run(2, bpr, steps, str(d2), extra=(kind,))
+    (s0,) = _run(1, 2 * bpr, steps, str(d1), extra=(kind,))
+    assert np.array_equal(r0["params"], r1["params"]) and np.array_equal(r0["state"], r1["state"])
+    assert np.allclose((r0["losses"] + r1["losses"]) / 2, s0["losses"], rtol=2e-5, atol=1e-7)
+    assert r0["state"].size > 0 and np.max(np.abs(r0["state"] - s0["state"])) <= 1e-5
+    assert np.max(np.abs(r0["params"] - s0["params"])) <= 1e-5
+    assert np.max(np.abs(s0["params"])) > 0
 
 
 PARAM_KEYS = ("ae_params", "ce_params", "ced_params", "un_params", "und_params")

@@ -328,6 +328,43 @@ def test_data_parallel_world2_equals_single_process_full_batch(tmp_path):
     assert (r0 - single).abs().max().item() < 1e-9
 
 
+def _syncbn_worker(rank, world, port, out):
+    """Each rank: the moments of its shard -> GradReducer.combine_moments; a small sum through all_reduce_small."""
+    import torch.distributed as dist
+    from spectrum_vae_amd.parallel import GradReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = torch.tensor(np.random.default_rng(11).standard_normal((2, 12, 5)) * 3 + 100.0, dtype=torch.float64)
+        shard = X[:, rank * 6:(rank + 1) * 6]  # [groups, rows, C]: every group's rows split over the ranks
+        mom = torch.stack([torch.full((2, 5), 6.0, dtype=torch.float64), shard.mean(1),
+                           ((shard - shard.mean(1, keepdim=True)) ** 2).sum(1)], dim=1)  # [groups, 3, C]
+        red = GradReducer(sync_batchnorm=True)
+        mean, invstd, var, total = red.combine_moments(mom, 1e-3)
+        s = red.all_reduce_small(torch.full((3,), float(rank + 1)))
+        torch.save({"mean": mean, "invstd": invstd, "var": var, "total": total, "sum": s}, os.path.join(out, f"bn{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batchnorm_moments_of_two_ranks_combine_to_the_statistics_of_all_rows(tmp_path):
+    """The exchange step of synchronised BatchNorm at world_size 2 over gloo: count-weighted means and deviations plus
+    the between-rank term reproduce mean / biased variance of the undivided rows (data with mean 100, deviation 3: the
+    form sum(x^2) / n - mean^2 would lose five digits in float32; this one is exact to float64 round-off)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "bn0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(tmp_path, "bn1.pt"), weights_only=True)
+    X = torch.tensor(np.random.default_rng(11).standard_normal((2, 12, 5)) * 3 + 100.0, dtype=torch.float64)
+    for r in (r0, r1):
+        assert torch.equal(r["total"], torch.full((2, 5), 12.0, dtype=torch.float64))
+        assert (r["var"] - X.var(1, unbiased=False)).abs().max() < 1e-12
+        assert (r["mean"].double() - X.mean(1)).abs().max() < 1e-5 and r["mean"].dtype == torch.float32
+        assert (r["invstd"].double() - (X.var(1, unbiased=False) + 1e-3).rsqrt()).abs().max() < 1e-6
+        assert torch.equal(r["sum"], torch.full((3,), 3.0))
+
+
 def test_init_from_env_single_process_is_a_no_op(monkeypatch):
     from spectrum_vae_amd import parallel
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
