@@ -409,6 +409,17 @@ class Model(Layer):
         "sum the partial slabs into dw / db" steps of the strided / transposed conv family are queued and run as ONE
         launch at the end of the pass (every layer then works in scratch of its own)."""
         ctx = self._calls[call]
+        # data-parallel, gradient buffer of several buckets: the buckets leave for the all-reduce as the pass completes
+        # them, which needs every gradient written by its own layer's launches (no batched or deferred reductions)
+        pipe = None
+        if self._reducer is not None and ctx.param_grads and ctx.side is None and len(self._calls) == 1:
+            pipe = self._reducer.pipeline(self._grads, self.trainable_variables)
+        if pipe is not None:
+            ctx.grad_ready = pipe.done
+            try:
+                return self._backward_raw(ctx, dy, need_dx)
+            finally:
+                ctx.grad_ready = None
         if not (self.defer_reduces and ctx.param_grads and ctx.side is None):
             return self._backward_raw(ctx, dy, need_dx)
         ops.deferred_reduce_begin()
@@ -425,7 +436,7 @@ class Model(Layer):
 
     def _backward_raw(self, ctx, dy: torch.Tensor, need_dx: bool):
         self._grads_clean = False
-        if self.defer_wgrad_reduce and ctx.param_grads and ctx.wgrad_jobs is None:
+        if self.defer_wgrad_reduce and ctx.param_grads and ctx.wgrad_jobs is None and ctx.grad_ready is None:
             ctx.wgrad_jobs, ctx.wgrad_finish = [], []
             dx = self.backward(ctx, dy, need_dx=need_dx)
             nb = self.wgrad_batch_blocks if len(ctx.wgrad_jobs) >= 3 else 0

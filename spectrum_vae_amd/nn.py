@@ -231,6 +231,9 @@ class CallCtx:
         self.bn_groups = 1
         # a parallel.GradReducer with sync_batchnorm: BatchNorm statistics run over the rows of every replica
         self.sync_bn = None
+        # callable(variables): a layer's gradients are final on the compute stream (a data-parallel bucket pipeline
+        # sends the buckets they complete); set for one backward pass
+        self.grad_ready = None
 
     def buf(self, layer, role, shape, dtype=None):
         return self.pool.get((id(layer), role, self.slot), shape, self.dtype if dtype is None else dtype)
@@ -1021,6 +1024,10 @@ class Sequential(Layer):
         for i in range(len(self.layers) - 1, -1, -1):
             want = need_dx or i > first
             dy = self.layers[i].backward(ctx, dy, need_dx=want)
+            if ctx.grad_ready is not None:
+                vs = self.layers[i].all_variables()
+                if vs:
+                    ctx.grad_ready(vs)
             if dy is None:
                 return None
         mask = ctx.saved.get(("input_mask", id(self)))

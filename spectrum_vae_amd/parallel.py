@@ -8,8 +8,11 @@ launch (``grad_scale``) makes N ranks at batch B identical to one rank at batch 
 losses used here (BatchNorm statistics stay per-rank unless ``sync_batchnorm`` is added).
 
 Gradient messages are small (48 KB for the default CAEPadded, 18 MB for the context encoder), i.e. the
-collective is latency-bound on xGMI.  The flat buffer goes out in buckets of ``bucket_bytes`` (one bucket for the
-small models; a ring all-reduce of the larger ones pipelines over the buckets), on the compute stream.  With RCCL
+collective is latency-bound on xGMI.  The flat buffer goes out in buckets of ``bucket_bytes``.  A model whose buffer is
+ONE bucket reduces it on the compute stream after the backward pass; a larger one hands its buckets to a communication
+stream DURING the backward pass (``BucketPipeline``): a bucket goes out as soon as the last gradient inside it has been
+written - the decoder's first, since the pass runs from the output back - and the optimizer launch waits for the last
+bucket, so all but the first layers' exchange hides behind the rest of the pass.  With RCCL
 the collective is recorded INTO the step's HIP graph (after a probe that records and replays a small all-reduce and
 that every rank must pass); otherwise (gloo rehearsals, a failed probe) the step is two graphs with the all-reduce
 issued between them.
@@ -46,6 +49,68 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+class BucketPipeline:
+    """The buckets of one flat gradient buffer on their way out during a backward pass.
+
+    ``done(variables)`` is called (on the compute stream's host thread) when a layer's gradients are final on the
+    compute stream; a bucket all of whose variables are done is reduced: on the communication stream behind an event
+    (RCCL), or at once through host memory (gloo rehearsals).  ``finish()`` sends what is left and makes the compute
+    stream wait for every bucket.  Elements of the buffer that belong to no variable (alignment gaps) count as done."""
+
+    def __init__(self, reducer: "GradReducer", flat: torch.Tensor, variables):
+        self.red, self.flat = reducer, flat.view(-1)
+        per = max(4, (reducer.bucket_bytes // self.flat.element_size()) & ~3)
+        n = self.flat.numel()
+        self.bounds = [(lo, min(lo + per, n)) for lo in range(0, n, per)]
+        self.pending = [0] * len(self.bounds)  # variables of each bucket not final yet
+        self.where = {}                        # id(variable) -> buckets it overlaps
+        for v in variables:
+            ks = [k for k, (lo, hi) in enumerate(self.bounds) if v.offset < hi and v.offset + v.size > lo]
+            self.where[id(v)] = ks
+            for k in ks:
+                self.pending[k] += 1
+        self.sent = [False] * len(self.bounds)
+        self.seen = set()
+        self.order = []  # buckets in the order they went out
+        self.comm = reducer.comm_stream(flat.device) if (flat.is_cuda and not reducer._host_staged) else None
+        self.last = None
+
+    def _send(self, k: int):
+        lo, hi = self.bounds[k]
+        self.sent[k] = True
+        self.order.append(k)
+        b = self.flat[lo:hi]
+        if self.comm is None:
+            self.red._reduce(b, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.red.group))
+            return
+        main = torch.cuda.current_stream(self.flat.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.red.group)
+            self.last = torch.cuda.Event()
+            self.last.record(self.comm)
+
+    def done(self, variables):
+        for v in variables:
+            if id(v) in self.seen or id(v) not in self.where:
+                continue
+            self.seen.add(id(v))
+            for k in self.where[id(v)]:
+                self.pending[k] -= 1
+        for k in range(len(self.bounds) - 1, -1, -1):  # the buffer's tail holds the layers the pass reaches first
+            if not self.sent[k] and self.pending[k] == 0:
+                self._send(k)
+
+    def finish(self):
+        for k in range(len(self.bounds) - 1, -1, -1):
+            if not self.sent[k]:
+                self._send(k)
+        if self.last is not None:
+            torch.cuda.current_stream(self.flat.device).wait_event(self.last)
+
+
 class GradReducer:
     """Sum-all-reduce of a flat gradient buffer.  ``all_reduce`` returns the factor the optimizer must apply
     to the summed gradient (1 / world_size)."""
@@ -56,6 +121,10 @@ class GradReducer:
         # BatchNormalization layers of a model this reducer is attached to take their batch statistics (and the two
         # sums of their backward pass) over the rows of every replica: N replicas at batch B equal one at batch N * B
         self.sync_batchnorm = bool(sync_batchnorm)
+        self.overlap = True          # multi-bucket buffers go out during the backward pass (BucketPipeline)
+        self._comm = {}              # device -> communication stream
+        self._pipelines = {}         # data_ptr of a flat buffer -> its pipeline of the pass that just ran
+        self.last_pipeline = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.calls = 0
         self.bytes = 0
@@ -88,7 +157,31 @@ class GradReducer:
         per = max(4, (self.bucket_bytes // v.element_size()) & ~3)
         return [v[i:i + per] for i in range(0, v.numel(), per)]
 
+    def comm_stream(self, device):
+        key = torch.device(device).index
+        if key not in self._comm:
+            self._comm[key] = torch.cuda.Stream(device=device)
+        return self._comm[key]
+
+    def pipeline(self, flat: torch.Tensor, variables) -> Optional[BucketPipeline]:
+        """A ``BucketPipeline`` for the backward pass about to run, or None when the buffer goes out in one piece (one
+        bucket, no collective, overlap switched off, or a stream recording that cannot hold the collective)."""
+        if not (self.overlap and self._collective()) or flat.numel() * flat.element_size() <= self.bucket_bytes:
+            return None
+        if flat.is_cuda and torch.cuda.is_current_stream_capturing() and (self._host_staged or not self.capturable(flat.device)):
+            return None
+        p = BucketPipeline(self, flat, variables)
+        self._pipelines[flat.data_ptr()] = p
+        return p
+
     def all_reduce(self, flat: torch.Tensor) -> float:
+        p = self._pipelines.pop(flat.data_ptr(), None)
+        if p is not None:  # the buckets left during the backward pass: send the rest, join the communication stream
+            early = len(p.order)
+            p.finish()
+            self.last_pipeline = (tuple(p.order), early)  # (buckets in the order sent, how many left during the pass)
+            self.note_reduced(flat)
+            return 1.0 / self.world
         if self._collective():
             if self._host_staged and flat.is_cuda:
                 self._reduce(flat, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))

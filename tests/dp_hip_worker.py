@@ -8,7 +8,9 @@ attached (two recorded graphs with the all-reduce between them; gloo when the ra
 the same steps on the whole batch without a reducer.  Weights and per-step losses go to OUTDIR/rank<r>.npz.
 KIND: "cae" (default), "cae_bn" = the auto-encoder with BatchNormalization and "disc" = context_encoder.Discriminator
 (MSE against a constant), both with the reducer's sync_batchnorm on: statistics over the rows of both ranks, steps run
-eagerly (the exchange inside the passes goes through host memory with gloo).
+eagerly (the exchange inside the passes goes through host memory with gloo).  "ce_overlap" / "ce_plain" =
+context_encoder.ContextEncoder (18 MB of gradients) with 1 MB buckets, eager steps, the buckets sent during the backward
+pass or after it.
 """
 import os
 import sys
@@ -36,14 +38,23 @@ def main():
     assert (r, w) == (rank, world)
     torch.cuda.set_device(0)
     device = torch.device("cuda", 0)
-    model = context_encoder.Discriminator() if kind == "disc" else autoencoder.CAEPadded(**dict(CFG, batch_norm=kind == "cae_bn"))
+    if kind.startswith("ce_"):
+        model = context_encoder.ContextEncoder()
+        model.use_graphs = False
+    elif kind == "disc":
+        model = context_encoder.Discriminator()
+    else:
+        model = autoencoder.CAEPadded(**dict(CFG, batch_norm=kind == "cae_bn"))
     model.build((None, 32, 32, 3))
     model._materialize(device)
     model.compile(optimizer=build_optimizer(learning_rate=5e-4), loss=losses.MeanSquaredError())
     red = None
     if world > 1:
-        red = parallel.GradReducer(sync_batchnorm=kind != "cae")
+        red = parallel.GradReducer(sync_batchnorm=kind in ("cae_bn", "disc"))
         assert red.world == world
+        if kind.startswith("ce_"):
+            red.bucket_bytes = 1 << 20
+            red.overlap = kind == "ce_overlap"
         if rank != 0:  # replicas start different on purpose: the broadcast must make them equal
             model._params.mul_(1.5)
         red.broadcast_(model._params)
@@ -62,14 +73,16 @@ def main():
         ops.gather_rows(Xd[g0 + rank * bpr:g0 + (rank + 1) * bpr], None, b["x"])
         model.train_on_device_batch(b, same_xy, float(bs))
         step_losses.append(float(b["loss"].item()))
-    if kind == "cae" or world == 1:
+    if kind == "cae" or (world == 1 and not kind.startswith("ce_")):
         g = next(iter(model._graphs.values()))
         assert not isinstance(g, str) and len(g) == (2 if world > 1 else 1), "the step was not replayed from graphs"
     if red is not None:
         assert red.calls == steps
     state = [v.numpy().ravel() for v in model.non_trainable_variables]
+    order, early = red.last_pipeline if red is not None and red.last_pipeline else ((), 0)
     np.savez(os.path.join(out, f"rank{rank}.npz"), params=model._params.cpu().numpy(), losses=np.array(step_losses),
-             state=np.concatenate(state) if state else np.zeros(0, np.float32))
+             state=np.concatenate(state) if state else np.zeros(0, np.float32), order=np.array(order, np.int64),
+             early=np.int64(early))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

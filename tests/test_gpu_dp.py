@@ -75,6 +75,23 @@ def test_synchronised_batchnorm_two_ranks_equal_one_rank_at_twice_the_batch(tmp_
     assert np.max(np.abs(s0["params"])) > 0
 
 
+def test_buckets_sent_during_the_backward_pass_equal_the_reduction_after_it(tmp_path):
+    """context_encoder.ContextEncoder on two ranks, 1 MB buckets: with the bucket pipeline the buckets leave last-first
+    while the backward pass is still running (all but the ones holding the first layers), and weights, losses and
+    BatchNorm state are bit-identical to the steps that reduce the whole buffer after the pass."""
+    steps, bpr = 3, 16
+    da, db = tmp_path / "overlap", tmp_path / "plain"
+    da.mkdir(); db.mkdir()
+    a0, a1 = _run(2, bpr, steps, str(da), extra=("ce_overlap",))
+    b0, b1 = _run(2, bpr, steps, str(db), extra=("ce_plain",))
+    for k in ("params", "losses", "state"):
+        assert np.array_equal(a0[k], b0[k]) and np.array_equal(a1[k], b1[k]), k
+    assert np.array_equal(a0["params"], a1["params"])
+    order = list(a0["order"])
+    assert len(order) >= 17 and order == sorted(order, reverse=True)  # 18 MB in 1 MB buckets, the buffer's tail first
+    assert int(a0["early"]) >= len(order) - 2 and len(b0["order"]) == 0
+
+
 PARAM_KEYS = ("ae_params", "ce_params", "ced_params", "un_params", "und_params")
 LOSS_KEYS = ("ae_losses", "ce_losses", "un_losses")
 

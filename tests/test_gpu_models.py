@@ -43,7 +43,7 @@ def _ref_pass(ref, x, tgt, dtype, dropout_masks=None):
     for p in ref.params:
         p.grad = None
     masks = None if dropout_masks is None else {k: v.to(dtype) for k, v in dropout_masks.items()}
-    pr = ref(xt, training=True, dropout_masks=masks)
+    pr = ref(xt, training=True) if masks is None else ref(xt, training=True, dropout_masks=masks)
     loss = torch_ref.mse(torch.from_numpy(tgt).to(dtype), pr)
     loss.backward()
     return pr.detach().numpy(), float(loss), [p.grad.numpy().copy() for p in ref.params]
@@ -833,7 +833,7 @@ def test_bench_shape_step_matches_oracle():
     model = autoencoder.CAEPadded(**RUN_MODEL_DEFAULTS)
     model.build((None, 32, 32, 3))
     model._materialize()
-    assert model.wgrad_batch_blocks_large == 128 and model.wgrad_batch_blocks == 256
+    assert model.wgrad_batch_blocks_large == 128 and model.wgrad_batch_blocks == 128
     enc, dec = omodels.caepadded(**RUN_MODEL_DEFAULTS)
     ref = RefSequential(enc + dec, (32, 32, 3))
     load_into_ref(ref, model)
