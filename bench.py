@@ -212,20 +212,20 @@ def _dominant_call(table, dtype: str) -> dict:
             "frac_of_matrix_peak": round(f_m, 4), "frac_of_hbm_peak": round(f_h, 4)}
 
 
-def run_secondary(device, steps: int = 30) -> dict:
+def run_secondary(device, steps: int = 40) -> dict:
     """The other single-GPU configurations under the same clock as the headline, after its timed region: the U-Net GAN
     step of run_unet.py:164-203 under the bf16 policy at batch 32 and 1024, the context-encoder + discriminator step of
     run_context_encoder.py:225-260 in f32 at batch 64, and one VAEPadded (MSE + KL) step at batch 1024.  Each: best of
-    three runs of `steps` HIP-graph replays, and the dominant conv call of one eager step against its roof."""
+    five runs of `steps` HIP-graph replays, and the dominant conv call of one eager step against its roof."""
     from spectrum_vae_amd import autoencoder, context_encoder, losses, mixed_precision, run_context_encoder, run_unet, unet
     from spectrum_vae_amd.data import synth_training_tensor
     from spectrum_vae_amd.run_model import build_optimizer
 
-    def timed(fn):
-        for _ in range(6):
+    def timed(fn):  # the same procedure as tools/bench_models.py: 10 untimed steps, best of five runs
+        for _ in range(10):
             fn()
         best = None
-        for _ in range(3):
+        for _ in range(5):
             torch.cuda.synchronize()
             t = time.perf_counter()
             for _ in range(steps):
@@ -511,6 +511,9 @@ def main():
 
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()  # the secondary models record their graphs into pools of their own, as in a fresh process
         secondary = run_secondary(device)
 
     cpu = None

@@ -22,12 +22,12 @@ from spectrum_vae_amd.data import synth_training_tensor  # noqa: E402
 
 
 def timed(fn, steps):
-    """Mean step time of the best of three timed runs of ``steps`` steps (after 10 untimed ones): these steps are a few
+    """Mean step time of the best of five timed runs of ``steps`` steps (after 10 untimed ones): these steps are a few
     hundred microseconds of GPU work behind a host-side graph launch, so a single run also measures the host's mood."""
     for _ in range(10):
         fn()
     best = None
-    for _ in range(3):
+    for _ in range(5):
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(steps):

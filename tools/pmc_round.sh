@@ -6,8 +6,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1
 out=gpurun_out/pmc_${tag}_step
 mkdir -p $out/p1 $out/p2
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $out/p1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > $out/p1.out 2> $out/p1.err || { echo pass 1 failed; tail -3 $out/p1.err; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $out/p2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > $out/p2.out 2> $out/p2.err || { echo pass 2 failed; tail -3 $out/p2.err; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $out/p1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-graph > $out/p1.out 2> $out/p1.err || { echo pass 1 failed; tail -3 $out/p1.err; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $out/p2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-graph > $out/p2.out 2> $out/p2.err || { echo pass 2 failed; tail -3 $out/p2.err; exit 1; }
 python3 - <<PY
 import csv, collections, glob, json
 res = collections.defaultdict(dict)

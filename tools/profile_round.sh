@@ -5,11 +5,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1
 out=gpurun_out/profile_$tag
 mkdir -p $out/trace $out/fetch $out/write
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_under_trace.json 2> $out/trace_err.log || { echo trace failed; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $out/bench_under_trace.json 2> $out/trace_err.log || { echo trace failed; exit 1; }
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
-timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > $out/fetch_out.json 2> $out/fetch_err.log || { echo fetch pass failed; exit 1; }
+timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-graph > $out/fetch_out.json 2> $out/fetch_err.log || { echo fetch pass failed; exit 1; }
 cp $(find $out/fetch -name "*counter_collection.csv" | head -1) $out/fetch.csv
-timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > $out/write_out.json 2> $out/write_err.log || { echo write pass failed; exit 1; }
+timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-graph > $out/write_out.json 2> $out/write_err.log || { echo write pass failed; exit 1; }
 cp $(find $out/write -name "*counter_collection.csv" | head -1) $out/write.csv
 python3 - <<PY
 import csv, collections, json
