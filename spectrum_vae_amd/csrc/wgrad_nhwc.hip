@@ -90,10 +90,17 @@ struct WnRegs {
 // row, overlaps them on three).
 constexpr int wn_rps(int CS, int WO) { return CS == 3 ? ((WO + 2) * 3 + 31 - 16) / 32 * 32 + 16 : (WO + 2) * CS; }
 
-template <int CS, int CP, int SWAP, int WO>
+// PAIR (8-channel P, whose channels fill half of a 16-column tile): a column is (pixel of a horizontally adjacent pair,
+// channel), the 4 reduction slots of an instruction are 4 consecutive PAIRS, and the rows are the shifted views of S over
+// a window 4 columns wide, (kh, kw', cs) with kw' = 0..3: the first pixel of a pair meets kernel column kw' (kw' <= 2),
+// the second one kw' - 1 (kw' >= 1).  3 x 4 x CS = 36 rows in 3 tiles serve 8 pixels, where 27 rows in 2 tiles served 4.
+template <int CS, int CP, int SWAP, int WO, bool PAIR = false>
 __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int gx) {
-    constexpr int M = 9 * CS, MT = (M + 15) / 16, NT = (CP + 15) / 16, NTILE = MT * NT;
-    constexpr int QX = WO / 4;                                 // pixel quads per image row
+    static_assert(!PAIR || (CP == 8 && SWAP == 0), "pairs of pixels fill the 8 columns an 8-channel P leaves empty");
+    constexpr int KWN = PAIR ? 4 : 3;                          // window columns a row of the GEMM can stand for
+    constexpr int M = 3 * KWN * CS, MT = (M + 15) / 16, NT = (CP + 15) / 16, NTILE = MT * NT;
+    constexpr int QX = PAIR ? WO / 8 : WO / 4;                 // reduction steps (pixel quads / quads of pairs) per image row
+    constexpr int KP = PAIR ? 2 : 1;                           // pixels per reduction slot
     constexpr int MTC = (4 * CS) / 16;                         // tile holding the centre tap's rows (SWAP: the bias sums)
     constexpr int Cin = SWAP ? CP : CS, Cout = SWAP ? CS : CP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -218,11 +225,11 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
     for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 16 + li;
         const int mm = m < M ? m : M - 1;  // unused rows read what the last used row reads (a broadcast, not a bank conflict)
-        const int kh = mm / (3 * CS), r = mm - kh * 3 * CS;
-        aoff[mt] = kh * RPS + r + lk * CS;
+        const int kh = mm / (KWN * CS), r = mm - kh * KWN * CS;
+        aoff[mt] = kh * RPS + r + lk * KP * CS;
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) boff[nt] = (lk >> pshift) * CP + nt * 16 + li;
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = PAIR ? lk * 2 * CP + li : (lk >> pshift) * CP + nt * 16 + li;
 
     wn_v4f acc[MT][NT];
 #pragma unroll
@@ -270,9 +277,9 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
 #pragma unroll
                 for (int q = 0; q < QX; ++q) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[q][nt] = pq[boff[nt] + ((4 * q) >> PS) * CP];
+                    for (int nt = 0; nt < NT; ++nt) bv[q][nt] = pq[boff[nt] + ((4 * KP * q) >> PS) * CP];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) av[q][mt] = sq[aoff[mt] + 4 * q * CS];
+                    for (int mt = 0; mt < MT; ++mt) av[q][mt] = sq[aoff[mt] + 4 * KP * q * CS];
                 }
             };
             auto mfma_row = [&](const float (&av)[QX][MT], const float (&bv)[QX][NT]) {
@@ -322,6 +329,7 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
     for (int nt = 0; nt < NT; ++nt) {  // the 4 pixel lanes of a channel
         bsum[nt] += __shfl_xor(bsum[nt], 16, 64);
         bsum[nt] += __shfl_xor(bsum[nt], 32, 64);
+        if (PAIR) bsum[nt] += __shfl_xor(bsum[nt], 8, 64);  // the two pixels of a pair
     }
     auto put = [&](int slot) {
         float4* d = xch + (size_t)slot * (NTILE + 1) * 64 + lane;
@@ -358,6 +366,24 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
     __syncthreads();
     float* img = smem;
     if (wave == 0) {
+        if constexpr (PAIR) {
+            // element (kh, kw', cs) x (e, co) belongs to kernel column kw' - e: the first pixels' values are placed,
+            // then the second pixels' are added (LDS operations of one wave complete in order)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mt * 16 + 4 * lk + r;
+                        const int kh = m / (KWN * CS), rem = m - kh * KWN * CS, kwp = rem / CS, cs = rem - kwp * CS;
+                        const int kw = kwp - e;
+                        if (m < M && (li >> 3) == e && kw >= 0 && kw <= 2) {
+                            const int at = ((kh * 3 + kw) * Cin + cs) * Cout + (li & 7);
+                            img[at] = e == 0 ? acc[mt][0][r] : img[at] + acc[mt][0][r];
+                        }
+                    }
+        } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -371,6 +397,7 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
                     if (m < M && n < CP) img[at] = acc[mt][nt][r];
                 }
             }
+        }
         if (lk == 0) {
             if (SWAP) {
                 const int cs = li - (4 * CS) % 16;
@@ -378,7 +405,7 @@ __device__ __forceinline__ void wn_body(const WnArgs& a, const int bx, const int
             } else {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    if (nt * 16 + li < CP) img[9 * Cin * Cout + nt * 16 + li] = bsum[nt];
+                    if (nt * 16 + li < CP) img[9 * Cin * Cout + nt * 16 + li] = bsum[nt];  // PAIR: lanes 0..7 hold both pixels' sum
             }
         }
         if (lane < a.slab_floats - (9 * Cin * Cout + Cout)) img[9 * Cin * Cout + Cout + lane] = 0.f;
@@ -638,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_nhwc_multi(WnMultiArgs m) {
     WnArgs a;
     __builtin_memcpy(&a, &mp->job[j], sizeof(WnArgs));
     switch (m.shape[j]) {
-        case 0: wn_body<3, 8, 0, 32>(a, bx, gx); break;
+        case 0: wn_body<3, 8, 0, 32, true>(a, bx, gx); break;
         case 1: wn_body<8, 16, 0, 16>(a, bx, gx); break;
         case 2: wn_body<16, 32, 0, 8>(a, bx, gx); break;
         case 4: wn_body<3, 8, 1, 32>(a, bx, gx); break;
