@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <utility>
+
 #include "tile_common.h"
 
 namespace sv {
@@ -400,6 +402,18 @@ __device__ __forceinline__ void net_layer_fwd_any(const NetFwdArgs& a, const Net
 // A wave owns units of 32 pixels (two tiles: 4 rows x 8 or 2 rows x 16), which contain whole 2 x 2 pooling windows.
 typedef float nf_v4f __attribute__((ext_vector_type(4)));
 
+// Order of one turn of a matrix-core loop: NM matrix instructions with the NR LDS reads of the NEXT turn's operands
+// placed two behind each of the first ones (the reads issue in the shadow of the matrix pipe).
+template <int NM, int NR, int... I>
+__device__ __forceinline__ void nf_interleave_seq(std::integer_sequence<int, I...>) {
+    ((__builtin_amdgcn_sched_group_barrier(0x008, 1, 0),
+      __builtin_amdgcn_sched_group_barrier(0x100, (NR - 2 * I) >= 2 ? 2 : ((NR - 2 * I) > 0 ? (NR - 2 * I) : 0), 0)), ...);
+}
+template <int NM, int NR>
+__device__ __forceinline__ void nf_interleave() {
+    nf_interleave_seq<NM, NR>(std::make_integer_sequence<int, NM>{});
+}
+
 template <int CIN, int NT, int UP, int POOL>
 __device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const NetLayer& L, float* smem, int ns, int nt) {
     constexpr int K = 3, KK = 9, CO8 = 8;
@@ -460,11 +474,13 @@ __device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const Ne
                 for (int n = 0; n < NT; ++n) b_[cg][n] = w_lds[boff[n] + cg * 4 * (KK * CO8) + tap * CO8];
             }
         };
+        constexpr bool MIX = CG * (2 + NT) <= 2 * CG * 2 * NT;  // at most two reads per matrix instruction
         load_tap(0, av[0], bv[0]);
+        if (MIX) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             if (tap + 1 < KK) load_tap(tap + 1, av[(tap + 1) & 1], bv[(tap + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!MIX) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cg = 0; cg < CG; ++cg)
 #pragma unroll
@@ -472,6 +488,7 @@ __device__ __forceinline__ void net_layer_fwd_mfma(const NetFwdArgs& a, const Ne
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap & 1][cg][t], bv[tap & 1][cg][n], acc[t][n], 0, 0, 0);
+            if (MIX && tap + 1 < KK) nf_interleave<CG * 2 * NT, CG * (2 + NT)>();
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue: lane holds, per tile and channel co = 16 n + li, the pixels 4 lk .. 4 lk + 3 of the tile
@@ -624,11 +641,13 @@ __device__ __forceinline__ void net_layer_fwd_mfma_up2(const NetFwdArgs& a, cons
                 for (int n = 0; n < NT; ++n) b_[cg][n] = w_lane[((tap * CG + cg) * NT + n) * 64];
             }
         };
+        constexpr bool MIX = CG * (2 + NT) <= 2 * CG * 2 * NT;  // at most two reads per matrix instruction
         load_tap(0, av[0], bv[0]);
+        if (MIX) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             if (tap + 1 < KK) load_tap(tap + 1, av[(tap + 1) & 1], bv[(tap + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!MIX) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cg = 0; cg < CG; ++cg)
 #pragma unroll
@@ -636,6 +655,7 @@ __device__ __forceinline__ void net_layer_fwd_mfma_up2(const NetFwdArgs& a, cons
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap & 1][cg][t], bv[tap & 1][cg][n], acc[t][n], 0, 0, 0);
+            if (MIX && tap + 1 < KK) nf_interleave<CG * 2 * NT, CG * (2 + NT)>();
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue: the lane holds column 16 n + li = (phase, co) of stored pixels 4 lk .. 4 lk + 3 of each tile
