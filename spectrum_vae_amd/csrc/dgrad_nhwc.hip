@@ -13,6 +13,7 @@
 // a fixed order.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "tile_common.h"
@@ -20,6 +21,18 @@
 namespace sv {
 
 typedef float dn_v4f __attribute__((ext_vector_type(4)));
+
+// Order of one turn of the tile loop: NM matrix instructions with the NR LDS reads of the NEXT tile's operands placed one
+// behind each of the first ones (the reads issue in the shadow of the matrix pipe).
+template <int NM, int NR, int... I>
+__device__ __forceinline__ void dn_interleave_seq(std::integer_sequence<int, I...>) {
+    ((__builtin_amdgcn_sched_group_barrier(0x008, 1, 0), __builtin_amdgcn_sched_group_barrier(0x100, I < NR ? 1 : 0, 0)), ...);
+}
+template <int NM, int NR>
+__device__ __forceinline__ void dn_interleave() {
+    static_assert(NR <= NM, "one read per matrix instruction at most");
+    dn_interleave_seq<NM, NR>(std::make_integer_sequence<int, NM>{});
+}
 
 #ifdef SV_TRACE
 // diagnostic builds: thread 0 of every workgroup stores the 100 MHz wall clock at phase marks, 16 slots per workgroup
@@ -344,19 +357,28 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
             }
         };
         if constexpr (PING) {
-            // tiles in pairs, the reads of the next tile issued before the current tile's matrix instructions; with an odd
-            // count the last turn reads its own tile again and skips the second half (a wave-uniform branch at its end)
-            load_tile(zv0, 0);
-            for (int i = 0; i < ntile; i += 2) {
-                const bool two = i + 1 < ntile;
-                load_tile(zv1, two ? i + 1 : i);
+            // tiles in pairs, the next tile's reads placed between the current tile's matrix instructions; an odd count
+            // runs its first tile on its own, so the loop body has no branch
+            constexpr int NM = NSTEP * VEC * MT;
+            int first = 0;
+            if (ntile & 1) {
+                load_tile(zv0, 0);
+                mfma_tile(zv0, 0, true);
+                first = 1;
+            }
+            if (first < ntile) {
+                load_tile(zv0, first);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_tile(zv0, i, true);
-                __builtin_amdgcn_sched_barrier(0);
-                load_tile(zv0, min(i + 2, ntile - 1));
-                __builtin_amdgcn_sched_barrier(0);
-                if (two) mfma_tile(zv1, i + 1, true);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = first; i < ntile; i += 2) {
+                    load_tile(zv1, i + 1);
+                    mfma_tile(zv0, i, true);
+                    dn_interleave<NM, NSTEP>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_tile(zv0, min(i + 2, ntile - 1));
+                    mfma_tile(zv1, i + 1, true);
+                    dn_interleave<NM, NSTEP>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else {
             for (int i = 0; i < ntile; ++i) {
