@@ -483,7 +483,41 @@ __global__ void bn_apply_k(const T* __restrict__ x, const float* __restrict__ ga
     if (vec) {  // 16-byte pieces (C is a multiple of the piece, so a piece never straddles two rows)
         constexpr int VN = 16 / sizeof(T);
         const int64_t nv = total / VN;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if ((stride * VN) % C == 0) {
+            // a thread's pieces all start at the same channel: the per-channel values stay in registers (reloaded when
+            // the walk enters another statistics group) and the loop is one load, VN fused operations, one store
+            const int c0 = (int)((i * VN) % C);
+            float mu[VN], iv[VN], ga[VN], be[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) { ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; mu[e] = 0.f; iv[e] = 0.f; }
+            int64_t g_end = 0;  // first element past the group whose statistics are loaded
+            for (; i < nv; i += stride) {
+                const int64_t b = i * VN;
+                if (b >= g_end) {
+                    const int64_t g = group_elems >= total ? 0 : b / group_elems;
+                    g_end = group_elems >= total ? total : (g + 1) * group_elems;
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) {
+                        const float s = var_or_invstd[g * C + c0 + e];
+                        iv[e] = is_var ? rsqrtf(s + eps) : s;
+                        mu[e] = mean[g * C + c0 + e];
+                    }
+                }
+                float v[VN];
+                ld16(x + b, v);
+                Pack16<T> o;
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    const T t = (T)((v[e] - mu[e]) * iv[e] * ga[e] + be[e]);
+                    o.v[e] = act == SV_ACT_NONE ? t : (T)act_apply((float)t, act, alpha);
+                }
+                *reinterpret_cast<Pack16<T>*>(y + b) = o;
+            }
+            return;
+        }
+        for (; i < nv; i += stride) {
             const int64_t b = i * VN;
             const int c0 = (int)(b % C);
             const int s0 = group_elems >= total ? c0 : (int)(b / group_elems) * C + c0;
@@ -653,7 +687,40 @@ __global__ void bn_bwd_apply_k(const T* __restrict__ x, const T* __restrict__ dy
     if (vec) {
         constexpr int VN = 16 / sizeof(T);
         const int64_t nv = total / VN;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if ((stride * VN) % C == 0) {  // per-channel values in registers: see bn_apply_k
+            const int c0 = (int)((i * VN) % C);
+            float mu[VN], iv[VN], gi[VN], s1[VN], s2[VN];
+            int64_t g_end = 0;
+            for (; i < nv; i += stride) {
+                const int64_t b = i * VN;
+                if (b >= g_end) {
+                    const int64_t g = groups == 1 ? 0 : b / group_elems;
+                    g_end = (g + 1) * group_elems;
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) {
+                        iv[e] = invstd[g * C + c0 + e];
+                        mu[e] = mean[g * C + c0 + e];
+                        gi[e] = gamma[c0 + e] * iv[e];
+                        s1[e] = stats2[2 * g * C + c0 + e];
+                        s2[e] = stats2[(2 * g + 1) * C + c0 + e];
+                    }
+                }
+                float xv[VN], gv[VN];
+                ld16(x + b, xv);
+                ld16(dy + b, gv);
+                Pack16<T> o;
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    const float xh = (xv[e] - mu[e]) * iv[e];
+                    o.v[e] = (T)(gi[e] * (gv[e] - invm * (s1[e] + xh * s2[e])));
+                }
+                *reinterpret_cast<Pack16<T>*>(dx + b) = o;
+            }
+            return;
+        }
+        for (; i < nv; i += stride) {
             const int64_t b = i * VN;
             const int c0 = (int)(b % C);
             const int g = groups == 1 ? 0 : (int)(b / group_elems);
