@@ -347,6 +347,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the U-Net / context-encoder / VAE steps")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+                    help="plan-time option of the library (sv_set_option) for this run; measurements only")
     ap.add_argument("--profile-out", default=None, help="write the per-call HIP-event table to this JSON file")
     args = ap.parse_args()
     if os.environ.get("SV_BENCH_WATCHDOG"):  # diagnostic: dump every thread's stack if the run takes longer than this
@@ -358,6 +360,9 @@ def main():
     from spectrum_vae_amd import autoencoder, losses, ops, parallel
     from spectrum_vae_amd.run_model import build_optimizer
 
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        ops.set_option(name, int(val))
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

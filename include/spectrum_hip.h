@@ -225,6 +225,27 @@ int sv_conv2d_wgrad_batch_slabs_supported(const sv_wgrad_batch_job* jobs, int n_
 int sv_conv2d_wgrad_batch_slabs(const sv_wgrad_batch_job* jobs, int n_jobs, sv_grad_slabs* slabs_out, int dtype,
                                 sv_stream_t stream);
 
+/* ---- The input gradients of SEVERAL consecutive layers of one backward pass (the activation-gradient chain of the tape
+ *      in run_model.py:281-289 through the conv stack of autoencoder.py:437-526) in one launch: the same arithmetic as
+ *      the dx half of sv_conv2d_bwd per job, jobs in list order.  A job may read, as its dy, the dx of an EARLIER job of
+ *      the list (sample n of it depends on sample n only, so a workgroup takes its samples through the whole list
+ *      without waiting for any other); no other overlap between one job's dx and another job's tensors is allowed.
+ *      All jobs share the batch size.  Only the few-channel 3x3 family has this form:
+ *      sv_conv2d_dgrad_chain_supported tells (1) whether the whole list is in it; otherwise the call fails with
+ *      SV_E_UNSUPPORTED, nothing is launched, and the caller issues sv_conv2d_bwd per job.  At most 8 jobs. */
+typedef struct sv_dgrad_job {
+    sv_conv_geom g;
+    const void* w;        /* the forward conv's HWIO filters */
+    const void* dy;       /* gradient w.r.t. the layer output (pooled extent when idx != NULL) */
+    const void* y;        /* layer output (after activation, pooled when idx != NULL) */
+    const uint8_t* idx;   /* pooling argmax or NULL */
+    void* dx;             /* gradient w.r.t. the layer input (summed over the 2x2 windows when the conv upsampled) */
+    int32_t act;
+    float alpha;
+} sv_dgrad_job;
+int sv_conv2d_dgrad_chain_supported(const sv_dgrad_job* jobs, int n_jobs);
+int sv_conv2d_dgrad_chain(const sv_dgrad_job* jobs, int n_jobs, int dtype, sv_stream_t stream);
+
 /* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
 /* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */
 int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,

@@ -65,6 +65,13 @@ class WgradBatchJob(C.Structure):
                 ("act", C.c_int32), ("alpha", C.c_float), ("accumulate", C.c_int32), ("blocks", C.c_int32)]
 
 
+class DgradJob(C.Structure):
+    """Mirror of ``sv_dgrad_job``."""
+
+    _fields_ = [("g", ConvGeom), ("w", C.c_void_p), ("dy", C.c_void_p), ("y", C.c_void_p), ("idx", C.c_void_p),
+                ("dx", C.c_void_p), ("act", C.c_int32), ("alpha", C.c_float)]
+
+
 _p, _i, _f, _i64, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64, C.c_size_t
 _g = C.POINTER(ConvGeom)
 
@@ -93,6 +100,8 @@ SIGNATURES = {
     "sv_conv2d_bwd_partial": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p, _sz, _i, _p]),
     "sv_conv2d_wgrad_finish": (_i, [C.POINTER(WgradJob), _i, _i, _p]),
     "sv_conv2d_wgrad_batch": (_i, [C.POINTER(WgradBatchJob), _i, _i, _i, _p]),
+    "sv_conv2d_dgrad_chain_supported": (_i, [C.POINTER(DgradJob), _i]),
+    "sv_conv2d_dgrad_chain": (_i, [C.POINTER(DgradJob), _i, _i, _p]),
     "sv_conv2d_wgrad_batch_slabs_supported": (_i, [C.POINTER(WgradBatchJob), _i]),
     "sv_conv2d_wgrad_batch_slabs": (_i, [C.POINTER(WgradBatchJob), _i, C.POINTER(GradSlabs), _i, _p]),
     "sv_conv2d_transpose_fwd": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p]),

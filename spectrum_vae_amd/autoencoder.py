@@ -33,6 +33,8 @@ class _EncoderDecoder(Model):
     def forward(self, ctx, x):
         return self.decoder.forward(ctx, self.encoder.forward(ctx, x))
 
+    chain_dgrad_ok = True  # backward() hands gradients from Sequential to Sequential only
+
     def backward(self, ctx, dy, need_dx=True):
         d = self.decoder.backward(ctx, dy, need_dx=True)
         return self.encoder.backward(ctx, d, need_dx=need_dx)
@@ -345,8 +347,11 @@ class VAEPadded(Model):
         ctx.extra_losses = [(kl, self.beta)]
         return self.decoder.forward(ctx, z)
 
+    chain_dgrad_ok = True
+
     def backward(self, ctx, dy, need_dx=True):
         dz = self.decoder.backward(ctx, dy, need_dx=True)
+        ctx.flush_dgrad()  # the sampling layer reads dz here, outside any Sequential
         dmean, dlogvar = self.sampling.sample_backward(ctx, dz, self.beta)
         dh = self.z_mean.backward(ctx, dmean, need_dx=True)
         ops.axpy(dh, self.z_log_var.backward(ctx, dlogvar, need_dx=True), 1.0)

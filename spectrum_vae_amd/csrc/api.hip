@@ -13,7 +13,8 @@ thread_local char g_last_error[512] = "";
 static std::atomic<int> g_opt[OPT_COUNT];
 static const char* const kOptNames[OPT_COUNT] = {
     "dgrad_nhwc", "dgrad_phase", "dgrad_pair", "dgrad_grid", "dgrad_valu", "wgrad_nhwc", "wgrad_valu", "netfwd_generic",
-    "netfwd_pair", "netfwd_phase", "netfwd_valu", "netfwd_s", "netfwd_grid", "small_convt", "s1_mfma", "wgrad_stored"};
+    "netfwd_pair", "netfwd_phase", "netfwd_valu", "netfwd_s", "netfwd_grid", "small_convt", "s1_mfma", "wgrad_stored",
+    "dgrad_chain"};
 static const bool g_opt_init = [] {
     for (int i = 0; i < OPT_COUNT; ++i) g_opt[i].store(-1, std::memory_order_relaxed);
     return true;
@@ -75,6 +76,7 @@ int launch_form_dz(const float* dy, const float* y, const uint8_t* idx, float* d
                    float alpha, hipStream_t st);
 bool wgrad_nhwc_batch_ok(const sv_wgrad_batch_job* jobs, int n_jobs);  // wgrad_nhwc.hip
 int launch_wgrad_nhwc_batch(const sv_wgrad_batch_job* jobs, int n_jobs, hipStream_t st, sv_grad_slabs* slabs_out);
+int launch_dgrad_chain(const sv_dgrad_job* jobs, int n_jobs, bool launch, hipStream_t st);
 int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
                       int act, float alpha, hipStream_t st);
 
@@ -330,6 +332,27 @@ int sv_conv2d_bwd(const sv_conv_geom* g, const void* x, const void* w, const voi
                          g->Cin, g->KH, 1, 1, g->up_h == 2 ? 2 : 0, SV_ACT_NONE, 0.f, to_stream(stream), zmode,
                          (const float*)y, idx, act, alpha);
     return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_bwd: shape not covered") : rc;
+}
+
+static bool dgrad_chain_jobs_valid(const sv_dgrad_job* jobs, int n_jobs) {
+    if (jobs == nullptr || n_jobs < 1 || n_jobs > 8) return false;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (validate_geom(&jobs[j].g, "sv_conv2d_dgrad_chain")) return false;
+        if (!jobs[j].w || !jobs[j].dy || !jobs[j].y || !jobs[j].dx) return false;
+    }
+    return true;
+}
+
+int sv_conv2d_dgrad_chain_supported(const sv_dgrad_job* jobs, int n_jobs) {
+    return dgrad_chain_jobs_valid(jobs, n_jobs) && launch_dgrad_chain(jobs, n_jobs, false, nullptr) == 0 ? 1 : 0;
+}
+
+int sv_conv2d_dgrad_chain(const sv_dgrad_job* jobs, int n_jobs, int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_conv2d_dgrad_chain");
+    SV_REQUIRE(dgrad_chain_jobs_valid(jobs, n_jobs), "sv_conv2d_dgrad_chain: bad job list (1..8 jobs, tensors set)");
+    const int rc = launch_dgrad_chain(jobs, n_jobs, true, to_stream(stream));
+    return rc > 0 ? fail(SV_E_UNSUPPORTED, "sv_conv2d_dgrad_chain: a job is outside the few-channel 3x3 family, or the "
+                                           "batch sizes differ") : rc;
 }
 
 int sv_conv2d_bwd_partial(const sv_conv_geom* g, const void* x, const void* dy, const void* y, const uint8_t* idx,

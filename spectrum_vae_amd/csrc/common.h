@@ -68,6 +68,7 @@ enum SvOpt {
     OPT_SMALL_CONVT,     // 0: few-channel transposed convs through the implicit GEMM
     OPT_S1_MFMA,         // 0: stride-1 SAME convs outside the few-channel family through the planar kernels
     OPT_WGRAD_STORED,    // 0: kernel gradients of upsampled layers over the pixels of the upsampled image
+    OPT_DGRAD_CHAIN,     // 0: sv_conv2d_dgrad_chain declines every list (one launch per layer); > 1: its workgroups
     OPT_COUNT
 };
 int opt(int id);  // api.hip

@@ -95,8 +95,9 @@ __device__ __forceinline__ float dn_dpp_ror8(float v) {  // value of lane ^ 8 (r
 // MODE 2 (8 input channels, where the filters fill only half of a 16-row A operand): rows 8..15 hold the same filters
 // shifted by one column, so a result column is a PAIR of horizontally adjacent pixels (even column in rows 0..7, odd
 // column in rows 8..15) reading a 3 x 4 window of dz between them: 12 window taps per pixel pair instead of 2 x 9.
+// The workgroup's samples are [nb, ne) in passes of a.ns, `step` samples from one pass to the next; `wg` names it in traces.
 template <int CZ, int CX, int WO, int MODE>
-__global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
+__device__ __forceinline__ void dn_body(const DnArgs& a, const int nb, const int ne, const int step, [[maybe_unused]] const int wg) {
     constexpr bool PH = MODE == 1, WD = MODE == 2;
     static_assert(!WD || CX == 8, "the pair form fills the rows an 8-channel filter leaves empty");
     constexpr int MT = (CX + 15) / 16;
@@ -110,7 +111,11 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     static_assert(!WD || CZ != 3, "pair form: channel counts that are multiples of 4");
     constexpr bool PING = NSTEP * VEC <= 36;                      // operand registers of two tiles fit
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the thread index behind an opaque copy: what a layer derives from it is then not loop-invariant for the chain
+    // kernel's layer loop, which would otherwise hoist every layer's per-lane values in front of the loop and spill them
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int pr = li >> 3, pc = li & 7;
     const int H = a.H;
@@ -125,12 +130,12 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     float4 rv[kDnUnits], ry[kDnUnits];
     uint32_t rk[kDnUnits];
     auto load_pass = [&](int n0) {
-        const int ns = min(a.ns, a.N - n0);
+        const int ns = min(a.ns, ne - n0);
         const int su = (ns * s_sample) >> 2;
         const size_t sb = (size_t)n0 * s_sample;
 #pragma unroll
         for (int i = 0; i < kDnUnits; ++i) {
-            const int u = min((int)threadIdx.x + i * 256, su - 1);
+            const int u = min(tid + i * 256, su - 1);
             rv[i] = *reinterpret_cast<const float4*>(a.dy + sb + 4 * (size_t)u);
             ry[i] = *reinterpret_cast<const float4*>(a.zy + sb + 4 * (size_t)u);
             rk[i] = zmode == 2 ? *reinterpret_cast<const uint32_t*>(a.zidx + sb + 4 * (size_t)u) : 0u;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
         const int su = (ns * s_sample) >> 2;
 #pragma unroll
         for (int i = 0; i < kDnUnits; ++i) {
-            const int u = threadIdx.x + i * 256;
+            const int u = tid + i * 256;
             if (u >= su) continue;
             float4 v = rv[i];
             v.x *= act_grad_q(ry[i].x, a.zk); v.y *= act_grad_q(ry[i].y, a.zk);
@@ -191,23 +196,23 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     // round trip for the workgroup) behind the dz image and the lane picks its values out of LDS; the two instantiations
     // with the fewest values per lane read them from global memory directly (measured 1 us faster there).
     constexpr bool WLDS = !((CZ == 16 && CX == 32) || (CZ == 8 && CX == 16));
-    int n0 = blockIdx.x * a.ns;
-    if (n0 < a.N) load_pass(n0);
+    int n0 = nb;
+    if (n0 < ne) load_pass(n0);
     const int zimg4 = (a.ns * sampleZ + 3 + 16) >> 2;  // 16-byte pieces of the dz images (and the pad behind them)
     const float* wl = WLDS ? smem + 4 * zimg4 : a.w;
     if constexpr (!WLDS) {
-        for (int i = threadIdx.x; i < zimg4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < zimg4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
         constexpr int W4 = 9 * CX * CZ / 4;
         static_assert(9 * CX * CZ % 4 == 0, "the filters are copied as 16-byte pieces");
         float4 wv[(W4 + 255) / 256];
 #pragma unroll
         for (int i = 0; i < (W4 + 255) / 256; ++i)
-            wv[i] = reinterpret_cast<const float4*>(a.w)[min((int)threadIdx.x + i * 256, W4 - 1)];
-        for (int i = threadIdx.x; i < zimg4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[i] = reinterpret_cast<const float4*>(a.w)[min(tid + i * 256, W4 - 1)];
+        for (int i = tid; i < zimg4; i += 256) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < (W4 + 255) / 256; ++i)
-            if ((int)threadIdx.x + i * 256 < W4) reinterpret_cast<float4*>(smem)[zimg4 + threadIdx.x + i * 256] = wv[i];
+            if (tid + i * 256 < W4) reinterpret_cast<float4*>(smem)[zimg4 + tid + i * 256] = wv[i];
     }
     if constexpr (WLDS) __syncthreads();
     float wreg[NSTEP][VEC][MT];
@@ -272,13 +277,13 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     const int tps_log = a.tps_log, tps_mask = (1 << tps_log) - 1;
     DN_MARK(2, false);
     [[maybe_unused]] int pass = 0;
-    for (; n0 < a.N; n0 += gridDim.x * a.ns) {
-        const int ns = min(a.ns, a.N - n0);
+    for (; n0 < ne; n0 += step) {
+        const int ns = min(a.ns, ne - n0);
         __syncthreads();
         store_pass(ns);
         __syncthreads();
         DN_MARK(3 + 2 * pass, false);
-        if (n0 + (int)gridDim.x * a.ns < a.N) load_pass(n0 + gridDim.x * a.ns);
+        if (n0 + step < ne) load_pass(n0 + step);
 
         const int ntile = (ns << tps_log) >> 2;  // tiles of this wave: tps is a multiple of 4
         float zv0[NSTEP][VEC], zv1[NSTEP][VEC];
@@ -395,6 +400,54 @@ __global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
     DN_MARK(15, true);
 }
 
+template <int CZ, int CX, int WO, int MODE>
+__global__ __launch_bounds__(256, 2) void dgrad_nhwc(DnArgs a) {
+    dn_body<CZ, CX, WO, MODE>(a, blockIdx.x * a.ns, a.N, gridDim.x * a.ns, blockIdx.x);
+}
+
+// ---- the input gradients of SEVERAL consecutive layers in one launch.  A sample's gradient chain touches no other
+// sample, so a workgroup can take its samples through every layer in turn: layer j + 1 reads (as dy) what the workgroup
+// itself wrote as layer j's dx, and nothing orders it against other workgroups.  Saves the launch ramps and gaps between
+// the layers (each layer alone runs 8..12 us, of which 2..3 us pass before its first matrix instruction).
+constexpr int kDnChainMax = 8;
+struct DnChainArgs {
+    DnArgs job[kDnChainMax];
+    int code[kDnChainMax];  // shape * 4 + mode
+    int n_jobs, S;          // S: samples per workgroup, the same range in every layer
+};
+
+__global__ __launch_bounds__(256, 2) void dgrad_chain_k(DnChainArgs) {
+    // the table is indexed by a loop counter: read it where the launch put it (the kernel argument segment, scalar loads)
+    // instead of through the by-value parameter, which the compiler would first copy into every lane's scratch memory
+#if defined(__HIP_DEVICE_COMPILE__)
+    const DnChainArgs& c = *(const DnChainArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const DnChainArgs c{};  // host pass: the body is never run
+#endif
+    const int nb = blockIdx.x * c.S;
+    for (int j = 0; j < c.n_jobs; ++j) {
+        const DnArgs& a = c.job[j];
+        const int ne = min(a.N, nb + c.S);
+        if (j > 0) {
+            // this workgroup's stores of the previous layer's dx before its loads of them; the barrier also keeps the
+            // LDS images of the previous layer alive until its last wave has left the tile loop
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        switch (c.code[j]) {
+            case 0: dn_body<3, 8, 32, 0>(a, nb, ne, a.ns, blockIdx.x); break;
+            case 1: dn_body<3, 8, 32, 1>(a, nb, ne, a.ns, blockIdx.x); break;
+            case 4: dn_body<8, 16, 16, 0>(a, nb, ne, a.ns, blockIdx.x); break;
+            case 5: dn_body<8, 16, 16, 1>(a, nb, ne, a.ns, blockIdx.x); break;
+            case 8: dn_body<16, 32, 8, 0>(a, nb, ne, a.ns, blockIdx.x); break;
+            case 12: dn_body<32, 16, 8, 0>(a, nb, ne, a.ns, blockIdx.x); break;
+            case 16: dn_body<16, 8, 16, 0>(a, nb, ne, a.ns, blockIdx.x); break;
+            default: dn_body<16, 8, 16, 2>(a, nb, ne, a.ns, blockIdx.x); break;  // 18
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- host side
 template <int CZ, int CX, int WO>
 static int dn_launch(const DnArgs& a, int grid, size_t lds, hipStream_t st, int mode) {
@@ -414,10 +467,16 @@ static int dn_launch(const DnArgs& a, int grid, size_t lds, hipStream_t st, int 
     return check_launch("dgrad_nhwc");
 }
 
-// dx of the conv described by g (its input gradient), dz formed from (dy, y, idx).  1: shape outside this family (the
-// caller takes the planar kernels); 0: launched; < 0: error.
-int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
-                      int act, float alpha, hipStream_t st) {
+// The kernel form of one layer: shape and mode (-> template arguments), tiles per sample, staging units per sample.
+struct DnPlan {
+    int shape, mode, tps, zmode;
+    int64_t sampleZ, units;
+    size_t lds(int ns) const { return (size_t)(ns * sampleZ + 3 + 16) / 4 * 16 + w_bytes; }
+    size_t w_bytes;
+};
+
+// 0: planned; 1: shape outside this family
+static int dn_plan(const sv_conv_geom& g, const float* y, const uint8_t* idx, DnPlan& p) {
     if (opt(OPT_DGRAD_NHWC) == 0) return 1;
     if (g.KH != 3 || g.KW != 3 || g.SH != 1 || g.SW != 1 || g.up_h != g.up_w || (g.up_h != 1 && g.up_h != 2)) return 1;
     if (g.Ho != g.H || g.Wo != g.W || g.pad_t != 1 || g.pad_l != 1) return 1;
@@ -446,10 +505,34 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
         else wd = false;
     }
     if (tps < 4 || (tps & (tps - 1))) return 1;
-    const int mode = ph ? 1 : (wd ? 2 : 0);
-    const int64_t sampleZ = (int64_t)(H + 2) * dn_rp(CZ, W, mode);
-    const int64_t units = (zmode == 2 ? (int64_t)(H / 2) * (W / 2) * CZ : (int64_t)H * W * CZ) / 4;
-    auto lds = [&](int ns) { return (size_t)(ns * sampleZ + 3 + 16) / 4 * 16 + (size_t)9 * CX * CZ * sizeof(float); };
+    p.shape = shape;
+    p.mode = ph ? 1 : (wd ? 2 : 0);
+    p.tps = tps;
+    p.zmode = zmode;
+    p.sampleZ = (int64_t)(H + 2) * dn_rp(CZ, W, p.mode);
+    p.units = (zmode == 2 ? (int64_t)(H / 2) * (W / 2) * CZ : (int64_t)H * W * CZ) / 4;
+    p.w_bytes = (size_t)9 * CX * CZ * sizeof(float);
+    return 0;
+}
+
+static void dn_fill(DnArgs& a, const DnPlan& p, const sv_conv_geom& g, const float* w, const float* dy, const float* y,
+                    const uint8_t* idx, float* dx, int act, float alpha, int ns) {
+    a = DnArgs{};
+    a.dy = dy; a.zy = y; a.zidx = idx; a.w = w; a.dx = dx;
+    a.N = g.N; a.H = g.H; a.up = g.up_h; a.zmode = p.zmode; a.ns = ns; a.tps_log = __builtin_ctz(p.tps);
+    a.zk = act_grad_coef(act, alpha);
+}
+
+// dx of the conv described by g (its input gradient), dz formed from (dy, y, idx).  1: shape outside this family (the
+// caller takes the planar kernels); 0: launched; < 0: error.
+int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, const float* y, const uint8_t* idx, float* dx,
+                      int act, float alpha, hipStream_t st) {
+    DnPlan p;
+    if (dn_plan(g, y, idx, p)) return 1;
+    const int shape = p.shape, CZ = g.Cout;
+    const bool ph = p.mode == 1, wd = p.mode == 2;
+    const int64_t units = p.units;
+    auto lds = [&](int ns) { return p.lds(ns); };
     // workgroups (measured at batch 1024): one sample each for the 32-wide 3-channel image (few registers, 14 KB of LDS:
     // four workgroups share a CU and hide each other's load latencies), two per CU for the 16-wide image with 8-channel
     // dz, one per CU elsewhere, where more workgroups only repeat the filter loads
@@ -464,10 +547,8 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     while (ns < 8 && lds(ns + 1) <= 64 * 1024 && (ns + 1) * units <= per_pass && (int64_t)(ns + 1) * grid <= g.N) ++ns;
     if (lds(ns) > 64 * 1024 || ns * units > per_pass) return 1;
     if ((int64_t)grid * ns > g.N) grid = (g.N + ns - 1) / ns;
-    DnArgs a{};
-    a.dy = dy; a.zy = y; a.zidx = idx; a.w = w; a.dx = dx;
-    a.N = g.N; a.H = H; a.up = g.up_h; a.zmode = zmode; a.ns = ns; a.tps_log = __builtin_ctz(tps);
-    a.zk = act_grad_coef(act, alpha);
+    DnArgs a;
+    dn_fill(a, p, g, w, dy, y, idx, dx, act, alpha, ns);
     const size_t bytes = lds(ns);
     switch (shape) {
         case 0: return dn_launch<3, 8, 32>(a, grid, bytes, st, ph ? 1 : 0);
@@ -476,6 +557,37 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
         case 3: return dn_launch<32, 16, 8>(a, grid, bytes, st, 0);
         default: return dn_launch<16, 8, 16>(a, grid, bytes, st, wd ? 2 : 0);
     }
+}
+
+// Several layers' input gradients as one launch (dgrad_chain_k).  launch == false: only tell whether the list qualifies.
+// 0: launched / qualifies; 1: a layer is outside the family, the batch sizes differ or the list is too long; < 0: error.
+int launch_dgrad_chain(const sv_dgrad_job* jobs, int n_jobs, bool launch, hipStream_t st) {
+    if (n_jobs < 1 || n_jobs > kDnChainMax || opt(OPT_DGRAD_CHAIN) == 0) return 1;
+    DnChainArgs c{};
+    const int N = jobs[0].g.N;
+    int grid = opt(OPT_DGRAD_CHAIN) > 1 ? opt(OPT_DGRAD_CHAIN) : 512;
+    if (grid > N) grid = N;
+    const int S = (N + grid - 1) / grid;
+    grid = (N + S - 1) / S;
+    size_t bytes = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const sv_dgrad_job& q = jobs[j];
+        DnPlan p;
+        if (q.g.N != N || dn_plan(q.g, (const float*)q.y, q.idx, p)) return 1;
+        const int per_pass = 256 * dn_units(q.g.Cout);
+        int ns = 1;
+        while (ns < S && p.lds(ns + 1) <= 64 * 1024 && (ns + 1) * p.units <= per_pass) ++ns;
+        if (p.lds(ns) > 64 * 1024 || ns * p.units > per_pass) return 1;
+        dn_fill(c.job[j], p, q.g, (const float*)q.w, (const float*)q.dy, (const float*)q.y, q.idx, (float*)q.dx, q.act,
+                q.alpha, ns);
+        c.code[j] = p.shape * 4 + p.mode;
+        if (p.lds(ns) > bytes) bytes = p.lds(ns);
+    }
+    if (!launch) return 0;
+    c.n_jobs = n_jobs;
+    c.S = S;
+    hipLaunchKernelGGL(dgrad_chain_k, dim3((unsigned)grid), dim3(256), bytes, st, c);
+    return check_launch("dgrad_chain");
 }
 
 }  // namespace sv

@@ -96,6 +96,10 @@ class Model(Layer):
         # 1024: tools/wgrad_ab.py sweeps other splits)
         self.wgrad_batch_blocks_large = 128  # layers of >= 256 pixels
         self.wgrad_batch_blocks = 128
+        # The input gradients of consecutive few-channel 3x3 layers in one launch (CallCtx.dgrad_jobs).  Off unless the
+        # model's backward() reads gradient tensors only inside Sequentials (which launch what is pending first) or
+        # behind a ctx.flush_dgrad() of its own; such a class says so with chain_dgrad_ok = True.
+        self.chain_dgrad = bool(getattr(type(self), "chain_dgrad_ok", False))
         self.defer_wgrad_reduce = True  # one reduction launch for the kernel gradients of all fused conv layers
         self._chain_cache: Dict[int, object] = {}
         self._slabs_wanted = False   # set around the backward pass of a training step whose optimizer launch can sum slabs
@@ -438,7 +442,11 @@ class Model(Layer):
         self._grads_clean = False
         if self.defer_wgrad_reduce and ctx.param_grads and ctx.wgrad_jobs is None and ctx.grad_ready is None:
             ctx.wgrad_jobs, ctx.wgrad_finish = [], []
+            if self.chain_dgrad and ctx.dgrad_jobs is None:
+                ctx.dgrad_jobs = []  # consecutive 3x3 layers' input gradients as one launch
             dx = self.backward(ctx, dy, need_dx=need_dx)
+            ctx.flush_dgrad()
+            ctx.dgrad_jobs = None
             nb = self.wgrad_batch_blocks if len(ctx.wgrad_jobs) >= 3 else 0
             for j in ctx.wgrad_jobs:  # layers with large images: fewer workgroups, each staging more samples
                 j["blocks"] = (self.wgrad_batch_blocks_large if j["g"].H * j["g"].W >= 256 else nb) if nb else 0

@@ -234,6 +234,24 @@ class CallCtx:
         # callable(variables): a layer's gradients are final on the compute stream (a data-parallel bucket pipeline
         # sends the buckets they complete); set for one backward pass
         self.grad_ready = None
+        # A list: fused 3x3 conv layers append their input-gradient job instead of launching it, and the owner issues the
+        # whole chain as one launch (ops.conv2d_dgrad_chain).  Any layer that READS a gradient tensor launches what is
+        # pending first (flush_dgrad); conv layers of the chain and layers that only pass the tensor on do not.
+        self.dgrad_jobs: Optional[list] = None
+
+    def flush_dgrad(self):
+        """Launch the input-gradient jobs collected so far (one launch when the library has the chained form for them,
+        else one per layer, in order)."""
+        jobs = self.dgrad_jobs
+        if not jobs:
+            return
+        self.dgrad_jobs = []
+        if len(jobs) > 1 and ops.conv2d_dgrad_chain_supported(jobs):
+            ops.conv2d_dgrad_chain(jobs)
+            return
+        for j in jobs:
+            ops.conv2d_bwd(j["g"], None, j["w"], j["dy"], j["y"], j.get("idx"), j["dx"], None, None, j["act"], j["alpha"],
+                           None)
 
     def buf(self, layer, role, shape, dtype=None):
         return self.pool.get((id(layer), role, self.slot), shape, self.dtype if dtype is None else dtype)
@@ -250,6 +268,7 @@ class CallCtx:
         v = CallCtx(self.pool, ("grp", g, self.slot), self.training, self.dtype)
         v.param_grads = self.param_grads
         v.sync_bn = self.sync_bn
+        v.dgrad_jobs = self.dgrad_jobs
         for key, d in self.saved.items():
             nd = {}
             for name, t in d.items():
@@ -496,12 +515,16 @@ class _ConvBase(Layer):
         n = x.shape[0]
         g = self.geom(n)
         ho, wo, cout = self.output_shape_
-        if self.fused_bwd and ctx.param_grads and not ctx.lp:
+        fused = self.fused_bwd and ctx.param_grads and not ctx.lp
+        s1 = self.__dict__.setdefault("_s1_bwd", {})  # per batch size
+        if fused and n not in s1:
+            s1[n] = ops.conv2d_s1_mfma_bwd(g)
+        if ctx.dgrad_jobs and not (fused and not s1[n] and ctx.wgrad_jobs is not None and not ctx.side
+                                   and self.kernel_size == (3, 3)):
+            ctx.flush_dgrad()  # this layer's launches read dy now: the pending launches that produce it go first
+        if fused:
             dx = ctx.buf(self, "dx", tuple(x.shape)) if need_dx else None
             db = self.bias.grad if self.bias is not None else None
-            s1 = self.__dict__.setdefault("_s1_bwd", {})  # per batch size
-            if n not in s1:
-                s1[n] = ops.conv2d_s1_mfma_bwd(g)
             if s1[n] and not ctx.side:
                 # 16..128-channel layers: one call forms dz once and runs both gradients on the matrix cores; the
                 # workspace (dz + the kernel gradient's partial sums) is this layer's own until the deferred sums ran
@@ -518,7 +541,10 @@ class _ConvBase(Layer):
                 else:
                     ops.conv2d_bwd_partial(g, x, dy, y, s.get("idx"), self.act, self.alpha, db is not None, ws)
                     ctx.wgrad_finish.append((g, ws, self.kernel.grad, db))
-                if need_dx:
+                if need_dx and ctx.dgrad_jobs is not None and self.kernel_size == (3, 3):
+                    ctx.dgrad_jobs.append(dict(g=g, w=self.kernel.data, dy=dy, y=y, idx=s.get("idx"), dx=dx, act=self.act,
+                                               alpha=self.alpha))
+                elif need_dx:
                     ops.conv2d_bwd(g, None, self.kernel.data, dy, y, s.get("idx"), dx, None, None, self.act, self.alpha,
                                    None)
                 return dx
@@ -1023,7 +1049,10 @@ class Sequential(Layer):
             first += 1  # layers before the first weighted one only matter if the caller wants dx
         for i in range(len(self.layers) - 1, -1, -1):
             want = need_dx or i > first
-            dy = self.layers[i].backward(ctx, dy, need_dx=want)
+            l = self.layers[i]
+            if ctx.dgrad_jobs and not (isinstance(l, (Sequential, InputLayer, _ConvBase)) or getattr(l, "folded", False)):
+                ctx.flush_dgrad()  # this layer reads dy: the launches that produce it go first
+            dy = l.backward(ctx, dy, need_dx=want)
             if ctx.grad_ready is not None:
                 vs = self.layers[i].all_variables()
                 if vs:

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT, BF16, F32, BatchRows, ConvGeom, GradSlabs, NetLayer, WgradBatchJob, WgradJob, check, lib
+from ._lib import ACT, BF16, F32, BatchRows, ConvGeom, DgradJob, GradSlabs, NetLayer, WgradBatchJob, WgradJob, check, lib
 
 
 def set_option(name: str, value: int):
@@ -337,6 +337,28 @@ def conv2d_wgrad_finish(jobs):
         a.workspace, a.dw, a.db = _ptr(ws, torch.uint8), _ptr(dw), _ptr(db)
         a.accumulate, a.blocks = 1, (job[4] if len(job) > 4 else 0)
     check(lib.sv_conv2d_wgrad_finish(arr, len(jobs), F32, _stream()), "sv_conv2d_wgrad_finish")
+
+
+def _dgrad_jobs(jobs):
+    arr = (DgradJob * len(jobs))()
+    for a, d in zip(arr, jobs):
+        a.g = d["g"]
+        a.w, a.dy, a.y, a.idx, a.dx = _ptr(d["w"]), _ptr(d["dy"]), _ptr(d["y"]), _ptr(d.get("idx"), torch.uint8), _ptr(d["dx"])
+        a.act, a.alpha = ACT[d["act"]], d["alpha"] or 0.0
+    return arr
+
+
+def conv2d_dgrad_chain_supported(jobs) -> bool:
+    """Whether ``conv2d_dgrad_chain`` takes these jobs (all in the few-channel 3x3 family, one batch size, at most 8)."""
+    if not jobs or len(jobs) > 8:
+        return False
+    return bool(lib.sv_conv2d_dgrad_chain_supported(_dgrad_jobs(jobs), len(jobs)))
+
+
+def conv2d_dgrad_chain(jobs):
+    """The input gradients of consecutive layers (dicts g, w, dy, y, idx, dx, act, alpha; a job's dy may be an earlier
+    job's dx) in one launch."""
+    check(lib.sv_conv2d_dgrad_chain(_dgrad_jobs(jobs), len(jobs), F32, _stream()), "sv_conv2d_dgrad_chain")
 
 
 def conv2d_bwd(g: ConvGeom, x, w, dy, y, idx, dx, dw, db, act: str, alpha: float, ws: Optional[torch.Tensor]):

@@ -110,3 +110,58 @@ def test_pixel_pair_form_of_the_8_channel_layer_equals_the_direct_form(n, sv_opt
         ops.conv2d_bwd(g, None, wt, dy, y, idx, dx, None, None, act, 1.0, None)
         got[pair] = dx
     assert torch.equal(got["1"], got["0"])
+
+
+def chain_jobs(n, seed):
+    """The five input-gradient jobs of the default stack's backward pass, decoder first, each reading the previous
+    job's dx as its dy."""
+    from spectrum_vae_amd import ops
+    rng = np.random.default_rng(seed)
+    jobs, dy = [], None
+    for h, w_, cin, cout, up, pooled, act in (LAYERS[4], LAYERS[3], LAYERS[2], LAYERS[1], LAYERS[0]):
+        H, W = h * up, w_ * up
+        oh, ow = (H // 2, W // 2) if pooled else (H, W)
+        g = ops.conv_geom(n, H, W, cin, 3, 3, 1, 1, "same", cout, (up, up))
+        y = rng.standard_normal((n, oh, ow, cout)).astype(np.float32)
+        if dy is None:
+            dy = torch.from_numpy(rng.standard_normal((n, oh, ow, cout)).astype(np.float32)).cuda()
+        assert tuple(dy.shape) == (n, oh, ow, cout)
+        idx = torch.from_numpy(rng.integers(0, 4, (n, oh, ow, cout)).astype(np.uint8)).cuda() if pooled else None
+        dx = torch.full((n, h, w_, cin), 7.0, device="cuda")
+        jobs.append(dict(g=g, w=torch.from_numpy((0.3 * rng.standard_normal((3, 3, cin, cout))).astype(np.float32)).cuda(),
+                         dy=dy, y=torch.from_numpy(np.tanh(y) if act == "tanh" else y).cuda(), idx=idx, dx=dx, act=act,
+                         alpha=1.0))
+        dy = dx
+    return jobs
+
+
+@pytest.mark.parametrize("grid", [-1, 2, 256, 1024])
+@pytest.mark.parametrize("n", [1, 5, 130, 1024, 1027])
+def test_chain_of_layers_in_one_launch_equals_one_launch_per_layer(n, grid, sv_opts):
+    from spectrum_vae_amd import ops
+    sv_opts("dgrad_chain", grid)
+    jobs = chain_jobs(n, 11 + n)
+    assert ops.conv2d_dgrad_chain_supported(jobs)
+    ops.conv2d_dgrad_chain(jobs)
+    got = [j["dx"].clone() for j in jobs]
+    for j in jobs:
+        j["dx"].fill_(-3.0)
+    for j in jobs:
+        ops.conv2d_bwd(j["g"], None, j["w"], j["dy"], j["y"], j["idx"], j["dx"], None, None, j["act"], j["alpha"], None)
+    for a, j in zip(got, jobs):
+        assert torch.equal(a, j["dx"])  # the same products summed in the same order, whoever owns the sample
+
+
+def test_chain_declines_what_it_does_not_cover(sv_opts):
+    from spectrum_vae_amd import ops
+    jobs = chain_jobs(8, 3)
+    sv_opts("dgrad_chain", 0)
+    assert not ops.conv2d_dgrad_chain_supported(jobs)
+    sv_opts("dgrad_chain", -1)
+    other = chain_jobs(4, 3)
+    assert not ops.conv2d_dgrad_chain_supported(jobs[:2] + other[2:])  # batch sizes differ
+    g5 = ops.conv_geom(8, 16, 16, 8, 5, 5, 1, 1, "same", 16)
+    bad = dict(jobs[0], g=g5)
+    assert not ops.conv2d_dgrad_chain_supported([bad] + jobs[1:])
+    with pytest.raises(RuntimeError, match="outside the few-channel 3x3 family"):
+        ops.conv2d_dgrad_chain([bad] + jobs[1:])
