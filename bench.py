@@ -108,7 +108,11 @@ class OpTimer:
                 nhwc = all(sh in ((3, 8, 32), (8, 16, 16), (16, 32, 8), (32, 16, 8), (16, 8, 16), (8, 3, 32)) for sh in shapes)
                 slabs = name.endswith("_slabs")  # one launch: the slabs stay for the optimizer launch to sum
                 info = {"jobs": nj, "flops": fl, "single_launch": slabs or not args[2], "nhwc": nhwc, "slabs": slabs}
-            elif name in ("sv_convnet_fwd", "sv_convnet_fwd_mse", "sv_convnet_fwd_mse_rows"):
+            elif name == "sv_conv2d_dgrad_chain":
+                arr, nj = args[0], args[1]
+                info = {"jobs": nj, "flops": sum(2 * arr[i].g.N * arr[i].g.Ho * arr[i].g.Wo * arr[i].g.Cout * arr[i].g.KH *
+                                                 arr[i].g.KW * arr[i].g.Cin for i in range(nj))}
+            elif name in ("sv_convnet_fwd", "sv_convnet_fwd_mse", "sv_convnet_fwd_mse_rows", "sv_convnet_fwd_mse_dgrad"):
                 arr, nl, n, h, w = args[0], args[1], args[2], args[3], args[4]
                 fl = 0
                 for i in range(nl):
@@ -118,6 +122,11 @@ class OpTimer:
                     h, w = (ho // 2, wo // 2) if L.pool else (ho, wo)
                 chain = [(arr[i].Cin, arr[i].Cout, arr[i].up, arr[i].pool) for i in range(nl)]
                 info = {"N": n, "layers": nl, "flops": fl, "default_chain": chain == DEFAULT_CHAIN and args[3] == 32 and args[4] == 32}
+                if name == "sv_convnet_fwd_mse_dgrad":  # the input-gradient jobs the launch also runs: args[13], args[14]
+                    jb, nj = args[13], args[14]
+                    info["dgrad_jobs"] = nj
+                    info["flops"] += sum(2 * jb[i].g.N * jb[i].g.Ho * jb[i].g.Wo * jb[i].g.Cout * jb[i].g.KH * jb[i].g.KW *
+                                         jb[i].g.Cin for i in range(nj))
             self.records.append((name, info, s, e))
             self.calls.append((name, info, fn, args))
             return rc
@@ -147,6 +156,10 @@ def kernel_of_call(name: str, g):
         # the layer table of the run_model.py defaults has a kernel built for it; other tables take the run-time-table one
         known = g.get("default_chain") and _opt("netfwd_generic") != 1
         return ("net_fwd_cae" if known else "net_fwd_s1<3>"), float(g["flops"])
+    if name == "sv_convnet_fwd_mse_dgrad":
+        return "net_fwd_dgrad_cae", float(g["flops"])  # forward + the input-gradient chain, one launch
+    if name == "sv_conv2d_dgrad_chain":
+        return "dgrad_chain_k", float(g["flops"])
     if name == "sv_conv2d_wgrad_batch_slabs":
         return "wgrad_nhwc_multi", float(g["flops"])  # exactly that launch; the optimizer launch sums its slabs
     if name == "sv_conv2d_wgrad_batch":

@@ -246,6 +246,19 @@ typedef struct sv_dgrad_job {
 int sv_conv2d_dgrad_chain_supported(const sv_dgrad_job* jobs, int n_jobs);
 int sv_conv2d_dgrad_chain(const sv_dgrad_job* jobs, int n_jobs, int dtype, sv_stream_t stream);
 
+/* ---- sv_convnet_fwd_mse (x given, rows NULL) or sv_convnet_fwd_mse_rows (rows given, x ignored) followed IN THE SAME
+ *      LAUNCH by the input-gradient jobs of the backward pass (sv_conv2d_dgrad_chain's list): the first half of the
+ *      training step of run_model.py:281-289 (forward, loss, activation-gradient chain of the tape).  The jobs may
+ *      read dpred and the layers' y / idx buffers of this call: a workgroup carries its samples from the input to the
+ *      last job.  Only the default stack's forward kernel has this form and the jobs must be in the chain's family:
+ *      sv_convnet_fwd_mse_dgrad_supported tells (1); otherwise SV_E_UNSUPPORTED and nothing is launched. */
+int sv_convnet_fwd_mse_dgrad_supported(const sv_net_layer* layers, int n_layers, int N, int H, int W,
+                                       const sv_dgrad_job* jobs, int n_jobs);
+int sv_convnet_fwd_mse_dgrad(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x,
+                             const sv_batch_rows* rows, const void* params, const float* y_true, float* dpred,
+                             float loss_scale, float* partials, int* n_partials, const sv_dgrad_job* jobs, int n_jobs,
+                             int dtype, sv_stream_t stream);
+
 /* ---- Conv2DTranspose (autoencoder.py:371,382; unet.py:69,123; context_encoder.py:92,105,119,260,276,290) */
 /* y[(H,W,Cin) side] = act(conv_transpose(x[(Ho,Wo,Cout) side], w) + bias), w laid out (kh,kw,Cin_of_geom,Cout_of_geom). */
 int sv_conv2d_transpose_fwd(const sv_conv_geom* g, const void* x, const void* w, const void* bias, void* y,

@@ -100,6 +100,9 @@ SIGNATURES = {
     "sv_conv2d_bwd_partial": (_i, [_g, _p, _p, _p, _p, _i, _f, _i, _p, _sz, _i, _p]),
     "sv_conv2d_wgrad_finish": (_i, [C.POINTER(WgradJob), _i, _i, _p]),
     "sv_conv2d_wgrad_batch": (_i, [C.POINTER(WgradBatchJob), _i, _i, _i, _p]),
+    "sv_convnet_fwd_mse_dgrad_supported": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, C.POINTER(DgradJob), _i]),
+    "sv_convnet_fwd_mse_dgrad": (_i, [C.POINTER(NetLayer), _i, _i, _i, _i, _p, C.POINTER(BatchRows), _p, _p, _p, _f, _p,
+                                 C.POINTER(C.c_int), C.POINTER(DgradJob), _i, _i, _p]),
     "sv_conv2d_dgrad_chain_supported": (_i, [C.POINTER(DgradJob), _i]),
     "sv_conv2d_dgrad_chain": (_i, [C.POINTER(DgradJob), _i, _i, _p]),
     "sv_conv2d_wgrad_batch_slabs_supported": (_i, [C.POINTER(WgradBatchJob), _i]),

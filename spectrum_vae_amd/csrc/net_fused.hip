@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "tile_common.h"
+#include "dgrad_nhwc_body.h"
 
 namespace sv {
 
@@ -1143,6 +1144,36 @@ __global__ __launch_bounds__(256, 2) void net_fwd_cae(NetCaeArgs r) {
     }, smem);
 }
 
+// The same forward pass followed, in the same launch, by the input-gradient chain of the backward pass: dL/dy of the
+// squared error leaves with the last layer's output, and every tensor a sample's gradient chain reads (that gradient,
+// the layers' outputs and argmax bytes) was written by the workgroup that carries the sample, so it goes straight on
+// instead of waiting for the slowest workgroup of the forward launch and for the next launch to ramp up.
+struct NetCaeTrainArgs {
+    NetCaeArgs r;
+    DnChainArgs c;  // S == the forward's samples per workgroup
+};
+
+__global__ __launch_bounds__(256, 2) void net_fwd_dgrad_cae(NetCaeTrainArgs t) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const NetCaeArgs& r = t.r;
+    NetFwdArgs a{};
+    a.x = r.x; a.params = r.params; a.N = r.N; a.S = kCae.a.S; a.n_layers = kCaeLayers; a.w_off = kCae.a.w_off;
+    a.loss_t = r.loss_t; a.loss_dpred = r.loss_dpred; a.loss_partials = r.loss_partials; a.loss_gscale = r.loss_gscale;
+    a.rows = r.rows;
+    net_fwd_run<3, kCaeLayers>(a, [&](int l) __attribute__((always_inline)) {
+        NetLayer L = kCae.a.L[l];
+        L.w_off = r.rt[l].w_off; L.b_off = r.rt[l].b_off;
+        L.y = r.rt[l].y; L.idx = r.rt[l].idx;
+        return L;
+    }, smem);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the table is indexed by a loop counter: read it where the launch put it (scalar loads), not through the parameter
+    const DnChainArgs& c = *(const DnChainArgs*)((const char*)(const void*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                 offsetof(NetCaeTrainArgs, c));
+    dn_chain_run(c, blockIdx.x * c.S, true);
+#endif
+}
+
 // true when the plan's table is the compile-time one (pointers and parameter offsets aside)
 static bool net_plan_is_cae(const NetFwdArgs& p, int nt) {
     if (opt(OPT_NETFWD_GENERIC) == 1 || nt != 256 || p.n_layers != kCaeLayers || p.S != kCae.a.S || p.w_off != kCae.a.w_off) return false;
@@ -1215,6 +1246,9 @@ static int net_enable_lds(size_t bytes) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&net_fwd_cae), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kNetLdsPerBlock);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&net_fwd_dgrad_cae),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNetLdsPerBlock);
     if (e != hipSuccess) return fail(SV_E_LAUNCH, "net_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
     enabled = kNetLdsPerBlock;
     return SV_OK;
@@ -1244,7 +1278,8 @@ static bool net_rows_ok(const NetPlan& p, const sv_net_layer* layers, int H, int
 
 static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x,
                            const void* params, const float* y_true, float* dpred, float loss_scale, float* partials,
-                           int* n_partials, sv_stream_t stream, const sv_batch_rows* rows = nullptr) {
+                           int* n_partials, sv_stream_t stream, const sv_batch_rows* rows = nullptr,
+                           const sv_dgrad_job* jobs = nullptr, int n_jobs = 0) {
     int rc = net_validate(layers, n_layers, N, H, W, who);
     if (rc) return rc;
     if (rows != nullptr) x = rows->x_batch;
@@ -1287,9 +1322,23 @@ static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_la
         }
         const int passes = (N + p.S - 1) / p.S;
         if (y_true != nullptr) *n_partials = passes;
+        if (jobs != nullptr) {
+            NetCaeTrainArgs t{};
+            t.r = r;
+            int grid = 0;
+            size_t chain_lds = 0;
+            if (plan_dgrad_chain(jobs, n_jobs, p.S, &t.c, &grid, &chain_lds) || grid != passes || jobs[0].g.N != N ||
+                chain_lds > kNetLdsPerBlock)
+                return fail(SV_E_UNSUPPORTED, "%s: the input-gradient jobs do not run behind this forward launch", who);
+            const size_t lds = chain_lds > p.lds_bytes ? chain_lds : p.lds_bytes;
+            hipLaunchKernelGGL(net_fwd_dgrad_cae, dim3((unsigned)passes), dim3(256), lds, to_stream(stream), t);
+            return check_launch("net_fwd_dgrad_cae");
+        }
         hipLaunchKernelGGL(net_fwd_cae, dim3((unsigned)passes), dim3(256), p.lds_bytes, to_stream(stream), r);
         return check_launch("net_fwd_cae");
     }
+    if (jobs != nullptr)
+        return fail(SV_E_UNSUPPORTED, "%s: this layer table has no launch that also runs input-gradient jobs", who);
     hipLaunchKernelGGL((net_fwd_s1<3>), dim3((unsigned)p.grid), dim3((unsigned)p.nt), p.lds_bytes, to_stream(stream), p.args);
     return check_launch("net_fwd_s1");
 }
@@ -1330,6 +1379,46 @@ int sv_convnet_fwd_mse_rows(const sv_net_layer* layers, int n_layers, int N, int
                "sv_convnet_fwd_mse_rows: tensors must be 16-byte aligned");
     return convnet_fwd_any("sv_convnet_fwd_mse_rows", layers, n_layers, N, H, W, nullptr, params, y_true, dpred, loss_scale,
                            partials, n_partials, stream, rows);
+}
+
+// ---- forward + squared error + the input-gradient chain of the backward pass in one launch
+static bool dgrad_jobs_set(const sv_dgrad_job* jobs, int n_jobs) {
+    if (jobs == nullptr || n_jobs < 1 || n_jobs > 8) return false;
+    for (int j = 0; j < n_jobs; ++j)
+        if (!jobs[j].w || !jobs[j].dy || !jobs[j].y || !jobs[j].dx) return false;
+    return true;
+}
+
+int sv_convnet_fwd_mse_dgrad_supported(const sv_net_layer* layers, int n_layers, int N, int H, int W,
+                                       const sv_dgrad_job* jobs, int n_jobs) {
+    if (net_validate(layers, n_layers, N, H, W, "sv_convnet_fwd_mse_dgrad_supported") || !dgrad_jobs_set(jobs, n_jobs)) return 0;
+    const NetPlan p = plan_net_fwd(layers, n_layers, N, H, W);
+    if (!p.ok || !net_plan_is_cae(p.args, p.nt) || (N + p.S - 1) / p.S > 1024) return 0;
+    DnChainArgs c;
+    int grid = 0;
+    size_t lds = 0;
+    return plan_dgrad_chain(jobs, n_jobs, p.S, &c, &grid, &lds) == 0 && grid == (N + p.S - 1) / p.S && jobs[0].g.N == N &&
+                   lds <= kNetLdsPerBlock ? 1 : 0;
+}
+
+int sv_convnet_fwd_mse_dgrad(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x,
+                             const sv_batch_rows* rows, const void* params, const float* y_true, float* dpred,
+                             float loss_scale, float* partials, int* n_partials, const sv_dgrad_job* jobs, int n_jobs,
+                             int dtype, sv_stream_t stream) {
+    SV_F32_ONLY(dtype, "sv_convnet_fwd_mse_dgrad");
+    SV_REQUIRE(y_true && dpred && partials && n_partials, "sv_convnet_fwd_mse_dgrad: null loss argument");
+    SV_REQUIRE(dgrad_jobs_set(jobs, n_jobs), "sv_convnet_fwd_mse_dgrad: bad job list (1..8 jobs, tensors set)");
+    if (rows != nullptr) {
+        SV_REQUIRE(rows->x_rows && rows->row_index && rows->x_batch, "sv_convnet_fwd_mse_dgrad: null row table");
+        SV_REQUIRE(rows->n_rows > 0 && rows->n_index >= N && rows->batch_stride >= 0,
+                   "sv_convnet_fwd_mse_dgrad: the index list is shorter than the batch");
+        SV_REQUIRE((rows->counter == nullptr) == (rows->counter_base == nullptr),
+                   "sv_convnet_fwd_mse_dgrad: counter and counter_base go together");
+        SV_REQUIRE(((uintptr_t)rows->x_rows % 16 == 0) && ((uintptr_t)rows->x_batch % 16 == 0),
+                   "sv_convnet_fwd_mse_dgrad: tensors must be 16-byte aligned");
+    }
+    return convnet_fwd_any("sv_convnet_fwd_mse_dgrad", layers, n_layers, N, H, W, x, params, y_true, dpred, loss_scale,
+                           partials, n_partials, stream, rows, jobs, n_jobs);
 }
 
 }  // extern "C"

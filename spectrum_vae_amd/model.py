@@ -100,6 +100,8 @@ class Model(Layer):
         # model's backward() reads gradient tensors only inside Sequentials (which launch what is pending first) or
         # behind a ctx.flush_dgrad() of its own; such a class says so with chain_dgrad_ok = True.
         self.chain_dgrad = bool(getattr(type(self), "chain_dgrad_ok", False))
+        self.fuse_fwd_dgrad = True   # ... and that launch behind the forward pass, in the forward launch
+        self._dgrad_plans = {}       # (batch, slot) -> the job list of the last backward pass that was one chain
         self.defer_wgrad_reduce = True  # one reduction launch for the kernel gradients of all fused conv layers
         self._chain_cache: Dict[int, object] = {}
         self._slabs_wanted = False   # set around the backward pass of a training step whose optimizer launch can sum slabs
@@ -344,6 +346,14 @@ class Model(Layer):
         if plan is False:
             return None
         arr, bufs, h, w = plan
+        # The input-gradient jobs the backward pass of an earlier step with these buffers issued (same batch size and slot
+        # -> same pool buffers -> same addresses): when that pass follows this forward call directly, as in a training
+        # step, the forward launch runs them too and the backward pass finds them done (CallCtx.flush_dgrad compares the
+        # list it collects with this one and launches it itself if they differ).
+        jobs = self._dgrad_plans.get(key) if (ctx.training and mse is not None and self.fuse_fwd_dgrad) else None
+        if jobs is not None and not (jobs[0]["dy"].data_ptr() == mse[1].data_ptr()
+                                     and ops.convnet_fwd_mse_dgrad_supported(arr, n, h, w, jobs)):
+            jobs = None
         if self._rows is not None:
             # the launch gathers the batch into x (fit / rows_step_supported chose this form for this chain)
             if not (mse is not None and mse[0] is x and ops.convnet_rows_supported(arr, n, h, w)):
@@ -351,11 +361,19 @@ class Model(Layer):
             y_true, dpred, partials = mse
             r = self._rows
             rows = ops.batch_rows(r["X"], r["index"], x, self.optimizer._ensure_state(x.device), r["base"], r["stride"])
-            cnt = ops.convnet_fwd_mse_rows(arr, n, h, w, rows, self._params, y_true, dpred, 1.0, partials)
+            if jobs is not None:
+                cnt = ops.convnet_fwd_mse_dgrad(arr, n, h, w, None, rows, self._params, y_true, dpred, 1.0, partials, jobs)
+                ctx.dgrad_prelaunched = ctx.dgrad_signature(jobs)
+            else:
+                cnt = ops.convnet_fwd_mse_rows(arr, n, h, w, rows, self._params, y_true, dpred, 1.0, partials)
             ctx.loss_fold = (partials, cnt, 1.0 / y_true.numel())
         elif mse is not None and bufs[-1][2] is None and tuple(mse[0].shape) == tuple(bufs[-1][1].shape):
             y_true, dpred, partials = mse
-            cnt = ops.convnet_fwd_mse(arr, n, h, w, x, self._params, y_true, dpred, 1.0, partials)
+            if jobs is not None:
+                cnt = ops.convnet_fwd_mse_dgrad(arr, n, h, w, x, None, self._params, y_true, dpred, 1.0, partials, jobs)
+                ctx.dgrad_prelaunched = ctx.dgrad_signature(jobs)
+            else:
+                cnt = ops.convnet_fwd_mse(arr, n, h, w, x, self._params, y_true, dpred, 1.0, partials)
             ctx.loss_fold = (partials, cnt, 1.0 / y_true.numel())
         else:
             ops.convnet_fwd(arr, n, h, w, x, self._params)
@@ -372,7 +390,9 @@ class Model(Layer):
                     input_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Forward on a prepared device tensor; the result aliases the model's buffer pool.  ``side``: stream
         the backward pass of this call may use for its weight-gradient kernels (the caller joins it).  ``mse``: see
-        ``_net_forward``; honoured only when the whole forward is the one-launch kernel (check ``ctx.loss_fold``).
+        ``_net_forward``; honoured only when the whole forward is the one-launch kernel (check ``ctx.loss_fold``).  The
+        gradient buffer in it must reach ``backward_raw`` as the launch left it: the launch may already have run the
+        input-gradient chain from it.
         ``input_mask`` (float32, shape of x): the model sees x * (1 - input_mask) (run_context_encoder.py:242-243); when
         the first layer is a convolution of the implicit-GEMM family the product is formed inside its gathers (forward
         and kernel gradient) and the masked tensor never exists, otherwise it costs one elementwise pass."""
@@ -445,7 +465,13 @@ class Model(Layer):
             if self.chain_dgrad and ctx.dgrad_jobs is None:
                 ctx.dgrad_jobs = []  # consecutive 3x3 layers' input gradients as one launch
             dx = self.backward(ctx, dy, need_dx=need_dx)
+            whole = bool(ctx.dgrad_jobs) and ctx.dgrad_last is None  # nothing was launched on the way
             ctx.flush_dgrad()
+            if whole and ctx.loss_fold is not None and getattr(ctx, "net", None) is not None:
+                # the pass was forward launch -> loss gradient -> this one chain: the next step's forward launch takes it
+                n = dy.shape[0]
+                key = (n, ctx.slot if not isinstance(ctx.slot, int) else "train%d" % ctx.slot)
+                self._dgrad_plans[key] = ctx.dgrad_last
             ctx.dgrad_jobs = None
             nb = self.wgrad_batch_blocks if len(ctx.wgrad_jobs) >= 3 else 0
             for j in ctx.wgrad_jobs:  # layers with large images: fewer workgroups, each staging more samples

@@ -238,14 +238,28 @@ class CallCtx:
         # whole chain as one launch (ops.conv2d_dgrad_chain).  Any layer that READS a gradient tensor launches what is
         # pending first (flush_dgrad); conv layers of the chain and layers that only pass the tensor on do not.
         self.dgrad_jobs: Optional[list] = None
+        # the jobs the forward launch of this call already ran (Model._net_forward), as dgrad_signature() of the list
+        self.dgrad_prelaunched = None
+        self.dgrad_last = None  # the list the last flush_dgrad of this call was asked to launch
+
+    @staticmethod
+    def dgrad_signature(jobs):
+        """What identifies a job list to a launch: geometry, activation and the addresses of every tensor."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        return tuple((bytes(j["g"]), j["act"], j["alpha"], ptr(j["w"]), ptr(j["dy"]), ptr(j["y"]), ptr(j.get("idx")),
+                      ptr(j["dx"])) for j in jobs)
 
     def flush_dgrad(self):
         """Launch the input-gradient jobs collected so far (one launch when the library has the chained form for them,
-        else one per layer, in order)."""
+        else one per layer, in order); nothing to launch when the forward launch of this call ran exactly this list."""
         jobs = self.dgrad_jobs
         if not jobs:
             return
         self.dgrad_jobs = []
+        self.dgrad_last = jobs
+        done, self.dgrad_prelaunched = self.dgrad_prelaunched, None
+        if done is not None and done == self.dgrad_signature(jobs):
+            return
         if len(jobs) > 1 and ops.conv2d_dgrad_chain_supported(jobs):
             ops.conv2d_dgrad_chain(jobs)
             return

@@ -246,6 +246,25 @@ def convnet_fwd_mse_rows(arr, n: int, h: int, w: int, rows: BatchRows, params, y
     return int(cnt.value)
 
 
+def convnet_fwd_mse_dgrad_supported(arr, n: int, h: int, w: int, jobs) -> bool:
+    """Whether ``convnet_fwd_mse_dgrad`` takes this layer table with these input-gradient jobs behind it."""
+    if not jobs or len(jobs) > 8:
+        return False
+    return bool(lib.sv_convnet_fwd_mse_dgrad_supported(arr, len(arr), n, h, w, _dgrad_jobs(jobs), len(jobs)))
+
+
+def convnet_fwd_mse_dgrad(arr, n: int, h: int, w: int, x, rows, params, y_true, dpred, loss_scale, partials, jobs) -> int:
+    """``convnet_fwd_mse`` (``rows`` None) or ``convnet_fwd_mse_rows`` (``rows`` a ``batch_rows`` table) with the
+    input-gradient jobs of the backward pass (``conv2d_dgrad_chain``'s list) run by the same launch."""
+    if y_true.numel() != dpred.numel() or partials.numel() < loss_workspace_floats():
+        raise ValueError("convnet_fwd_mse_dgrad: y_true / dpred sizes differ or the partial-sum scratch is too small")
+    cnt = C.c_int(0)
+    check(lib.sv_convnet_fwd_mse_dgrad(arr, len(arr), n, h, w, _ptr(x), C.byref(rows) if rows is not None else None,
+                                       _ptr(params), _ptr(y_true), _ptr(dpred), loss_scale, _ptr(partials), C.byref(cnt),
+                                       _dgrad_jobs(jobs), len(jobs), F32, _stream()), "sv_convnet_fwd_mse_dgrad")
+    return int(cnt.value)
+
+
 def convnet_fwd_mse(arr, n: int, h: int, w: int, x, params, y_true, dpred, loss_scale, partials) -> int:
     """Forward + squared-error loss gradient in one launch; returns how many entries of ``partials`` hold the
     per-workgroup sums of squared errors (fold them with ``fold_scalar`` or the optimizer launch)."""

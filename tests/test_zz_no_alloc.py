@@ -3,6 +3,8 @@ workspace argument, no allocation) against sv_conv2d_wgrad with a caller workspa
 
 Bar: bit-identical (the same kernels run, the partial sums are folded in the same fixed order), on two calls in a row of
 which the second has the smaller input - it must not see what the first left in the shared array."""
+import gc
+
 import numpy as np
 import pytest
 import torch
@@ -31,13 +33,20 @@ def _both(g, x, dz, accumulate):
     ops.conv2d_wgrad(g, x, dz, want, accumulate, ws)
     got = start.clone()
     ops.static_scratch_bytes()  # the once-per-GPU address lookup, outside the measurement below
-    torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
-    free_before = torch.cuda.mem_get_info()[0]
-    ops.conv2d_wgrad_static(g, x, dz, got, accumulate)
-    torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before  # nothing came from torch's allocator ...
-    assert torch.cuda.mem_get_info()[0] == free_before  # ... and nothing from hipMalloc inside the library
+    # earlier tests' models (reference cycles) are collected now, not by a collection that happens to run inside the
+    # measured window and returns their buffers to the allocator
+    gc.collect()
+    gc.disable()
+    try:
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        free_before = torch.cuda.mem_get_info()[0]
+        ops.conv2d_wgrad_static(g, x, dz, got, accumulate)
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() == before  # nothing came from torch's allocator ...
+        assert torch.cuda.mem_get_info()[0] == free_before  # ... and nothing from hipMalloc inside the library
+    finally:
+        gc.enable()
     return got, want
 
 
