@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_chain_k(DnChainArgs) {
 #else
     const DnChainArgs c{};  // host pass: the body is never run
 #endif
-    dn_chain_run(c, blockIdx.x * c.S, false);
+    dn_chain_run<true>(c, blockIdx.x * c.S, false);
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -70,16 +70,19 @@ static int dn_plan(const sv_conv_geom& g, const float* y, const uint8_t* idx, Dn
     else if (CZ == 16 && CX == 32 && W == 8) shape = 2;
     else if (CZ == 32 && CX == 16 && W == 8) shape = 3;
     else if (CZ == 16 && CX == 8 && W == 16) shape = 4;
+    else if (CZ == 8 && CX == 8 && W == 32) shape = 5;
+    else if (CZ == 8 && CX == 8 && W == 16) shape = 6;
+    else if (CZ == 8 && CX == 8 && W == 8) shape = 7;
     else return 1;
     if (CZ == 3 && zmode == 2) return 1;
     if ((H & 1) || y == nullptr) return 1;
     // an upsampled conv as a 4 x 4 window over the stored pixels (PH in the kernel) where the stored image holds tiles
-    bool ph = g.up_h == 2 && (shape == 0 || shape == 1) && (H % 4) == 0 && (W % 16) == 0;
+    bool ph = g.up_h == 2 && (shape == 0 || shape == 1 || shape == 5 || shape == 6) && (H % 4) == 0 && (W % 16) == 0;
     if (opt(OPT_DGRAD_PHASE) == 0) ph = false;
     int tps = ph ? (H / 4) * (W / 16) : (H / 2) * (W / 8);
     if (ph && (tps < 4 || (tps & (tps - 1)))) { ph = false; tps = (H / 2) * (W / 8); }
     // 8 input channels without upsampling: pixel pairs as result columns (MODE 2 in the kernel)
-    bool wd = !ph && g.up_h == 1 && shape == 4 && (W % 16) == 0;
+    bool wd = !ph && g.up_h == 1 && (shape == 4 || shape == 5 || shape == 6) && (W % 16) == 0;
     if (opt(OPT_DGRAD_PAIR) == 0) wd = false;
     if (wd) {
         const int t2 = (H / 2) * (W / 16);
@@ -118,14 +121,14 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
     // workgroups (measured at batch 1024): one sample each for the 32-wide 3-channel image (few registers, 14 KB of LDS:
     // four workgroups share a CU and hide each other's load latencies), two per CU for the 16-wide image with 8-channel
     // dz, one per CU elsewhere, where more workgroups only repeat the filter loads
-    int grid = shape == 0 ? 1024 : ((shape == 1 || shape == 3 || shape == 4) ? 512 : 256);
+    int grid = shape == 0 ? 1024 : ((shape == 1 || shape == 3 || shape == 4 || shape >= 5) ? 512 : 256);
     if (ph) grid = 512;  // a quarter of the tiles per sample: fewer, longer-lived workgroups
     if (opt(OPT_DGRAD_GRID) > 0) grid = opt(OPT_DGRAD_GRID);
     if (grid > g.N) grid = g.N;
     int ns = 1;
     // one pass per workgroup where the samples fit (LDS, staging registers): a second pass costs its staging and two
     // barriers again, and two workgroups per CU already overlap each other's phases
-    const int per_pass = 256 * dn_units(CZ);
+    const int per_pass = 256 * dn_units(CZ, g.W);
     while (ns < 8 && lds(ns + 1) <= 64 * 1024 && (ns + 1) * units <= per_pass && (int64_t)(ns + 1) * grid <= g.N) ++ns;
     if (lds(ns) > 64 * 1024 || ns * units > per_pass) return 1;
     if ((int64_t)grid * ns > g.N) grid = (g.N + ns - 1) / ns;
@@ -137,7 +140,10 @@ int launch_dgrad_nhwc(const sv_conv_geom& g, const float* w, const float* dy, co
         case 1: return dn_launch<8, 16, 16>(a, grid, bytes, st, ph ? 1 : 0);
         case 2: return dn_launch<16, 32, 8>(a, grid, bytes, st, 0);
         case 3: return dn_launch<32, 16, 8>(a, grid, bytes, st, 0);
-        default: return dn_launch<16, 8, 16>(a, grid, bytes, st, wd ? 2 : 0);
+        case 4: return dn_launch<16, 8, 16>(a, grid, bytes, st, wd ? 2 : 0);
+        case 5: return dn_launch<8, 8, 32>(a, grid, bytes, st, p.mode);
+        case 6: return dn_launch<8, 8, 16>(a, grid, bytes, st, p.mode);
+        default: return dn_launch<8, 8, 8>(a, grid, bytes, st, 0);
     }
 }
 
@@ -156,7 +162,7 @@ int plan_dgrad_chain(const sv_dgrad_job* jobs, int n_jobs, int S, DnChainArgs* c
         const sv_dgrad_job& q = jobs[j];
         DnPlan p;
         if (q.g.N != N || dn_plan(q.g, (const float*)q.y, q.idx, p)) return 1;
-        const int per_pass = 256 * dn_units(q.g.Cout);
+        const int per_pass = 256 * dn_units(q.g.Cout, q.g.W);
         int ns = 1;
         while (ns < S && p.lds(ns + 1) <= 64 * 1024 && (ns + 1) * p.units <= per_pass) ++ns;
         if (p.lds(ns) > 64 * 1024 || ns * p.units > per_pass) return 1;

@@ -49,7 +49,8 @@ struct DnArgs {
 
 // 16-byte pieces per thread and pass held in registers between load and store (two samples of 3-channel dz a pass were
 // measured: 13.6 against 11.9 us, its scalar staging then has nothing to hide behind)
-constexpr int dn_units(int) { return 4; }
+// (the 32 x 32 image of 8-channel dz is 2 048 pieces: eight per thread)
+constexpr int dn_units(int CZ, int WO) { return (CZ == 8 && WO == 32) ? 8 : 4; }
 
 // The LDS image of dz: floats from one pixel to the next (PS) and from one row to the next (RP).  The 16 lanes that one
 // LDS cycle of an operand read serves are 4 x 4 (16-byte reads), 2 x 16 (8- and 4-byte reads) (pixel, channel group)
@@ -116,7 +117,7 @@ __device__ __forceinline__ void dn_body(const DnArgs& a, const int nb, const int
     const int s_h = zmode == 2 ? H >> 1 : H, s_w = zmode == 2 ? WO >> 1 : WO;
     const int s_sample = s_h * s_w * CZ;
     const FDiv f_hw = fd_make(s_h * s_w), f_w = fd_make(s_w);
-    constexpr int kDnUnits = dn_units(CZ);
+    constexpr int kDnUnits = dn_units(CZ, WO);
     float4 rv[kDnUnits], ry[kDnUnits];
     uint32_t rk[kDnUnits];
     auto load_pass = [&](int n0) {
@@ -405,6 +406,9 @@ struct DnChainArgs {
 // The layers of the table in order, for the samples [nb, nb + c.S) of this workgroup.  `c` must be readable through
 // scalar loads with a run-time index (the kernel argument segment, not a by-value parameter, which the compiler would
 // first copy into every lane's scratch memory).
+// ALL: every shape of the family; otherwise only the layers of the default stack (the launch that runs the chain behind
+// that stack's forward pass carries no other bodies).
+template <bool ALL>
 __device__ __forceinline__ void dn_chain_run(const DnChainArgs& c, const int nb, const bool fence_first) {
     for (int j = 0; j < c.n_jobs; ++j) {
         const DnArgs& a = c.job[j];
@@ -424,7 +428,21 @@ __device__ __forceinline__ void dn_chain_run(const DnChainArgs& c, const int nb,
             case 8: dn_body<16, 32, 8, 0>(a, nb, ne, a.ns, blockIdx.x); break;
             case 12: dn_body<32, 16, 8, 0>(a, nb, ne, a.ns, blockIdx.x); break;
             case 16: dn_body<16, 8, 16, 0>(a, nb, ne, a.ns, blockIdx.x); break;
-            default: dn_body<16, 8, 16, 2>(a, nb, ne, a.ns, blockIdx.x); break;  // 18
+            case 18: dn_body<16, 8, 16, 2>(a, nb, ne, a.ns, blockIdx.x); break;
+            default:
+                if constexpr (ALL) {  // 8 -> 8 channels at the three image widths
+                    switch (c.code[j]) {
+                        case 20: dn_body<8, 8, 32, 0>(a, nb, ne, a.ns, blockIdx.x); break;
+                        case 21: dn_body<8, 8, 32, 1>(a, nb, ne, a.ns, blockIdx.x); break;
+                        case 22: dn_body<8, 8, 32, 2>(a, nb, ne, a.ns, blockIdx.x); break;
+                        case 24: dn_body<8, 8, 16, 0>(a, nb, ne, a.ns, blockIdx.x); break;
+                        case 25: dn_body<8, 8, 16, 1>(a, nb, ne, a.ns, blockIdx.x); break;
+                        case 26: dn_body<8, 8, 16, 2>(a, nb, ne, a.ns, blockIdx.x); break;
+                        case 28: dn_body<8, 8, 8, 0>(a, nb, ne, a.ns, blockIdx.x); break;
+                        default: break;
+                    }
+                }
+                break;
         }
     }
 }
@@ -433,5 +451,7 @@ __device__ __forceinline__ void dn_chain_run(const DnChainArgs& c, const int nb,
 // the batch, *lds_bytes is the largest layer's need.  0: planned; 1: a layer is outside the family, the batch sizes
 // differ or the list is too long.  (dgrad_nhwc.hip)
 int plan_dgrad_chain(const sv_dgrad_job* jobs, int n_jobs, int S, DnChainArgs* c, int* grid, size_t* lds_bytes);
+// whether a job's code is one of the default stack's (dn_chain_run<false> carries it)
+inline bool dn_code_in_default_stack(int code) { return code <= 18; }
 
 }  // namespace sv

@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256, 2) void net_fwd_dgrad_cae(NetCaeTrainArgs t) {
     // the table is indexed by a loop counter: read it where the launch put it (scalar loads), not through the parameter
     const DnChainArgs& c = *(const DnChainArgs*)((const char*)(const void*)__builtin_amdgcn_kernarg_segment_ptr() +
                                                  offsetof(NetCaeTrainArgs, c));
-    dn_chain_run(c, blockIdx.x * c.S, true);
+    dn_chain_run<false>(c, blockIdx.x * c.S, true);
 #endif
 }
 
@@ -1327,8 +1327,9 @@ static int convnet_fwd_any(const char* who, const sv_net_layer* layers, int n_la
             t.r = r;
             int grid = 0;
             size_t chain_lds = 0;
-            if (plan_dgrad_chain(jobs, n_jobs, p.S, &t.c, &grid, &chain_lds) || grid != passes || jobs[0].g.N != N ||
-                chain_lds > kNetLdsPerBlock)
+            bool carried = plan_dgrad_chain(jobs, n_jobs, p.S, &t.c, &grid, &chain_lds) == 0;
+            for (int j = 0; carried && j < n_jobs; ++j) carried = dn_code_in_default_stack(t.c.code[j]);
+            if (!carried || grid != passes || jobs[0].g.N != N || chain_lds > kNetLdsPerBlock)
                 return fail(SV_E_UNSUPPORTED, "%s: the input-gradient jobs do not run behind this forward launch", who);
             const size_t lds = chain_lds > p.lds_bytes ? chain_lds : p.lds_bytes;
             hipLaunchKernelGGL(net_fwd_dgrad_cae, dim3((unsigned)passes), dim3(256), lds, to_stream(stream), t);
@@ -1397,8 +1398,10 @@ int sv_convnet_fwd_mse_dgrad_supported(const sv_net_layer* layers, int n_layers,
     DnChainArgs c;
     int grid = 0;
     size_t lds = 0;
-    return plan_dgrad_chain(jobs, n_jobs, p.S, &c, &grid, &lds) == 0 && grid == (N + p.S - 1) / p.S && jobs[0].g.N == N &&
-                   lds <= kNetLdsPerBlock ? 1 : 0;
+    if (plan_dgrad_chain(jobs, n_jobs, p.S, &c, &grid, &lds)) return 0;
+    for (int j = 0; j < n_jobs; ++j)
+        if (!dn_code_in_default_stack(c.code[j])) return 0;
+    return grid == (N + p.S - 1) / p.S && jobs[0].g.N == N && lds <= kNetLdsPerBlock ? 1 : 0;
 }
 
 int sv_convnet_fwd_mse_dgrad(const sv_net_layer* layers, int n_layers, int N, int H, int W, const void* x,

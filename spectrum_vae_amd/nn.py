@@ -260,12 +260,14 @@ class CallCtx:
         done, self.dgrad_prelaunched = self.dgrad_prelaunched, None
         if done is not None and done == self.dgrad_signature(jobs):
             return
-        if len(jobs) > 1 and ops.conv2d_dgrad_chain_supported(jobs):
-            ops.conv2d_dgrad_chain(jobs)
-            return
-        for j in jobs:
-            ops.conv2d_bwd(j["g"], None, j["w"], j["dy"], j["y"], j.get("idx"), j["dx"], None, None, j["act"], j["alpha"],
-                           None)
+        for i in range(0, len(jobs), 8):  # a launch carries at most eight layers
+            part = jobs[i:i + 8]
+            if len(part) > 1 and ops.conv2d_dgrad_chain_supported(part):
+                ops.conv2d_dgrad_chain(part)
+                continue
+            for j in part:
+                ops.conv2d_bwd(j["g"], None, j["w"], j["dy"], j["y"], j.get("idx"), j["dx"], None, None, j["act"],
+                               j["alpha"], None)
 
     def buf(self, layer, role, shape, dtype=None):
         return self.pool.get((id(layer), role, self.slot), shape, self.dtype if dtype is None else dtype)

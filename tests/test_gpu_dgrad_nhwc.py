@@ -36,8 +36,19 @@ def reference(w, dy, y, idx, up, act):
     return dx
 
 
+# the 8 -> 8 channel layers of the run_model.py:164-219 grid points with conv_layer_multiplier 1 / conv_operations > 1, at the
+# three image widths, plain / pooled / behind an upsampling
+LAYERS_8TO8 = [(32, 32, 8, 8, 1, True, "elu"), (32, 32, 8, 8, 1, False, "elu"), (16, 16, 8, 8, 2, False, "elu"),
+               (16, 16, 8, 8, 1, True, "relu"), (16, 16, 8, 8, 1, False, "elu"), (8, 8, 8, 8, 2, False, "elu"),
+               (8, 8, 8, 8, 1, True, "elu"), (8, 8, 8, 8, 1, False, "elu"), (4, 4, 8, 8, 2, False, "elu")]
+
+
+def _ids(specs):
+    return [f"{s[2]}to{s[3]}at{s[0] * s[4]}{'p' if s[5] else ''}{'u' if s[4] == 2 else ''}" for s in specs]
+
+
 @pytest.mark.parametrize("n", [1, 3, 7, 130, 1024, 1027])
-@pytest.mark.parametrize("spec", LAYERS, ids=[f"{s[2]}to{s[3]}" for s in LAYERS])
+@pytest.mark.parametrize("spec", LAYERS + LAYERS_8TO8, ids=_ids(LAYERS + LAYERS_8TO8))
 def test_matches_float64(spec, n, sv_opts):
     from spectrum_vae_amd import ops
     h, w_, cin, cout, up, pooled, act = spec
@@ -54,6 +65,8 @@ def test_matches_float64(spec, n, sv_opts):
     dx = torch.full((n, h, w_, cin), 7.0, device="cuda")
     args = (g, None, torch.from_numpy(wt).cuda(), torch.from_numpy(dy).cuda(), torch.from_numpy(y).cuda(),
             torch.from_numpy(idx).cuda() if pooled else None, dx, None, None, act, 1.0, None)
+    job = dict(g=g, w=args[2], dy=args[3], y=args[4], idx=args[5], dx=dx, act=act, alpha=1.0)
+    assert ops.conv2d_dgrad_chain_supported([job, job]), "the layer is in the channel-last matrix-core family"
     ops.conv2d_bwd(*args)
     want = reference(wt, dy, y, idx, up, act)
     err = float(np.abs(dx.cpu().numpy() - want).max() / np.abs(want).max())
@@ -165,3 +178,27 @@ def test_chain_declines_what_it_does_not_cover(sv_opts):
     assert not ops.conv2d_dgrad_chain_supported([bad] + jobs[1:])
     with pytest.raises(RuntimeError, match="outside the few-channel 3x3 family"):
         ops.conv2d_dgrad_chain([bad] + jobs[1:])
+
+
+@pytest.mark.parametrize("n", [1, 5, 130, 1027])
+@pytest.mark.parametrize("spec", [s for s in LAYERS_8TO8 if s[0] * s[4] >= 16 and not s[5]], ids=lambda s: f"at{s[0] * s[4]}up{s[4]}")
+def test_forms_of_the_8_to_8_layers_agree_with_the_direct_form(spec, n, sv_opts):
+    """Pixel pairs as result columns (plain layers) and the window over the stored pixels (upsampled layers) against the
+    direct form of the same kernel: the same products, summed in another order."""
+    from spectrum_vae_amd import ops
+    h, w_, cin, cout, up, pooled, act = spec
+    H, W = h * up, w_ * up
+    rng = np.random.default_rng(3 * n + H)
+    g = ops.conv_geom(n, H, W, cin, 3, 3, 1, 1, "same", cout, (up, up))
+    wt = torch.from_numpy(rng.standard_normal((3, 3, cin, cout)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.standard_normal((n, H, W, cout)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((n, H, W, cout)).astype(np.float32)).cuda()
+    out = {}
+    for form in (1, 0):
+        sv_opts("dgrad_phase", form)
+        sv_opts("dgrad_pair", form)
+        dx = torch.full((n, h, w_, cin), 7.0, device="cuda")
+        ops.conv2d_bwd(g, None, wt, dy, y, None, dx, None, None, act, 1.0, None)
+        out[form] = dx
+    err = float((out[1] - out[0]).abs().max() / out[0].abs().max())
+    assert err < 2e-6, err
