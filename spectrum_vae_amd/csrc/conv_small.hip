@@ -12,6 +12,7 @@
 // channel-rich side, filters [KH][KW][Cin][Cout].  Covered: KH = KW = K, SH = SW = S, K a multiple of S, H = S Ho,
 // W = S Wo, pad_t = pad_l = (K - S) / 2, Cout a multiple of 4.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -216,6 +217,112 @@ __global__ __launch_bounds__(256) void convt_small_split_k(const T* __restrict__
     }
 }
 
+// ---- bf16 storage on the matrix cores.  Over the STORED pixels of the channel-rich tensor the layer is one GEMM:
+//   D[pixel][(phase r, c; image channel co)] = sum over the WIN x WIN window around the pixel and ch of
+//       x[pixel + (dh, dw) - HB][ch] * Wp[(dh, dw)][ch][(r, c, co)],
+// where Wp holds the tap that connects window position (dh, dw) with output phase (r, c) (zero where there is none: a 4x4
+// stride-2 layer reads a 3 x 3 window of which each phase uses 2 x 2).  16 pixels x 16 columns x 16 channels per
+// v_mfma_f32_16x16x16_bf16; S * S * CB <= 16 columns.  A workgroup builds Wp in LDS once (16-channel pieces copied from
+// the filter tensor) and walks 8 x 8 pixel tiles: the tile and its halo are staged as bf16 [pixel][channel] with a
+// 16-byte pad per pixel (the 8-byte operand reads of 16 pixels then cover all banks), wave v owns rows 2v, 2v + 1.
+// The layer is bound by reading x once instead of by the vector pipe's scalar filter loads.
+typedef short sm_v4s __attribute__((ext_vector_type(4)));
+typedef float sm_v4f __attribute__((ext_vector_type(4)));
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void convt_small_mfma_k(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
+                                                          const float* __restrict__ bias, __bf16* __restrict__ y, int Hs,
+                                                          int Ws, int Cs, int CB, int act, float alpha, int tiles_w,
+                                                          int tiles_per_img, int n_tiles) {
+    constexpr int Q = K / S, PT = (K - S) / 2, HB = Q - 1, HA = (S - 1 + PT) / S, WIN = HB + 1 + HA, TP = 8 + HB + HA;
+    extern __shared__ float4 smem4[];
+    unsigned char* sm = reinterpret_cast<unsigned char*>(smem4);
+    const int KK = Cs >> 4;                 // 16-channel steps
+    const int pitch = Cs * 2 + 16;          // bytes per staged pixel
+    unsigned char* wp = sm;                 // [WIN * WIN][KK][16 columns][16 channels] bf16
+    unsigned char* xt = sm + WIN * WIN * KK * 512;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ncol = S * S * CB;
+    for (int u = threadIdx.x; u < WIN * WIN * KK * 16; u += 256) {
+        const int col = u & 15, kk = (u >> 4) % KK, pos = (u >> 4) / KK;
+        const int dh = pos / WIN, dw = pos - dh * WIN;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (col < ncol) {
+            const int phase = col / CB, co = col - phase * CB;
+            const int r = phase / S, c = phase - r * S;
+            const int jh = HB + (r + PT) / S - dh, jw = HB + (c + PT) / S - dw;
+            if (jh >= 0 && jh < Q && jw >= 0 && jw < Q) {
+                const int a = (r + PT) % S + S * jh, b = (c + PT) % S + S * jw;
+                const float4* src = reinterpret_cast<const float4*>(w + (int64_t)((a * K + b) * CB + co) * Cs + 16 * kk);
+                v0 = src[0];
+                v1 = src[1];
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(wp + (size_t)u * 32);
+        dst[0] = v0;
+        dst[1] = v1;
+    }
+    const int prow = 2 * wv + (li >> 3), pcol = li & 7;
+    const int abase = (prow * TP + pcol) * pitch + lk * 8;
+    const int Hb = Hs * S, Wb = Ws * S;
+    const int pieces = Cs >> 3;  // 16-byte pieces per pixel
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_img, t = tile - n * tiles_per_img;
+        const int th0 = (t / tiles_w) * 8, tw0 = (t % tiles_w) * 8;
+        __syncthreads();  // the previous tile has been consumed (first turn: nothing to wait for but Wp's writers)
+        for (int u = threadIdx.x; u < TP * TP * pieces; u += 256) {
+            const int p = u / pieces, v = u - p * pieces;
+            const int ph = p / TP, pw = p - ph * TP;
+            const int ih = th0 + ph - HB, iw = tw0 + pw - HB;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ih >= 0 && ih < Hs && iw >= 0 && iw < Ws)
+                val = *reinterpret_cast<const float4*>(x + (((int64_t)n * Hs + ih) * Ws + iw) * Cs + 8 * v);
+            *reinterpret_cast<float4*>(xt + p * pitch + v * 16) = val;
+        }
+        __syncthreads();
+        sm_v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pos = 0; pos < WIN * WIN; ++pos) {
+            const unsigned char* ap = xt + abase + ((pos / WIN) * TP + (pos % WIN)) * pitch;
+            const unsigned char* bp = wp + ((size_t)pos * KK * 16 + li) * 32 + lk * 8;
+            for (int kk = 0; kk < KK; ++kk) {
+                const sm_v4s av = *reinterpret_cast<const sm_v4s*>(ap + kk * 32);
+                const sm_v4s bv = *reinterpret_cast<const sm_v4s*>(bp + kk * 512);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc, 0, 0, 0);
+            }
+        }
+        // the lane holds column li = (phase, co) of pixels 4 lk .. 4 lk + 3 of the wave's 16
+        if (li < ncol) {
+            const int phase = li / CB, co = li - phase * CB;
+            const int r = phase / S, c = phase - r * S;
+            const float bz = bias != nullptr ? bias[co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = 4 * lk + j;
+                const int m = th0 + 2 * wv + (p >> 3), q = tw0 + (p & 7);
+                if (m < Hs && q < Ws)
+                    y[(((int64_t)n * Hb + S * m + r) * Wb + S * q + c) * CB + co] = (__bf16)act_apply(acc[j] + bz, act, alpha);
+            }
+        }
+    }
+}
+
+template <int K, int S>
+static int launch_small_mfma(const sv_conv_geom& g, const __bf16* x, const __bf16* w, const float* bias, __bf16* y, int act,
+                             float alpha, hipStream_t st) {
+    constexpr int Q = K / S, PT = (K - S) / 2, WIN = Q + (S - 1 + PT) / S, TP = 8 + WIN - 1;
+    const int th8 = (int)ceil_div(g.Ho, 8), tw8 = (int)ceil_div(g.Wo, 8);
+    const int64_t tiles = (int64_t)g.N * th8 * tw8;
+    if (tiles > (1ll << 30)) return 1;
+    const size_t lds = (size_t)WIN * WIN * (g.Cout / 16) * 512 + (size_t)TP * TP * (g.Cout * 2 + 16);
+    if (lds > 64 * 1024) return 1;
+    const int grid = tiles < 2048 ? (int)tiles : 2048;
+    hipLaunchKernelGGL((convt_small_mfma_k<K, S>), dim3((unsigned)grid), dim3(256), lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout,
+                       g.Cin, act, alpha, tw8, th8 * tw8, (int)tiles);
+    return check_launch("convt_small_mfma");
+}
+
 template <int K, int S, typename T>
 static int launch_small_ks(const sv_conv_geom& g, const T* x, const T* w, const float* bias, T* y, int act, float alpha,
                            hipStream_t st) {
@@ -269,6 +376,14 @@ static int launch_small_any(const sv_conv_geom& g, const T* x, const T* w, const
     if (!convt_small_ok(g, 16 / (int)sizeof(T))) return 1;
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return 1;
     if (opt(OPT_SMALL_CONVT) == 0) return 1;  // the general (implicit GEMM) path, for A/B measurements
+    if constexpr (std::is_same<T, __bf16>::value) {
+        // bf16 storage, whole 16-channel steps: the matrix-core form (option value 2 keeps the vector form, for A/B runs)
+        if (opt(OPT_SMALL_CONVT) != 2 && g.SH == 2 && (g.Cout & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+            const int rc = g.KH == 4 ? launch_small_mfma<4, 2>(g, x, w, bias, y, act, alpha, st)
+                                     : launch_small_mfma<2, 2>(g, x, w, bias, y, act, alpha, st);
+            if (rc <= 0) return rc;
+        }
+    }
     if (g.KH == 4 && g.SH == 1) return launch_small_ks<4, 1, T>(g, x, w, bias, y, act, alpha, st);
     if (g.KH == 4) return launch_small_ks<4, 2, T>(g, x, w, bias, y, act, alpha, st);
     return launch_small_ks<2, 2, T>(g, x, w, bias, y, act, alpha, st);
