@@ -65,7 +65,7 @@ enum SvOpt {
     OPT_NETFWD_VALU,     // 1: every layer of the fused forward on the vector pipe
     OPT_NETFWD_S,        // > 0: cap on the samples a workgroup of the fused forward carries
     OPT_NETFWD_GRID,     // > 0: cap on the workgroups of the fused forward
-    OPT_SMALL_CONVT,     // 0: few-channel transposed convs through the implicit GEMM; 2: bf16 ones on the vector pipe
+    OPT_SMALL_CONVT,     // 0: few-channel transposed convs through the implicit GEMM; 2: on the vector pipe only; 3: f32 ones on the matrix cores at any size
     OPT_S1_MFMA,         // 0: stride-1 SAME convs outside the few-channel family through the planar kernels
     OPT_WGRAD_STORED,    // 0: kernel gradients of upsampled layers over the pixels of the upsampled image
     OPT_DGRAD_CHAIN,     // 0: sv_conv2d_dgrad_chain declines every list (one launch per layer); > 1: its workgroups

@@ -229,18 +229,23 @@ __global__ __launch_bounds__(256) void convt_small_split_k(const T* __restrict__
 typedef short sm_v4s __attribute__((ext_vector_type(4)));
 typedef float sm_v4f __attribute__((ext_vector_type(4)));
 
-template <int K, int S>
-__global__ __launch_bounds__(256) void convt_small_mfma_k(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
-                                                          const float* __restrict__ bias, __bf16* __restrict__ y, int Hs,
+template <int K, int S, typename T>
+__global__ __launch_bounds__(256) void convt_small_mfma_k(const T* __restrict__ x, const T* __restrict__ w,
+                                                          const float* __restrict__ bias, T* __restrict__ y, int Hs,
                                                           int Ws, int Cs, int CB, int act, float alpha, int tiles_w,
                                                           int tiles_per_img, int n_tiles) {
     constexpr int Q = K / S, PT = (K - S) / 2, HB = Q - 1, HA = (S - 1 + PT) / S, WIN = HB + 1 + HA, TP = 8 + HB + HA;
+    constexpr bool LP = sizeof(T) == 2;
+    constexpr int EB = sizeof(T);            // bytes per element
+    constexpr int KS = LP ? 16 : 4;          // channels per matrix instruction (v_mfma_f32_16x16x16_bf16 / _16x16x4_f32)
+    constexpr int BLK = 16 * KS * EB;        // bytes of the filter image per (window position, channel step)
+    constexpr int LB = KS / 4 * EB;          // bytes a lane reads per operand: its KS / 4 consecutive channels
     extern __shared__ float4 smem4[];
     unsigned char* sm = reinterpret_cast<unsigned char*>(smem4);
-    const int KK = Cs >> 4;                 // 16-channel steps
-    const int pitch = Cs * 2 + 16;          // bytes per staged pixel
-    unsigned char* wp = sm;                 // [WIN * WIN][KK][16 columns][16 channels] bf16
-    unsigned char* xt = sm + WIN * WIN * KK * 512;
+    const int KK = Cs / KS;                  // channel steps
+    const int pitch = Cs * EB + 16;          // bytes per staged pixel
+    unsigned char* wp = sm;                  // [WIN * WIN][KK][16 columns][KS channels]
+    unsigned char* xt = sm + WIN * WIN * KK * BLK;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int ncol = S * S * CB;
@@ -254,19 +259,19 @@ __global__ __launch_bounds__(256) void convt_small_mfma_k(const __bf16* __restri
             const int jh = HB + (r + PT) / S - dh, jw = HB + (c + PT) / S - dw;
             if (jh >= 0 && jh < Q && jw >= 0 && jw < Q) {
                 const int a = (r + PT) % S + S * jh, b = (c + PT) % S + S * jw;
-                const float4* src = reinterpret_cast<const float4*>(w + (int64_t)((a * K + b) * CB + co) * Cs + 16 * kk);
+                const float4* src = reinterpret_cast<const float4*>(w + (int64_t)((a * K + b) * CB + co) * Cs + KS * kk);
                 v0 = src[0];
-                v1 = src[1];
+                if (LP) v1 = src[1];
             }
         }
-        float4* dst = reinterpret_cast<float4*>(wp + (size_t)u * 32);
+        float4* dst = reinterpret_cast<float4*>(wp + (size_t)u * (KS * EB));
         dst[0] = v0;
-        dst[1] = v1;
+        if (LP) dst[1] = v1;
     }
     const int prow = 2 * wv + (li >> 3), pcol = li & 7;
-    const int abase = (prow * TP + pcol) * pitch + lk * 8;
+    const int abase = (prow * TP + pcol) * pitch + lk * LB;
     const int Hb = Hs * S, Wb = Ws * S;
-    const int pieces = Cs >> 3;  // 16-byte pieces per pixel
+    const int pieces = Cs * EB >> 4;  // 16-byte pieces per pixel
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int n = tile / tiles_per_img, t = tile - n * tiles_per_img;
         const int th0 = (t / tiles_w) * 8, tw0 = (t % tiles_w) * 8;
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(256) void convt_small_mfma_k(const __bf16* __restri
             const int ih = th0 + ph - HB, iw = tw0 + pw - HB;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ih >= 0 && ih < Hs && iw >= 0 && iw < Ws)
-                val = *reinterpret_cast<const float4*>(x + (((int64_t)n * Hs + ih) * Ws + iw) * Cs + 8 * v);
+                val = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(x) +
+                                                       ((((int64_t)n * Hs + ih) * Ws + iw) * Cs * EB + 16 * v));
             *reinterpret_cast<float4*>(xt + p * pitch + v * 16) = val;
         }
         __syncthreads();
@@ -285,11 +291,17 @@ __global__ __launch_bounds__(256) void convt_small_mfma_k(const __bf16* __restri
 #pragma unroll
         for (int pos = 0; pos < WIN * WIN; ++pos) {
             const unsigned char* ap = xt + abase + ((pos / WIN) * TP + (pos % WIN)) * pitch;
-            const unsigned char* bp = wp + ((size_t)pos * KK * 16 + li) * 32 + lk * 8;
+            const unsigned char* bp = wp + ((size_t)pos * KK * 16 + li) * (KS * EB) + lk * LB;
             for (int kk = 0; kk < KK; ++kk) {
-                const sm_v4s av = *reinterpret_cast<const sm_v4s*>(ap + kk * 32);
-                const sm_v4s bv = *reinterpret_cast<const sm_v4s*>(bp + kk * 512);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc, 0, 0, 0);
+                if constexpr (LP) {
+                    const sm_v4s av = *reinterpret_cast<const sm_v4s*>(ap + kk * (KS * EB));
+                    const sm_v4s bv = *reinterpret_cast<const sm_v4s*>(bp + kk * BLK);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc, 0, 0, 0);
+                } else {
+                    const float av = *reinterpret_cast<const float*>(ap + kk * (KS * EB));
+                    const float bv = *reinterpret_cast<const float*>(bp + kk * BLK);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
             }
         }
         // the lane holds column li = (phase, co) of pixels 4 lk .. 4 lk + 3 of the wave's 16
@@ -302,24 +314,25 @@ __global__ __launch_bounds__(256) void convt_small_mfma_k(const __bf16* __restri
                 const int p = 4 * lk + j;
                 const int m = th0 + 2 * wv + (p >> 3), q = tw0 + (p & 7);
                 if (m < Hs && q < Ws)
-                    y[(((int64_t)n * Hb + S * m + r) * Wb + S * q + c) * CB + co] = (__bf16)act_apply(acc[j] + bz, act, alpha);
+                    y[(((int64_t)n * Hb + S * m + r) * Wb + S * q + c) * CB + co] = (T)act_apply(acc[j] + bz, act, alpha);
             }
         }
     }
 }
 
-template <int K, int S>
-static int launch_small_mfma(const sv_conv_geom& g, const __bf16* x, const __bf16* w, const float* bias, __bf16* y, int act,
-                             float alpha, hipStream_t st) {
+// 1: this form does not take the layer (the filter image and a tile do not fit 64 KB of LDS)
+template <int K, int S, typename T>
+static int launch_small_mfma(const sv_conv_geom& g, const T* x, const T* w, const float* bias, T* y, int act, float alpha,
+                             hipStream_t st) {
     constexpr int Q = K / S, PT = (K - S) / 2, WIN = Q + (S - 1 + PT) / S, TP = 8 + WIN - 1;
     const int th8 = (int)ceil_div(g.Ho, 8), tw8 = (int)ceil_div(g.Wo, 8);
     const int64_t tiles = (int64_t)g.N * th8 * tw8;
     if (tiles > (1ll << 30)) return 1;
-    const size_t lds = (size_t)WIN * WIN * (g.Cout / 16) * 512 + (size_t)TP * TP * (g.Cout * 2 + 16);
+    const size_t lds = (size_t)WIN * WIN * g.Cout * 16 * sizeof(T) + (size_t)TP * TP * (g.Cout * sizeof(T) + 16);
     if (lds > 64 * 1024) return 1;
     const int grid = tiles < 2048 ? (int)tiles : 2048;
-    hipLaunchKernelGGL((convt_small_mfma_k<K, S>), dim3((unsigned)grid), dim3(256), lds, st, x, w, bias, y, g.Ho, g.Wo, g.Cout,
-                       g.Cin, act, alpha, tw8, th8 * tw8, (int)tiles);
+    hipLaunchKernelGGL((convt_small_mfma_k<K, S, T>), dim3((unsigned)grid), dim3(256), lds, st, x, w, bias, y, g.Ho, g.Wo,
+                       g.Cout, g.Cin, act, alpha, tw8, th8 * tw8, (int)tiles);
     return check_launch("convt_small_mfma");
 }
 
@@ -376,11 +389,15 @@ static int launch_small_any(const sv_conv_geom& g, const T* x, const T* w, const
     if (!convt_small_ok(g, 16 / (int)sizeof(T))) return 1;
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return 1;
     if (opt(OPT_SMALL_CONVT) == 0) return 1;  // the general (implicit GEMM) path, for A/B measurements
-    if constexpr (std::is_same<T, __bf16>::value) {
-        // bf16 storage, whole 16-channel steps: the matrix-core form (option value 2 keeps the vector form, for A/B runs)
-        if (opt(OPT_SMALL_CONVT) != 2 && g.SH == 2 && (g.Cout & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
-            const int rc = g.KH == 4 ? launch_small_mfma<4, 2>(g, x, w, bias, y, act, alpha, st)
-                                     : launch_small_mfma<2, 2>(g, x, w, bias, y, act, alpha, st);
+    // The matrix-core form (option value 2 keeps the vector form, for A/B runs).  bf16 storage: whole 16-channel steps,
+    // any batch.  f32 storage only on request (option value 3): the f32 matrix instruction has the vector pipe's peak and
+    // this form multiplies the zero taps too - measured equal below 256 tiles (both at the launch floor), 1.3-1.5 x
+    // faster around 1 000 tiles, 1.15-1.85 x slower at 4 000.
+    if (opt(OPT_SMALL_CONVT) != 2 && g.SH == 2 && (g.Cout % (sizeof(T) == 2 ? 16 : 4)) == 0 &&
+        (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        if (sizeof(T) == 2 || opt(OPT_SMALL_CONVT) == 3) {
+            const int rc = g.KH == 4 ? launch_small_mfma<4, 2, T>(g, x, w, bias, y, act, alpha, st)
+                                     : launch_small_mfma<2, 2, T>(g, x, w, bias, y, act, alpha, st);
             if (rc <= 0) return rc;
         }
     }

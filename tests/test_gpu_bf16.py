@@ -291,3 +291,36 @@ def test_unet_gan_step_bf16():
     # the bf16 copy the convs read follows the float32 masters
     v = gen.trainable_variables[0]
     assert torch.equal(v.data_lp.float(), v.data.to(torch.bfloat16).float())
+
+
+# ================================================================================================ few-channel transposed convs
+# (kh, s, H, W, cin, cout, n): Conv2DTranspose layers with at most 4 output channels (context_encoder.py:296-304,
+# unet.py:104-112 and the first discriminator layers' input gradients)
+SMALL_T = [(2, 2, 16, 16, 128, 3, 2), (4, 2, 16, 16, 64, 3, 2), (4, 2, 16, 16, 64, 4, 37), (4, 2, 9, 21, 48, 4, 2),
+           (2, 2, 5, 7, 32, 1, 3), (4, 2, 8, 8, 128, 2, 5)]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("cfg", SMALL_T)
+def test_small_transposed_conv_on_the_matrix_cores_agrees_with_the_vector_form(cfg, dtype, sv_opts):
+    """One GEMM over the stored pixels (zero weights where a phase has no tap) against a thread per pixel with scalar
+    filter loads: the same products in f32, summed in another order; both against the float64 restatement."""
+    from spectrum_vae_amd import ops
+    k, st, H, W, cin, cout, n = cfg
+    rng = np.random.default_rng(zlib.crc32(repr((cfg, "small")).encode()))
+    x = bf(rng.standard_normal((n, H, W, cin)))
+    w = bf(rng.standard_normal((k, k, cout, cin)) * 0.2)
+    b = rng.standard_normal(cout).astype(np.float32).astype(np.float64)
+    g = ops.deconv_geom(n, H, W, cin, k, k, st, st, "same", cout)
+    want = np_ops.act_fwd(np_ops.conv2d_transpose(x, w, b, (st, st), "same"), "tanh")
+    dev = dev16 if dtype == "bf16" else dev32
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    out = {}
+    for form in (2, 3):
+        sv_opts("small_convt", form)
+        y = torch.full((n, g.H, g.W, cout), 9.0, device="cuda", dtype=tdt)
+        ops.conv2d_transpose_fwd(g, dev(x), dev(w), dev32(b), y, "tanh", 1.0, None)
+        close(y, want, BF16_RTOL if dtype == "bf16" else F32_RTOL, f"form {form}")
+        out[form] = y.float()
+    diff = float((out[2] - out[3]).abs().max())
+    assert diff <= (8e-3 if dtype == "bf16" else 2e-6), diff  # bf16: one unit in the last place of a result near 1

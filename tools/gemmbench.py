@@ -50,7 +50,10 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="plan-time option of the library")
     a = ap.parse_args()
+    for kv in a.opt:
+        ops.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     n = a.batch
     dev = "cuda"
     PEAK = PEAKS[a.dtype]
