@@ -33,7 +33,10 @@ def timed(fn, reps=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="plan-time option of the library")
     a = ap.parse_args()
+    for kv in a.opt:
+        ops.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     print(f"{'rows':>8} {'C':>5} {'grp':>3} {'fwd us':>8} {'bwd us':>8} {'bwd+act us':>10}  MB")
     for rows, c, g in [(16384, 64, 1), (4096, 64, 1), (1024, 128, 1), (8192, 64, 1), (2048, 128, 1), (512, 256, 1),
