@@ -412,6 +412,7 @@ class Model(Layer):
                 self._refresh_lp()
             x = self._to_act(x, ctx.slot)
         ctx.loss_fold = None
+        ctx.fuse_runs = bool(self.use_net_fused)
         if training and self._reducer is not None and getattr(self._reducer, "sync_batchnorm", False):
             ctx.sync_bn = self._reducer
         ctx.bn_groups = int(bn_groups)  # the batch is this many independent BatchNorm groups (see CallCtx)

@@ -240,6 +240,8 @@ class CallCtx:
         self.dgrad_jobs: Optional[list] = None
         # the jobs the forward launch of this call already ran (Model._net_forward), as dgrad_signature() of the list
         self.dgrad_prelaunched = None
+        # Model.forward_raw: runs of fused 3x3 convs inside a Sequential may go as one launch each (Sequential.forward)
+        self.fuse_runs = False
         self.dgrad_last = None  # the list the last flush_dgrad of this call was asked to launch
 
     @staticmethod
@@ -285,6 +287,7 @@ class CallCtx:
         v.param_grads = self.param_grads
         v.sync_bn = self.sync_bn
         v.dgrad_jobs = self.dgrad_jobs
+        v.fuse_runs = self.fuse_runs
         for key, d in self.saved.items():
             nd = {}
             for name, t in d.items():
@@ -1046,8 +1049,83 @@ class Sequential(Layer):
                     pool.folded = True
         return shape
 
+    def _conv_runs(self):
+        """Maximal runs of two or more 3x3 stride-1 convs of the fused family (their folded pooling / upsampling layers
+        and rate-0 dropouts between them): {index of the first layer: (index behind the run, its conv layers)}."""
+        runs = self.__dict__.get("_runs")
+        if runs is not None:
+            return runs
+        runs, i, n = {}, 0, len(self.layers)
+        while i < n:
+            convs, j, last = [], i, i
+            while j < n:
+                l = self.layers[j]
+                if (type(l) is Conv2D and l.fused_bwd and l.kernel_size == (3, 3) and l.up[0] == l.up[1]
+                        and l.strides == (1, 1) and l.padding == "same"):
+                    convs.append(l)
+                    last = j + 1
+                    if l.pool is not None:  # its folded pooling layer belongs to the run
+                        last = j + 2
+                        j += 1
+                elif not ((isinstance(l, UpSampling2D) and l.folded) or (isinstance(l, Dropout) and l.rate == 0)):
+                    break
+                j += 1
+            if len(convs) >= 2:
+                # a folded upsampling in front of the first conv is inside the run; one behind the last conv is not
+                runs[i] = (last, convs)
+                i = last
+            else:
+                i += 1
+        self.__dict__["_runs"] = runs
+        return runs
+
+    def _run_forward(self, ctx, x, convs):
+        """The convs of a run as one launch (ops.convnet_fwd); None when the library has no such launch for them."""
+        n = x.shape[0]
+        owner = convs[0].kernel.owner
+        if owner is None or any(l.kernel.owner is not owner for l in convs):
+            return None
+        plans = self.__dict__.setdefault("_run_plans", {})
+        key = (id(convs[0]), n, ctx.slot if not isinstance(ctx.slot, int) else "train%d" % ctx.slot)
+        plan = plans.get(key)
+        if plan is None and any(ops.conv2d_s1_mfma_bwd(l.geom(n)) for l in convs):
+            plan = plans[key] = False  # wide layers: their own matrix-core kernels beat the launch that carries a whole run
+        if plan is None:
+            specs, bufs = [], []
+            for l in convs:
+                ho, wo, cout = l.output_shape_
+                shp = (n, ho // 2, wo // 2, cout) if l.pool is not None else (n, ho, wo, cout)
+                y = ctx.buf(l, "y", shp)
+                idx = ctx.buf(l, "idx", shp, torch.uint8) if l.pool is not None else None
+                specs.append(dict(Cin=l.input_shape_[2], Cout=cout, K=3, up=l.up[0], pool=int(l.pool is not None),
+                                  act=l.act, alpha=l.alpha, w_off=l.kernel.offset,
+                                  b_off=l.bias.offset if l.bias is not None else -1, y=y, idx=idx))
+                bufs.append((l, y, idx))
+            arr = ops.net_layers(specs)
+            h, w = convs[0].input_shape_[0], convs[0].input_shape_[1]
+            plan = plans[key] = (arr, bufs, h, w) if ops.convnet_supported(arr, n, h, w) else False
+        if plan is False:
+            return None
+        arr, bufs, h, w = plan
+        ops.convnet_fwd(arr, n, h, w, x, owner._params)
+        prev = x
+        for l, y, idx in bufs:
+            if ctx.training:
+                ctx.saved[id(l)] = {"x": prev, "y": y, "idx": idx} if idx is not None else {"x": prev, "y": y}
+            prev = y
+        return prev
+
     def forward(self, ctx, x):
-        for l in self.layers:
+        runs = self._conv_runs() if (ctx.fuse_runs and not ctx.lp and self.built) else {}
+        skip_to = 0
+        for i, l in enumerate(self.layers):
+            if i < skip_to:
+                continue
+            if i in runs and ctx.input_mask is None and x.dtype == torch.float32:
+                y = self._run_forward(ctx, x, runs[i][1])
+                if y is not None:
+                    x, skip_to = y, runs[i][0]
+                    continue
             if ctx.input_mask is not None and type(l) is not Conv2D and not isinstance(l, (Sequential, InputLayer)):
                 # a pending input mask (Model.forward_raw) and a first layer that cannot read through it: one pass
                 mask, ctx.input_mask = ctx.input_mask, None
