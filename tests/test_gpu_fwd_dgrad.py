@@ -104,3 +104,28 @@ def test_fit_with_the_chain_in_the_forward_launch_equals_fit_with_separate_launc
     for mode in ("chain", "layers"):
         assert np.array_equal(res["fused"][0], res[mode][0])
         assert np.array_equal(res["fused"][1], res[mode][1])
+
+
+def test_conv_runs_around_a_dense_bottleneck_go_as_one_forward_launch_each():
+    """CAEPadded with latent_dimensions > 0 (the constructor default of autoencoder.py:410-428) is not one conv chain: its
+    encoder and decoder convs are runs inside the Sequentials, each issued as one forward launch; predictions, losses and
+    weights equal the layer-by-layer form's to float32 round-off (other kernels, another summation order)."""
+    from spectrum_vae_amd import autoencoder, losses
+    from spectrum_vae_amd.optimizers import Adam
+    x = data(96, seed=47)
+    res = {}
+    for fused in (True, False):
+        model = autoencoder.CAEPadded(**dict(RUN_MODEL_DEFAULTS, latent_dimensions=8, fc_layers=1, fc_layer_size=32, dropout=0.0))
+        model.build((None, 32, 32, 3))
+        model._materialize()
+        model.use_net_fused = fused
+        assert model._conv_chain() is None
+        runs = model.encoder._conv_runs()
+        assert len(runs) == 1 and len(next(iter(runs.values()))[1]) == 3
+        model.compile(optimizer=Adam(1e-3), loss=losses.MeanSquaredError())
+        h = model.fit(x, x, epochs=2, batch_size=32, shuffle=False, verbose=0)
+        res[fused] = (np.array(h.history["loss"]), model._params.cpu().numpy().copy(), model.predict(x[:8]))
+    assert bool(model.encoder.__dict__.get("_run_plans")) is False and res[True][0].shape == res[False][0].shape
+    assert np.allclose(res[True][0], res[False][0], rtol=1e-5)
+    assert np.allclose(res[True][2], res[False][2], rtol=1e-4, atol=1e-5)
+    assert np.abs(res[True][1] - res[False][1]).max() < 1e-4

@@ -28,6 +28,9 @@ POINTS = {
                                  kernel_size=5, batch_norm=False, activation="relu"),
     "i8_l4_m2_o1_k3": dict(initial_filters=8, conv_layers=4, conv_layer_multiplier=2, conv_operations=1, kernel_size=3,
                            batch_norm=False, activation="elu"),
+    # thirteen few-channel layers: the 8 -> 8 input gradients of the channel-last family, issued as two chain launches
+    "i8_l3_m1_o2_k3": dict(initial_filters=8, conv_layers=3, conv_layer_multiplier=1, conv_operations=2, kernel_size=3,
+                           batch_norm=False, activation="elu"),
     "i16_l4_m2_o2_k3_bn": dict(initial_filters=16, conv_layers=4, conv_layer_multiplier=2, conv_operations=2,
                                kernel_size=3, batch_norm=True, activation="elu"),
 }
