@@ -22,8 +22,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# Before the HIP runtime is loaded (it reads the variable then): the secondary GAN steps fork two streams inside their
+# recorded graphs, which only run side by side on hardware queues of their own (HIP's default is 4 per process, where
+# the branch usually shares the launch stream's queue).  The headline step is one stream and does not depend on it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

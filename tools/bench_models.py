@@ -14,6 +14,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# before the HIP runtime is loaded (it reads the variable then): the steps' two streams on hardware queues of their own
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
